@@ -1,0 +1,234 @@
+/* rpt.h — C ABI of the MI355X-native path-tracing integrator.
+ *
+ * This is the drop-in boundary for ONE hot path of markusmoenig/rust-pathtracer:
+ *     Tracer::render(&mut self, buffer: &mut ColorBuffer)
+ *         rust-pathtracer/src/tracer.rs:22-123   (rayon scanline loop + bounce loop)
+ * and its callees (direct_light :126, sample_light :173, Disney BSDF :223-626,
+ * Scene::sample_lights scene.rs:36-86, Pinhole::gen_ray camera/pinhole.rs:38-60,
+ * State/Material finalize globals.rs:50-62 / material.rs:117-131) plus the workload
+ * scene renderer/src/analytical.rs:13-204.
+ *
+ * The reference has no FFI of its own (the path is a plain Rust method), so these
+ * entry points are what a Rust `extern "C"` block for that method binds; the
+ * binding is shown in INTEGRATION.md and rust/gpu_tracer.rs.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative rpt_status; nothing unwinds
+ *     across the boundary (the reference's render() cannot fail: tracer.rs:22);
+ *   - plain pointers and sizes only; a context is used by one thread at a time
+ *     (render takes &mut self in the reference: tracer.rs:22);
+ *   - all arithmetic is f32 (rust-pathtracer/src/lib.rs:6).
+ */
+#ifndef RPT_H
+#define RPT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RPT_ABI_VERSION 1u
+
+typedef enum rpt_status {
+    RPT_OK              =  0,
+    RPT_ERR_INVALID_ARG = -1,
+    RPT_ERR_NO_DEVICE   = -2,   /* no usable gfx950 device: the product has no CPU fallback */
+    RPT_ERR_HIP         = -3,   /* a HIP runtime call failed; see rpt_last_error */
+    RPT_ERR_NO_SCENE    = -4,
+    RPT_ERR_UNSUPPORTED = -5
+} rpt_status;
+
+/* ---- scene as data ---------------------------------------------------------
+ * The reference's Scene is code (trait callbacks, scene.rs:5-90) and cannot run
+ * on the device, so the scene crosses the boundary as plain data.  The closed set
+ * below covers renderer/src/analytical.rs exactly, including its material
+ * layering: closest_hit overwrites fields of state.material each time a primitive
+ * is accepted (analytical.rs:56-58, 82-85, 115-116), so a material is a PATCH —
+ * a field mask plus values — applied over Material::new() (material.rs:82-114) in
+ * primitive order.                                                             */
+
+enum {                                /* rpt_material.mask bits */
+    RPT_MAT_RGB             = 1u << 0,
+    RPT_MAT_EMISSION        = 1u << 1,
+    RPT_MAT_ANISOTROPIC     = 1u << 2,
+    RPT_MAT_METALLIC        = 1u << 3,
+    RPT_MAT_ROUGHNESS       = 1u << 4,
+    RPT_MAT_SUBSURFACE      = 1u << 5,
+    RPT_MAT_SPECULAR_TINT   = 1u << 6,
+    RPT_MAT_SHEEN           = 1u << 7,
+    RPT_MAT_SHEEN_TINT      = 1u << 8,
+    RPT_MAT_CLEARCOAT       = 1u << 9,
+    RPT_MAT_CLEARCOAT_GLOSS = 1u << 10,
+    RPT_MAT_SPEC_TRANS      = 1u << 11,
+    RPT_MAT_IOR             = 1u << 12,
+    RPT_MAT_ALL             = (1u << 13) - 1u
+};
+
+enum {                                /* rpt_material.proc_kind */
+    RPT_PROC_NONE        = 0,
+    /* rgb = checker(dir.x/dir.y*s + o, dir.z/dir.y*s + o) ? a : b   (analytical.rs:107-115);
+     * proc_params = {s, o, a, b}.  Sets rgb regardless of RPT_MAT_RGB.          */
+    RPT_PROC_CHECKER_DIR = 1
+};
+
+typedef struct rpt_material {         /* user-set fields of material.rs:48-78 that the tracer reads */
+    uint32_t mask;
+    uint32_t proc_kind;
+    float rgb[3];
+    float emission[3];
+    float anisotropic;
+    float metallic;
+    float roughness;
+    float subsurface;
+    float specular_tint;
+    float sheen;
+    float sheen_tint;
+    float clearcoat;
+    float clearcoat_gloss;
+    float spec_trans;
+    float ior;
+    float proc_params[4];
+} rpt_material;
+
+typedef struct rpt_sphere {           /* analytical.rs:166-190 */
+    float    center[3];
+    float    radius;
+    uint32_t material;                /* index into rpt_scene_desc.materials */
+} rpt_sphere;
+
+typedef struct rpt_plane {            /* analytical.rs:193-204 generalised: dot(point - o, n) / dot(n, d) */
+    float    normal[3];
+    float    point[3];
+    float    min_denom;               /* reject |dot(n,d)| <= min_denom (1e-4 in the reference) */
+    uint32_t material;
+} rpt_plane;
+
+enum { RPT_LIGHT_RECTANGULAR = 0, RPT_LIGHT_SPHERICAL = 1, RPT_LIGHT_DISTANT = 2 };  /* globals.rs:69-73 */
+
+typedef struct rpt_light {            /* globals.rs:76-84; only SPHERICAL is sampled (tracer.rs:175-217) */
+    uint32_t type;
+    float    position[3];
+    float    emission[3];
+    float    u[3];
+    float    v[3];
+    float    radius;
+    float    area;                    /* 4*pi*r*r for a spherical light (light.rs:22) */
+} rpt_light;
+
+typedef struct rpt_camera {           /* camera/pinhole.rs:6-25 */
+    float origin[3];
+    float center[3];
+    float fov_deg;
+} rpt_camera;
+
+enum {
+    RPT_BG_CONSTANT   = 0,            /* colour_a * scale */
+    /* t = 0.5*(dir.y+1); to_linear((1-t)*colour_a + t*colour_b) * scale
+     * (analytical.rs:28-32, to_linear = powf(gamma) per channel, scene.rs:32-34) */
+    RPT_BG_GRADIENT_Y = 1
+};
+
+typedef struct rpt_background {
+    uint32_t kind;
+    float    colour_a[3];
+    float    colour_b[3];
+    float    gamma;
+    float    scale;
+} rpt_background;
+
+enum {                                /* rpt_scene_desc.flags */
+    /* Scene::any_hit honours max_dist.  OFF reproduces analytical.rs:130, which
+     * ignores it (anything along the shadow ray occludes). */
+    RPT_SCENE_ANYHIT_USES_MAX_DIST = 1u << 0
+};
+
+typedef struct rpt_scene_desc {
+    uint32_t abi_version;             /* RPT_ABI_VERSION */
+    uint32_t flags;
+    rpt_camera     camera;
+    rpt_background background;
+    float    eps;                     /* Tracer.eps = 0.005 (tracer.rs:16) */
+    uint32_t max_depth;               /* Scene::recursion_depth() = 4 (scene.rs:28-30) */
+    uint32_t n_spheres;   const rpt_sphere*   spheres;    /* tested first, in order */
+    uint32_t n_planes;    const rpt_plane*    planes;     /* then planes, in order  */
+    uint32_t n_lights;    const rpt_light*    lights;     /* then Scene::sample_lights */
+    uint32_t n_materials; const rpt_material* materials;
+} rpt_scene_desc;
+
+/* Fill `out` with renderer/src/analytical.rs's AnalyticalScene (2 spheres, plane,
+ * 1 spherical light, Pinhole defaults).  The arrays it points to are static.  */
+int rpt_scene_analytical(rpt_scene_desc* out);
+
+/* ---- render flags ---------------------------------------------------------- */
+enum {
+    RPT_RENDER_DEFAULT = 0u
+};
+
+/* ---- context --------------------------------------------------------------- */
+typedef struct rpt_ctx rpt_ctx;
+
+/* Create a context on HIP device `device_id` (must be gfx950).  Replaces
+ * Tracer::new (tracer.rs:13-19) together with rpt_upload_scene. */
+int rpt_create(rpt_ctx** out, int device_id);
+void rpt_destroy(rpt_ctx* ctx);
+const char* rpt_last_error(const rpt_ctx* ctx);   /* valid until the next call on ctx; ctx may be NULL */
+uint32_t rpt_abi_version(void);
+
+/* Copy the scene into the context (Tracer owns its scene: tracer.rs:8). */
+int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* scene);
+
+/* Tracer::render (tracer.rs:22-123) on a HOST ColorBuffer.
+ *   pixels      in/out, width*height*4 f32, RGBA, row 0 = top (buffer.rs:6-26)
+ *   frames_done ColorBuffer.frames before the call; the caller adds `spp` afterwards
+ *   spp         number of render() calls to fold into this one; spp = 1 is exactly
+ *               one reference render(); spp = S is bit-identical to S calls
+ *   seed        RNG seed (the reference's thread_rng, tracer.rs:44, is unseedable)
+ * Blocks until `pixels` holds the result. */
+int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height,
+               uint64_t frames_done, uint32_t spp, uint64_t seed, uint32_t flags);
+
+/* Same on a DEVICE-resident buffer, asynchronously on `stream` (a hipStream_t, or
+ * NULL for the context's stream).  With world > 1 the image is row-tiled: rows are
+ * dealt in blocks of `tile_rows` rows, block b to rank b % world, and `pixels` is
+ * this rank's COMPACT tile buffer (rpt_tile_row_count(...) rows of `width` RGBA
+ * pixels).  The RNG is keyed by the global pixel, so the image does not depend on
+ * world.  world = 1, rank = 0 renders the whole image in place. */
+int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t height,
+                      uint64_t frames_done, uint32_t spp, uint64_t seed, uint32_t flags,
+                      uint32_t tile_rows, uint32_t rank, uint32_t world, void* stream);
+
+/* Number of image rows rank `rank` owns under the cyclic row-block tiling. */
+uint32_t rpt_tile_row_count(uint32_t height, uint32_t tile_rows, uint32_t rank, uint32_t world);
+/* Global image row of local row `local_row` of rank `rank`. */
+uint32_t rpt_tile_global_row(uint32_t local_row, uint32_t tile_rows, uint32_t rank, uint32_t world);
+
+/* Scatter a rank-major concatenation of compact tiles (what an all-gather of the
+ * per-rank tile buffers yields, each padded to `rows_padded` rows) into the full
+ * top-down image, on the device. */
+int rpt_untile_device(rpt_ctx* ctx, const float* gathered_dev, float* image_dev,
+                      uint32_t width, uint32_t height, uint32_t tile_rows,
+                      uint32_t world, uint32_t rows_padded, void* stream);
+
+/* ColorBuffer::convert_to_u8 (buffer.rs:55-64): powf(0.4545)*255 saturating cast to
+ * u8 for r,g,b; a*255 for alpha.  Device buffers; the step that follows render in the
+ * reference's only caller (renderer/src/main.rs:118-122). */
+int rpt_convert_to_u8_device(rpt_ctx* ctx, const float* pixels_dev, uint8_t* out_dev,
+                             uint32_t width, uint32_t height, void* stream);
+
+int rpt_synchronize(rpt_ctx* ctx, void* stream);
+
+/* ---- test probes ------------------------------------------------------------
+ * Evaluate one device function over arrays (device pointers), so tests can compare
+ * leaf functions with the oracle bit for bit.  Not part of the drop-in surface.  */
+enum {
+    RPT_PROBE_SIN = 0, RPT_PROBE_COS = 1, RPT_PROBE_LOG2 = 2, RPT_PROBE_POW = 3,
+    RPT_PROBE_DIV = 4, RPT_PROBE_SQRT = 5, RPT_PROBE_RNG = 6
+};
+int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b_dev,
+                   float* out_dev, uint64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RPT_H */

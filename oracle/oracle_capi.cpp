@@ -1,0 +1,298 @@
+// oracle_capi.cpp — C entry points of the CPU oracle (ctypes-friendly).
+// TEST INFRASTRUCTURE: see the header of rpt_oracle.hpp.  PARITY UNPINNED (ibid.).
+#include "rpt_oracle.hpp"
+
+#include <cstdio>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+using namespace rpt_oracle;
+
+namespace {
+
+// renderer/src/analytical.rs:13-22 (light), :41-58 / :70-85 / :101-116 (primitives
+// and their material writes), camera/pinhole.rs:14-25 (Pinhole::new), tracer.rs:16
+// (eps), scene.rs:28-30 (depth) — written out independently of the product's
+// rpt_scene_analytical(); tests compare the two byte for byte.
+rpt_sphere g_spheres[2];
+rpt_plane g_planes[1];
+rpt_light g_lights[1];
+rpt_material g_materials[3];
+
+void build_analytical(rpt_scene_desc* out)
+{
+    std::memset(out, 0, sizeof(*out));
+    std::memset(g_spheres, 0, sizeof(g_spheres));
+    std::memset(g_planes, 0, sizeof(g_planes));
+    std::memset(g_lights, 0, sizeof(g_lights));
+    std::memset(g_materials, 0, sizeof(g_materials));
+
+    // left sphere: analytical.rs:41, :56-58
+    g_spheres[0].center[0] = -1.1f; g_spheres[0].radius = 1.0f; g_spheres[0].material = 0;
+    g_materials[0].mask = RPT_MAT_RGB | RPT_MAT_ROUGHNESS | RPT_MAT_METALLIC;
+    g_materials[0].rgb[0] = g_materials[0].rgb[1] = g_materials[0].rgb[2] = 1.0f;
+    g_materials[0].roughness = 0.05f;
+    g_materials[0].metallic = 1.0f;
+    // right sphere: analytical.rs:70, :82-85
+    g_spheres[1].center[0] = 1.1f; g_spheres[1].radius = 1.0f; g_spheres[1].material = 1;
+    g_materials[1].mask = RPT_MAT_RGB | RPT_MAT_CLEARCOAT | RPT_MAT_CLEARCOAT_GLOSS | RPT_MAT_ROUGHNESS;
+    g_materials[1].rgb[0] = 1.0f; g_materials[1].rgb[1] = 0.186f; g_materials[1].rgb[2] = 0.0f;
+    g_materials[1].clearcoat = 1.0f;
+    g_materials[1].clearcoat_gloss = 1.0f;
+    g_materials[1].roughness = 0.1f;
+    // plane y = -1: analytical.rs:194-198, :105-116
+    g_planes[0].normal[1] = 1.0f; g_planes[0].point[1] = -1.0f; g_planes[0].min_denom = 0.0001f; g_planes[0].material = 2;
+    g_materials[2].mask = RPT_MAT_ROUGHNESS;
+    g_materials[2].roughness = 1.0f;
+    g_materials[2].proc_kind = RPT_PROC_CHECKER_DIR;
+    g_materials[2].proc_params[0] = 0.5f; g_materials[2].proc_params[1] = 100.0f;
+    g_materials[2].proc_params[2] = 0.25f; g_materials[2].proc_params[3] = 0.1f;
+    // light: analytical.rs:15-16, light.rs:13-28
+    g_lights[0].type = RPT_LIGHT_SPHERICAL;
+    g_lights[0].position[0] = 3.0f; g_lights[0].position[1] = 2.0f; g_lights[0].position[2] = 2.0f;
+    g_lights[0].emission[0] = g_lights[0].emission[1] = g_lights[0].emission[2] = 3.0f;
+    g_lights[0].radius = 1.0f;
+    g_lights[0].area = 4.0f * PI_F * g_lights[0].radius * g_lights[0].radius;
+
+    out->abi_version = RPT_ABI_VERSION;
+    out->flags = 0;                                       // any_hit ignores max_dist: analytical.rs:130
+    out->camera.origin[2] = 3.0f;                         // pinhole.rs:16-17
+    out->camera.fov_deg = 80.0f;                          // pinhole.rs:23
+    out->background.kind = RPT_BG_GRADIENT_Y;             // analytical.rs:28-32
+    out->background.colour_a[0] = out->background.colour_a[1] = out->background.colour_a[2] = 1.0f;
+    out->background.colour_b[0] = 0.5f; out->background.colour_b[1] = 0.7f; out->background.colour_b[2] = 1.0f;
+    out->background.gamma = 2.2f;                         // scene.rs:33
+    out->background.scale = 0.5f;
+    out->eps = 0.005f;                                    // tracer.rs:16
+    out->max_depth = 4;                                   // scene.rs:29
+    out->n_spheres = 2; out->spheres = g_spheres;
+    out->n_planes = 1; out->planes = g_planes;
+    out->n_lights = 1; out->lights = g_lights;
+    out->n_materials = 3; out->materials = g_materials;
+}
+
+Material material_from_array(const float* m)
+{
+    Material mat;
+    mat.rgb = F3(m[0], m[1], m[2]); mat.emission = F3(m[3], m[4], m[5]);
+    mat.anisotropic = m[6]; mat.metallic = m[7]; mat.roughness = m[8]; mat.subsurface = m[9];
+    mat.specular_tint = m[10]; mat.sheen = m[11]; mat.sheen_tint = m[12]; mat.clearcoat = m[13];
+    mat.clearcoat_gloss = m[14]; mat.spec_trans = m[15]; mat.ior = m[16];
+    return mat;
+}
+
+}  // namespace
+
+extern "C" {
+
+int oracle_scene_analytical(rpt_scene_desc* out) { build_analytical(out); return 0; }
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+const char* oracle_build_info(void)
+{
+#if defined(RPT_OPCOUNT)
+    return "oracle: opcount";
+#elif defined(RPT_ORACLE_LIBM)
+    return "oracle: glibc libm";
+#else
+    return "oracle: strict math";
+#endif
+}
+
+// Tracer::render for spp frames, rows [row_begin,row_end) (0,height = whole image).
+int oracle_render(const rpt_scene_desc* desc, float* pixels, uint32_t width, uint32_t height, uint64_t frames_done,
+                  uint32_t spp, uint64_t seed, uint32_t row_begin, uint32_t row_end, int nthreads)
+{
+    if (!desc || !pixels || width == 0 || height == 0 || row_end > height || row_begin > row_end) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    Scene scene(*desc);
+    Tracer tracer(scene);
+    tracer.render(pixels, width, height, frames_done, spp, seed, row_begin, row_end);
+    return 0;
+}
+
+// Radiance of single pixel-samples (no accumulation): out[3*k..] for k-th (col,row,frame).
+int oracle_sample_pixels(const rpt_scene_desc* desc, const uint32_t* cols, const uint32_t* rows, const uint64_t* frames,
+                         uint64_t n, uint32_t width, uint32_t height, uint64_t seed, float* out)
+{
+    Scene scene(*desc);
+    Tracer tracer(scene);
+    for (uint64_t k = 0; k < n; ++k) {
+        F3 r = tracer.sample_pixel(cols[k], rows[k], width, height, frame_key(seed, frames[k]));
+        out[3 * k + 0] = raw(r.x); out[3 * k + 1] = raw(r.y); out[3 * k + 2] = raw(r.z);
+    }
+    return 0;
+}
+
+// Count floating-point operations over a render (RPT_OPCOUNT build; zeros otherwise).
+// counts = {add, mul, div, sqrt, transcendental, compare}
+int oracle_opcount(const rpt_scene_desc* desc, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t* counts)
+{
+    for (int i = 0; i < 6; ++i) counts[i] = 0;
+#ifdef RPT_OPCOUNT
+#ifdef _OPENMP
+    omp_set_num_threads(1);
+#endif
+    g_ops = OpCounts();
+    std::vector<float> px((size_t)width * height * 4, 0.0f);
+    Scene scene(*desc);
+    Tracer tracer(scene);
+    tracer.render(px.data(), width, height, 0, spp, seed, 0, height);
+    counts[0] = g_ops.add; counts[1] = g_ops.mul; counts[2] = g_ops.div;
+    counts[3] = g_ops.sqrt; counts[4] = g_ops.transc; counts[5] = g_ops.cmp;
+#else
+    (void)desc; (void)width; (void)height; (void)spp; (void)seed;
+#endif
+    return 0;
+}
+
+// ---- leaf probes (known-answer tests) ---------------------------------------
+int oracle_sphere(const float* o, const float* d, const float* c, float radius, float* t)
+{
+    F tt(0.0f);
+    bool hit = sphere(Ray(F3(o[0], o[1], o[2]), F3(d[0], d[1], d[2])), F3(c[0], c[1], c[2]), radius, tt);
+    *t = raw(tt);
+    return hit ? 1 : 0;
+}
+int oracle_plane(const float* o, const float* d, const rpt_plane* p, float* t)
+{
+    F tt(0.0f);
+    bool hit = plane(Ray(F3(o[0], o[1], o[2]), F3(d[0], d[1], d[2])), *p, tt);
+    *t = raw(tt);
+    return hit ? 1 : 0;
+}
+float oracle_power_heuristic(float a, float b) { return raw(Tracer::power_heuristic(a, b)); }
+float oracle_schlick_fresnel(float u) { return raw(Tracer::schlick_fresnel(u)); }
+float oracle_dielectric_fresnel(float c, float eta) { return raw(Tracer::dielectric_fresnel(c, eta)); }
+float oracle_gtr1(float ndoth, float a) { return raw(Tracer::gtr1(ndoth, a)); }
+float oracle_smithg(float ndotv, float alphag) { return raw(Tracer::smithg(ndotv, alphag)); }
+float oracle_gtr2aniso(float ndoth, float hx, float hy, float ax, float ay) { return raw(Tracer::gtr2aniso(ndoth, hx, hy, ax, ay)); }
+float oracle_luminance(const float* c) { return raw(Tracer::luminance(F3(c[0], c[1], c[2]))); }
+
+// Material::new + field overrides + finalize; m = 17 user-set floats (rgb, emission,
+// anisotropic, metallic, roughness, subsurface, specular_tint, sheen, sheen_tint,
+// clearcoat, clearcoat_gloss, spec_trans, ior); out = {roughness, clearcoat_roughness, ax, ay}
+void oracle_material_defaults(float* m)
+{
+    Material mat;
+    float v[17] = {raw(mat.rgb.x), raw(mat.rgb.y), raw(mat.rgb.z), raw(mat.emission.x), raw(mat.emission.y), raw(mat.emission.z),
+                   raw(mat.anisotropic), raw(mat.metallic), raw(mat.roughness), raw(mat.subsurface), raw(mat.specular_tint),
+                   raw(mat.sheen), raw(mat.sheen_tint), raw(mat.clearcoat), raw(mat.clearcoat_gloss), raw(mat.spec_trans), raw(mat.ior)};
+    std::memcpy(m, v, sizeof(v));
+}
+void oracle_material_finalize(const float* m, float* out)
+{
+    Material mat = material_from_array(m);
+    mat.finalize();
+    out[0] = raw(mat.roughness); out[1] = raw(mat.clearcoat_roughness); out[2] = raw(mat.ax); out[3] = raw(mat.ay);
+}
+
+// Pinhole::gen_ray: cam = {origin[3], center[3], fov}; out = {origin[3], direction[3]}
+void oracle_gen_ray(const float* cam, float px, float py, float offx, float offy, float width, float height, float* out)
+{
+    Pinhole p;
+    p.origin = F3(cam[0], cam[1], cam[2]); p.center = F3(cam[3], cam[4], cam[5]); p.fov = cam[6];
+    Ray r = p.gen_ray(px, py, offx, offy, width, height);
+    out[0] = raw(r.origin.x); out[1] = raw(r.origin.y); out[2] = raw(r.origin.z);
+    out[3] = raw(r.direction.x); out[4] = raw(r.direction.y); out[5] = raw(r.direction.z);
+}
+
+// disney_eval on a finalized material: returns f[3], pdf in out[0..3]
+void oracle_disney_eval(const float* m, float eta, const float* v, const float* n, const float* l, float* out)
+{
+    rpt_scene_desc d; build_analytical(&d);
+    Scene scene(d);
+    Tracer tr(scene);
+    State st;
+    st.material = material_from_array(m);
+    st.material.finalize();
+    st.eta = eta;
+    F pdf(0.0f);
+    F3 f = tr.disney_eval(st, F3(v[0], v[1], v[2]), F3(n[0], n[1], n[2]), F3(l[0], l[1], l[2]), pdf);
+    out[0] = raw(f.x); out[1] = raw(f.y); out[2] = raw(f.z); out[3] = raw(pdf);
+}
+
+// disney_sample with an explicit RNG position: out = {f[3], l[3], pdf, draws_used}
+void oracle_disney_sample(const float* m, float eta, const float* v, const float* n, const float* l_stale,
+                          uint32_t fkey, uint32_t pixel, uint32_t counter, float* out)
+{
+    rpt_scene_desc d; build_analytical(&d);
+    Scene scene(d);
+    Tracer tr(scene);
+    State st;
+    st.material = material_from_array(m);
+    st.material.finalize();
+    st.eta = eta;
+    Rng rng(fkey, pixel);
+    rng.counter = counter;
+    F3 l(l_stale[0], l_stale[1], l_stale[2]);
+    F pdf(0.0f);
+    F3 f = tr.disney_sample(st, F3(v[0], v[1], v[2]), F3(n[0], n[1], n[2]), l, pdf, rng);
+    out[0] = raw(f.x); out[1] = raw(f.y); out[2] = raw(f.z);
+    out[3] = raw(l.x); out[4] = raw(l.y); out[5] = raw(l.z);
+    out[6] = raw(pdf); out[7] = (float)(rng.counter - counter);
+}
+
+// RNG stream: first n u32 draws of (seed, frame, pixel)
+void oracle_rng_u32(uint64_t seed, uint64_t frame, uint32_t pixel, uint32_t n, uint32_t* out)
+{
+    Rng rng(frame_key(seed, frame), pixel);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng.next_u32();
+}
+void oracle_rng_f32(uint64_t seed, uint64_t frame, uint32_t pixel, uint32_t n, float* out)
+{
+    Rng rng(frame_key(seed, frame), pixel);
+    for (uint32_t i = 0; i < n; ++i) out[i] = raw(rng.gen());
+}
+
+// element-wise math through the oracle's f_* layer (strict or glibc per build)
+// fn: 0 sin, 1 cos, 2 log2, 3 pow(a,b), 4 a/b, 5 sqrt, 7 tan
+void oracle_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        switch (fn) {
+        case 0: out[i] = raw(f_sin(a[i])); break;
+        case 1: out[i] = raw(f_cos(a[i])); break;
+        case 2: out[i] = raw(f_log2(a[i])); break;
+        case 3: out[i] = raw(f_powf(a[i], b[i])); break;
+        case 4: out[i] = a[i] / b[i]; break;
+        case 5: out[i] = std::sqrt(a[i]); break;
+        case 7: out[i] = raw(f_tan(a[i])); break;
+        default: out[i] = 0.0f;
+        }
+    }
+}
+
+// ColorBuffer::convert_to_u8, buffer.rs:55-64: (p.powf(0.4545) * 255.0) as u8 for
+// r,g,b and (a * 255.0) as u8; Rust's `as u8` saturates and maps NaN to 0.
+static inline uint8_t as_u8(float x)
+{
+    if (!(x == x)) return 0;
+    if (x <= 0.0f) return 0;
+    if (x >= 255.0f) return 255;
+    return (uint8_t)x;
+}
+void oracle_convert_to_u8(const float* pixels, uint8_t* frame, uint32_t width, uint32_t height)
+{
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) {
+            size_t o = (size_t)x * 4 + (size_t)y * width * 4;
+            frame[o + 0] = as_u8(raw(f_powf(pixels[o + 0], 0.4545f) * F(255.0f)));
+            frame[o + 1] = as_u8(raw(f_powf(pixels[o + 1], 0.4545f) * F(255.0f)));
+            frame[o + 2] = as_u8(raw(f_powf(pixels[o + 2], 0.4545f) * F(255.0f)));
+            frame[o + 3] = as_u8(pixels[o + 3] * 255.0f);
+        }
+}
+
+}  // extern "C"

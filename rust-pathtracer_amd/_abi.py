@@ -1,0 +1,109 @@
+"""ctypes mirror of include/rpt.h (the C ABI).  Plain data only."""
+import ctypes as C
+
+RPT_ABI_VERSION = 1
+
+RPT_OK = 0
+RPT_ERR_INVALID_ARG = -1
+RPT_ERR_NO_DEVICE = -2
+RPT_ERR_HIP = -3
+RPT_ERR_NO_SCENE = -4
+RPT_ERR_UNSUPPORTED = -5
+
+RPT_MAT_RGB = 1 << 0
+RPT_MAT_EMISSION = 1 << 1
+RPT_MAT_ANISOTROPIC = 1 << 2
+RPT_MAT_METALLIC = 1 << 3
+RPT_MAT_ROUGHNESS = 1 << 4
+RPT_MAT_SUBSURFACE = 1 << 5
+RPT_MAT_SPECULAR_TINT = 1 << 6
+RPT_MAT_SHEEN = 1 << 7
+RPT_MAT_SHEEN_TINT = 1 << 8
+RPT_MAT_CLEARCOAT = 1 << 9
+RPT_MAT_CLEARCOAT_GLOSS = 1 << 10
+RPT_MAT_SPEC_TRANS = 1 << 11
+RPT_MAT_IOR = 1 << 12
+RPT_MAT_ALL = (1 << 13) - 1
+
+RPT_PROC_NONE = 0
+RPT_PROC_CHECKER_DIR = 1
+
+RPT_LIGHT_RECTANGULAR = 0
+RPT_LIGHT_SPHERICAL = 1
+RPT_LIGHT_DISTANT = 2
+
+RPT_BG_CONSTANT = 0
+RPT_BG_GRADIENT_Y = 1
+
+RPT_SCENE_ANYHIT_USES_MAX_DIST = 1 << 0
+
+RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG = range(7)
+
+F3 = C.c_float * 3
+F4 = C.c_float * 4
+
+
+class rpt_material(C.Structure):
+    _fields_ = [
+        ("mask", C.c_uint32), ("proc_kind", C.c_uint32),
+        ("rgb", F3), ("emission", F3),
+        ("anisotropic", C.c_float), ("metallic", C.c_float), ("roughness", C.c_float),
+        ("subsurface", C.c_float), ("specular_tint", C.c_float), ("sheen", C.c_float),
+        ("sheen_tint", C.c_float), ("clearcoat", C.c_float), ("clearcoat_gloss", C.c_float),
+        ("spec_trans", C.c_float), ("ior", C.c_float),
+        ("proc_params", F4),
+    ]
+
+
+class rpt_sphere(C.Structure):
+    _fields_ = [("center", F3), ("radius", C.c_float), ("material", C.c_uint32)]
+
+
+class rpt_plane(C.Structure):
+    _fields_ = [("normal", F3), ("point", F3), ("min_denom", C.c_float), ("material", C.c_uint32)]
+
+
+class rpt_light(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("position", F3), ("emission", F3), ("u", F3), ("v", F3),
+                ("radius", C.c_float), ("area", C.c_float)]
+
+
+class rpt_camera(C.Structure):
+    _fields_ = [("origin", F3), ("center", F3), ("fov_deg", C.c_float)]
+
+
+class rpt_background(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("colour_a", F3), ("colour_b", F3), ("gamma", C.c_float), ("scale", C.c_float)]
+
+
+class rpt_scene_desc(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_uint32), ("flags", C.c_uint32),
+        ("camera", rpt_camera), ("background", rpt_background),
+        ("eps", C.c_float), ("max_depth", C.c_uint32),
+        ("n_spheres", C.c_uint32), ("spheres", C.POINTER(rpt_sphere)),
+        ("n_planes", C.c_uint32), ("planes", C.POINTER(rpt_plane)),
+        ("n_lights", C.c_uint32), ("lights", C.POINTER(rpt_light)),
+        ("n_materials", C.c_uint32), ("materials", C.POINTER(rpt_material)),
+    ]
+
+
+# every symbol include/rpt.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "rpt_scene_analytical": (C.c_int, [C.POINTER(rpt_scene_desc)]),
+    "rpt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "rpt_destroy": (None, [C.c_void_p]),
+    "rpt_last_error": (C.c_char_p, [C.c_void_p]),
+    "rpt_abi_version": (C.c_uint32, []),
+    "rpt_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(rpt_scene_desc)]),
+    "rpt_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]),
+    "rpt_render_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64,
+                                    C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rpt_tile_row_count": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rpt_tile_global_row": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rpt_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                    C.c_uint32, C.c_void_p]),
+    "rpt_convert_to_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rpt_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_probe_math": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+}

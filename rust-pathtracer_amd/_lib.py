@@ -1,0 +1,39 @@
+"""Loads the HIP extension.  There is no CPU fallback: if librpt_hip.so is missing or
+cannot be loaded, importing the product API fails loudly."""
+import ctypes as C
+import os
+
+from . import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librpt_hip.so")
+
+_lib = None
+
+
+class RptError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__("rpt status %d: %s" % (status, message))
+        self.status = status
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -m rust_pathtracer_amd.build` or __graft_entry__.build(); "
+                "the product path has no CPU fallback" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _abi.SYMBOLS.items():
+            fn = getattr(l, name)      # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, ctx=None):
+    if status != _abi.RPT_OK:
+        msg = lib().rpt_last_error(ctx)
+        raise RptError(status, msg.decode() if msg else "")

@@ -1,0 +1,299 @@
+"""Host-side mirror of the reference's API for the render path, over the C ABI.
+
+Names and argument meaning follow the reference so code reads the same:
+    reference (Rust)                                   here
+    ------------------------------------------------   ---------------------------------
+    ColorBuffer::new(w, h)       buffer.rs:18          ColorBuffer(w, h) / DeviceColorBuffer(w, h)
+    Tracer::new(scene)           tracer.rs:13          Tracer(scene)
+    Tracer::render(&mut buffer)  tracer.rs:22          Tracer.render(buffer)     (1 spp, frames += 1)
+    Tracer::scene()              tracer.rs:629         Tracer.scene()
+    AnalyticalScene::new()       analytical.rs:13      AnalyticalScene()
+    Pinhole::new/set/set_fov     pinhole.rs:14-34      Pinhole(...)
+    AnalyticalLight::spherical   light.rs:13           AnalyticalLight.spherical(...)
+    buffer.convert_to_u8(frame)  buffer.rs:55          buffer.convert_to_u8()
+All computation happens in the HIP library; nothing here falls back to the CPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi
+from ._lib import RptError, check, lib
+
+
+class Pinhole:
+    """camera/pinhole.rs:6-34"""
+
+    def __init__(self, origin=(0.0, 0.0, 3.0), center=(0.0, 0.0, 0.0), fov=80.0):
+        self.origin = tuple(origin)
+        self.center = tuple(center)
+        self.fov = float(fov)
+
+    def set(self, origin, center):
+        self.origin = tuple(origin)
+        self.center = tuple(center)
+
+    def set_fov(self, fov):
+        self.fov = float(fov)
+
+
+class AnalyticalLight:
+    """light.rs:6-28"""
+
+    def __init__(self, light_type, position, emission, radius, area):
+        self.light_type = light_type
+        self.position = tuple(position)
+        self.emission = tuple(emission)
+        self.radius = float(radius)
+        self.area = float(area)
+
+    @staticmethod
+    def spherical(position, radius, emission):
+        r = np.float32(radius)
+        area = np.float32(4.0) * np.float32(math.pi) * r * r          # light.rs:22, f32 left to right
+        return AnalyticalLight(_abi.RPT_LIGHT_SPHERICAL, position, emission, radius, float(area))
+
+
+class Material:
+    """A material PATCH: only the fields passed are written over Material::new()
+    (material.rs:82-114), the way analytical.rs:56-58 assigns individual fields."""
+
+    _FIELDS = {
+        "rgb": _abi.RPT_MAT_RGB, "emission": _abi.RPT_MAT_EMISSION, "anisotropic": _abi.RPT_MAT_ANISOTROPIC,
+        "metallic": _abi.RPT_MAT_METALLIC, "roughness": _abi.RPT_MAT_ROUGHNESS, "subsurface": _abi.RPT_MAT_SUBSURFACE,
+        "specular_tint": _abi.RPT_MAT_SPECULAR_TINT, "sheen": _abi.RPT_MAT_SHEEN, "sheen_tint": _abi.RPT_MAT_SHEEN_TINT,
+        "clearcoat": _abi.RPT_MAT_CLEARCOAT, "clearcoat_gloss": _abi.RPT_MAT_CLEARCOAT_GLOSS,
+        "spec_trans": _abi.RPT_MAT_SPEC_TRANS, "ior": _abi.RPT_MAT_IOR,
+    }
+
+    def __init__(self, checker_dir=None, **fields):
+        for k in fields:
+            if k not in self._FIELDS:
+                raise TypeError("unknown material field %r" % k)
+        self.fields = fields
+        self.checker_dir = checker_dir       # (scale, offset, colour_a, colour_b) or None
+
+    def to_c(self):
+        m = _abi.rpt_material()
+        for k, v in self.fields.items():
+            m.mask |= self._FIELDS[k]
+            if k in ("rgb", "emission"):
+                setattr(m, k, _abi.F3(*v))
+            else:
+                setattr(m, k, float(v))
+        if self.checker_dir is not None:
+            m.proc_kind = _abi.RPT_PROC_CHECKER_DIR
+            m.proc_params = _abi.F4(*self.checker_dir)
+        return m
+
+
+class Scene:
+    """Data-driven counterpart of trait Scene (scene.rs:5-90): instead of callbacks the
+    scene describes itself (spheres, planes, lights, material patches, camera)."""
+
+    def __init__(self):
+        self.camera = Pinhole()
+        self.spheres = []        # (center, radius, material_index)
+        self.planes = []         # (normal, point, min_denom, material_index)
+        self.lights = []         # AnalyticalLight
+        self.materials = []      # Material
+        self.background = dict(kind=_abi.RPT_BG_CONSTANT, colour_a=(0.0, 0.0, 0.0), colour_b=(0.0, 0.0, 0.0), gamma=2.2, scale=1.0)
+        self.eps = 0.005         # tracer.rs:16
+        self.max_depth = 4       # scene.rs:28-30
+        self.any_hit_uses_max_dist = False
+        self._keep = None
+
+    def recursion_depth(self):
+        return self.max_depth
+
+    def number_of_lights(self):
+        return len(self.lights)
+
+    def light_at(self, index):
+        return self.lights[index]
+
+    def describe(self):
+        """-> rpt_scene_desc (keeps the backing arrays alive on self)."""
+        d = _abi.rpt_scene_desc()
+        d.abi_version = _abi.RPT_ABI_VERSION
+        d.flags = _abi.RPT_SCENE_ANYHIT_USES_MAX_DIST if self.any_hit_uses_max_dist else 0
+        d.camera.origin = _abi.F3(*self.camera.origin)
+        d.camera.center = _abi.F3(*self.camera.center)
+        d.camera.fov_deg = self.camera.fov
+        bg = self.background
+        d.background.kind = bg["kind"]
+        d.background.colour_a = _abi.F3(*bg["colour_a"])
+        d.background.colour_b = _abi.F3(*bg["colour_b"])
+        d.background.gamma = bg["gamma"]
+        d.background.scale = bg["scale"]
+        d.eps = self.eps
+        d.max_depth = self.max_depth
+        sph = (_abi.rpt_sphere * max(1, len(self.spheres)))()
+        for i, (c, r, m) in enumerate(self.spheres):
+            sph[i].center = _abi.F3(*c); sph[i].radius = r; sph[i].material = m
+        pl = (_abi.rpt_plane * max(1, len(self.planes)))()
+        for i, (n, p, md, m) in enumerate(self.planes):
+            pl[i].normal = _abi.F3(*n); pl[i].point = _abi.F3(*p); pl[i].min_denom = md; pl[i].material = m
+        li = (_abi.rpt_light * max(1, len(self.lights)))()
+        for i, L in enumerate(self.lights):
+            li[i].type = L.light_type; li[i].position = _abi.F3(*L.position); li[i].emission = _abi.F3(*L.emission)
+            li[i].radius = L.radius; li[i].area = L.area
+        ma = (_abi.rpt_material * max(1, len(self.materials)))()
+        for i, M in enumerate(self.materials):
+            ma[i] = M.to_c()
+        d.n_spheres = len(self.spheres); d.spheres = C.cast(sph, C.POINTER(_abi.rpt_sphere))
+        d.n_planes = len(self.planes); d.planes = C.cast(pl, C.POINTER(_abi.rpt_plane))
+        d.n_lights = len(self.lights); d.lights = C.cast(li, C.POINTER(_abi.rpt_light))
+        d.n_materials = len(self.materials); d.materials = C.cast(ma, C.POINTER(_abi.rpt_material))
+        self._keep = (sph, pl, li, ma)
+        return d
+
+
+class AnalyticalScene(Scene):
+    """renderer/src/analytical.rs:4-205 as data."""
+
+    def __init__(self):
+        super().__init__()
+        em = 3.0
+        self.lights = [AnalyticalLight.spherical((3.0, 2.0, 2.0), 1.0, (em, em, em))]            # analytical.rs:15-16
+        self.materials = [
+            Material(rgb=(1.0, 1.0, 1.0), roughness=0.05, metallic=1.0),                           # analytical.rs:56-58
+            Material(rgb=(1.0, 0.186, 0.0), clearcoat=1.0, clearcoat_gloss=1.0, roughness=0.1),    # analytical.rs:82-85
+            Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1)),                          # analytical.rs:107-116
+        ]
+        self.spheres = [((-1.1, 0.0, 0.0), 1.0, 0), ((1.1, 0.0, 0.0), 1.0, 1)]                     # analytical.rs:41,70
+        self.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2)]                             # analytical.rs:194-198
+        self.background = dict(kind=_abi.RPT_BG_GRADIENT_Y, colour_a=(1.0, 1.0, 1.0), colour_b=(0.5, 0.7, 1.0), gamma=2.2, scale=0.5)
+
+
+class ColorBuffer:
+    """buffer.rs:6-32: host RGBA f32 buffer, row 0 = top, plus the frame counter."""
+
+    def __init__(self, width, height):
+        self.width = int(width)
+        self.height = int(height)
+        self.pixels = np.zeros(self.width * self.height * 4, dtype=np.float32)
+        self.frames = 0
+
+    def at(self, x, y):                                            # buffer.rs:29-32
+        i = y * self.width * 4 + x * 4
+        return [float(v) for v in self.pixels[i:i + 4]]
+
+    def image(self):
+        return self.pixels.reshape(self.height, self.width, 4)
+
+    def convert_to_u8(self, frame=None):                           # buffer.rs:55-64, on the device
+        import torch
+        dev = torch.from_numpy(self.pixels).to("cuda")
+        out = _convert_to_u8_tensor(dev, self.width, self.height)
+        res = out.cpu().numpy().reshape(-1)
+        if frame is not None:
+            frame[:] = res
+        return res
+
+    def to_u8_vec(self):                                           # buffer.rs:37-52 (same arithmetic)
+        return self.convert_to_u8()
+
+
+class DeviceColorBuffer:
+    """ColorBuffer whose pixels live in HBM (a torch CUDA tensor): what the render loop
+    uses when frames are accumulated on the device and fetched once at the end."""
+
+    def __init__(self, width, height, device="cuda:0"):
+        import torch
+        self.width = int(width)
+        self.height = int(height)
+        self.pixels = torch.zeros(self.height, self.width, 4, dtype=torch.float32, device=device)
+        self.frames = 0
+
+    def to_host(self):
+        b = ColorBuffer(self.width, self.height)
+        b.pixels = self.pixels.detach().cpu().numpy().reshape(-1).copy()
+        b.frames = self.frames
+        return b
+
+    def convert_to_u8(self):
+        return _convert_to_u8_tensor(self.pixels, self.width, self.height)
+
+
+_default_ctx = {}
+
+
+def _ctx_for(device_index):
+    """A bare context (no scene) for stateless helpers such as convert_to_u8."""
+    if device_index not in _default_ctx:
+        h = C.c_void_p()
+        check(lib().rpt_create(C.byref(h), device_index))
+        _default_ctx[device_index] = h
+    return _default_ctx[device_index]
+
+
+def _convert_to_u8_tensor(pixels, width, height):
+    import torch
+    assert pixels.is_cuda and pixels.dtype == torch.float32 and pixels.is_contiguous()
+    idx = pixels.device.index or 0
+    out = torch.empty(height, width, 4, dtype=torch.uint8, device=pixels.device)
+    ctx = _ctx_for(idx)
+    stream = torch.cuda.current_stream(pixels.device).cuda_stream
+    check(lib().rpt_convert_to_u8_device(ctx, pixels.data_ptr(), out.data_ptr(), width, height, C.c_void_p(stream)), ctx)
+    return out
+
+
+class Tracer:
+    """tracer.rs:5-19.  Owns the scene; render() is the boundary into the HIP library."""
+
+    def __init__(self, scene, device=0, seed=1):
+        self._scene = scene
+        self.seed = int(seed)
+        self.device = int(device)
+        self._h = C.c_void_p()
+        check(lib().rpt_create(C.byref(self._h), self.device))
+        self.upload_scene()
+
+    def upload_scene(self):
+        """Call after mutating the scene returned by scene()."""
+        desc = self._scene.describe()
+        check(lib().rpt_upload_scene(self._h, C.byref(desc)), self._h)
+
+    def scene(self):                                               # tracer.rs:629-631
+        return self._scene
+
+    def render(self, buffer):
+        """Render one frame and accumulate into the pixels buffer (tracer.rs:21-123)."""
+        self.render_n(buffer, 1)
+
+    def render_n(self, buffer, spp):
+        """`spp` consecutive render() calls folded into one launch; bit-identical to them."""
+        if isinstance(buffer, ColorBuffer):
+            assert buffer.pixels.dtype == np.float32 and buffer.pixels.size == buffer.width * buffer.height * 4
+            check(lib().rpt_render(self._h, buffer.pixels.ctypes.data, buffer.width, buffer.height, buffer.frames,
+                                   spp, self.seed, 0), self._h)
+        else:
+            import torch
+            px = buffer.pixels
+            assert px.is_cuda and px.is_contiguous() and px.dtype == torch.float32
+            assert (px.device.index or 0) == self.device
+            stream = torch.cuda.current_stream(px.device).cuda_stream
+            check(lib().rpt_render_device(self._h, px.data_ptr(), buffer.width, buffer.height, buffer.frames, spp,
+                                          self.seed, 0, buffer.height, 0, 1, C.c_void_p(stream)), self._h)
+        buffer.frames += spp                                       # tracer.rs:121
+
+    def render_tile(self, tile_pixels, width, height, frames_done, spp, tile_rows, rank, world):
+        """Render this rank's rows of a row-tiled image into its compact tile tensor."""
+        import torch
+        assert tile_pixels.is_cuda and tile_pixels.is_contiguous() and tile_pixels.dtype == torch.float32
+        stream = torch.cuda.current_stream(tile_pixels.device).cuda_stream
+        check(lib().rpt_render_device(self._h, tile_pixels.data_ptr(), width, height, frames_done, spp, self.seed, 0,
+                                      tile_rows, rank, world, C.c_void_p(stream)), self._h)
+
+    def close(self):
+        if self._h:
+            lib().rpt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

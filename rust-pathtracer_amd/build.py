@@ -1,0 +1,41 @@
+"""Build the HIP extension (librpt_hip.so) for gfx950, in-tree."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "librpt_hip.so")
+SOURCES = ["rpt_hip.hip"]
+HEADERS = ["dev_math.h", "dev_bsdf.h", "dev_scene.h", "dev_integrator.h",
+           os.path.join("..", "..", "include", "rpt.h"), os.path.join("..", "..", "include", "rpt_strict_math.h")]
+# -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
+# fused operations are the explicit fma calls of rpt_strict_math.h.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip -> librpt_hip.so.  hipcc cross-compiles gfx950 without a GPU."""
+    if not force and not needs_build():
+        return LIB
+    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

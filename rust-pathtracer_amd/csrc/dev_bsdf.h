@@ -1,0 +1,356 @@
+// dev_bsdf.h — Disney principled BSDF of rust-pathtracer/src/tracer.rs:223-626 and
+// spherical-light sampling (tracer.rs:173-220), device side.  Operation order is
+// the reference's; see dev_math.h for why.
+#pragma once
+
+#include "dev_math.h"
+
+namespace rptdev {
+
+// Material after Material::new() + patches + finalize() (material.rs:82-131).
+struct Mat {
+    v3 rgb, emission;
+    float anisotropic, metallic, roughness, subsurface, specular_tint, sheen, sheen_tint;
+    float clearcoat, clearcoat_gloss, clearcoat_roughness, spec_trans, ior, ax, ay;
+};
+
+RPT_DEV void mat_defaults(Mat& m)                                   // material.rs:82-114
+{
+    m.rgb = mk3(1.5f, 1.5f, 1.5f);
+    m.emission = mk3(0.0f, 0.0f, 0.0f);
+    m.anisotropic = 0.0f; m.metallic = 0.0f; m.roughness = 0.5f; m.subsurface = 0.0f;
+    m.specular_tint = 0.0f; m.sheen = 0.0f; m.sheen_tint = 0.0f;
+    m.clearcoat = 0.0f; m.clearcoat_gloss = 0.0f; m.clearcoat_roughness = 0.0f;
+    m.spec_trans = 0.0f; m.ior = 1.45f; m.ax = 0.0f; m.ay = 0.0f;
+}
+
+RPT_DEV void mat_finalize(Mat& m)                                   // material.rs:117-131
+{
+    m.roughness = rmax(m.roughness, 0.01f);
+    m.clearcoat_roughness = mixf(0.1f, 0.001f, m.clearcoat_gloss);
+    float aspect = __builtin_sqrtf(1.0f - m.anisotropic * 0.9f);
+    m.ax = rmax(m.roughness / aspect, 0.001f);
+    m.ay = rmax(m.roughness * aspect, 0.001f);
+}
+
+RPT_DEV float power_heuristic(float a, float b)                     // tracer.rs:223
+{
+    float t = a * a;
+    return t / (b * b + t);
+}
+
+RPT_DEV float gtr1(float ndoth, float a)                            // tracer.rs:233 (log2, sic)
+{
+    if (a >= 1.0f) return kInvPi;
+    float a2 = a * a;
+    float t = 1.0f + (a2 - 1.0f) * ndoth * ndoth;
+    return (a2 - 1.0f) / (kPi * rpt_log2f(a2) * t);
+}
+
+RPT_DEV v3 sample_gtr1(float rgh, float r1)                         // tracer.rs:242 (r2 is unused there)
+{
+    float a = rmax(0.001f, rgh);
+    float a2 = a * a;
+    float phi = r1 * kTwoPi;
+    float cos_theta = __builtin_sqrtf((1.0f - rpt_powf(a2, 1.0f - r1)) / (1.0f - a2));
+    float sin_theta = clamp01(__builtin_sqrtf(1.0f - (cos_theta * cos_theta)));
+    float sin_phi, cos_phi;
+    rpt_sincosf(phi, &sin_phi, &cos_phi);
+    return mk3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+}
+
+RPT_DEV v3 sample_ggxvndf(v3 v, float ax, float ay, float r1, float r2)   // tracer.rs:256
+{
+    v3 vh = norm3(mk3(ax * v.x, ay * v.y, v.z));
+    float lensq = vh.x * vh.x + vh.y * vh.y;
+    v3 t_1 = mk3(1.0f, 0.0f, 0.0f);
+    if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), 1.0f / __builtin_sqrtf(lensq));
+    v3 t_2 = cross3(vh, t_1);
+    float r = __builtin_sqrtf(r1);
+    float phi = (2.0f * kPi) * r2;
+    float sn, cs;
+    rpt_sincosf(phi, &sn, &cs);
+    float t1 = r * cs;
+    float t2 = r * sn;
+    float s = 0.5f * (1.0f + vh.z);
+    t2 = (1.0f - s) * __builtin_sqrtf(1.0f - t1 * t1) + s * t2;
+    v3 nh = t1 * t_1 + t2 * t_2 + __builtin_sqrtf(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
+    return norm3(mk3(ax * nh.x, ay * nh.y, rmax(0.0f, nh.z)));
+}
+
+RPT_DEV float smithg(float ndotv, float alphag)                     // tracer.rs:276
+{
+    float a = alphag * alphag;
+    float b = ndotv * ndotv;
+    return (2.0f * ndotv) / (ndotv + __builtin_sqrtf(a + b - a * b));
+}
+
+RPT_DEV float luminance(v3 c)                                       // tracer.rs:284
+{
+    return 0.212671f * c.x + 0.715160f * c.y + 0.072169f * c.z;
+}
+
+RPT_DEV float schlick_fresnel(float u)                              // tracer.rs:288
+{
+    float m = clamp01(1.0f - u);
+    float m2 = m * m;
+    return m2 * m2 * m;
+}
+
+RPT_DEV float gtr2aniso(float ndoth, float hdotx, float hdoty, float ax, float ay)   // tracer.rs:294
+{
+    float a = hdotx / ax;
+    float b = hdoty / ay;
+    float c = a * a + b * b + ndoth * ndoth;
+    return 1.0f / (kPi * ax * ay * c * c);
+}
+
+RPT_DEV float smithganiso(float ndotv, float vdotx, float vdoty, float ax, float ay)   // tracer.rs:301
+{
+    float a = vdotx * ax;
+    float b = vdoty * ay;
+    float c = ndotv;
+    return (2.0f * ndotv) / (ndotv + __builtin_sqrtf(a * a + b * b + c * c));
+}
+
+RPT_DEV float dielectric_fresnel(float cos_theta_i, float eta)      // tracer.rs:308
+{
+    float sin_theta_tsq = eta * eta * (1.0f - cos_theta_i * cos_theta_i);
+    if (sin_theta_tsq > 1.0f) return 1.0f;
+    float cos_theta_t = __builtin_sqrtf(rmax(1.0f - sin_theta_tsq, 0.0f));
+    float rs = (eta * cos_theta_t - cos_theta_i) / (eta * cos_theta_t + cos_theta_i);
+    float rp = (eta * cos_theta_i - cos_theta_t) / (eta * cos_theta_i + cos_theta_t);
+    return 0.5f * (rs * rs + rp * rp);
+}
+
+RPT_DEV v3 cosine_sample_hemisphere(float r1, float r2)             // tracer.rs:324
+{
+    float r = __builtin_sqrtf(r1);
+    float phi = kTwoPi * r2;
+    float sn, cs;
+    rpt_sincosf(phi, &sn, &cs);
+    v3 dir;
+    dir.x = r * cs;
+    dir.y = r * sn;
+    dir.z = __builtin_sqrtf(rmax(0.0f, 1.0f - dir.x * dir.x - dir.y * dir.y));
+    return dir;
+}
+
+RPT_DEV void get_spec_color(const Mat& m, float eta, v3& spec_col, v3& sheen_col)   // tracer.rs:335
+{
+    float lum = luminance(m.rgb);
+    v3 ctint = mk3(1.0f, 1.0f, 1.0f);
+    if (lum > 0.0f) ctint = divs3(m.rgb, lum);
+    float f0 = (1.0f - eta) / (1.0f + eta);
+    spec_col = mix3((f0 * f0) * mix3(mk3(1.0f, 1.0f, 1.0f), ctint, m.specular_tint), m.rgb, m.metallic);
+    sheen_col = mix3(mk3(1.0f, 1.0f, 1.0f), ctint, m.sheen_tint);
+}
+
+RPT_DEV float disney_fresnel(const Mat& m, float eta, float ldoth, float vdoth)   // tracer.rs:435
+{
+    float metallic_fresnel = schlick_fresnel(ldoth);
+    float dielectric = dielectric_fresnel(__builtin_fabsf(vdoth), eta);
+    return mixf(dielectric, metallic_fresnel, m.metallic);
+}
+
+RPT_DEV v3 eval_diffuse(const Mat& m, v3 c_sheen, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:343
+{
+    pdf = 0.0f;
+    if (l.z <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    float ldh = dot3(l, h);
+    float fl = schlick_fresnel(l.z);
+    float fv = schlick_fresnel(v.z);
+    float fh = schlick_fresnel(ldh);
+    float fd90 = 0.5f + 2.0f * ldh * ldh * m.roughness;
+    float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
+    float fss90 = ldh * ldh * m.roughness;
+    float fss = mixf(1.0f, fss90, fl) * mixf(1.0f, fss90, fv);
+    float ss = 1.25f * (fss * (1.0f / (l.z + v.z) - 0.5f) + 0.5f);
+    v3 fsheen = (fh * m.sheen) * c_sheen;
+    pdf = l.z * kInvPi;
+    return ((1.0f - m.metallic) * (1.0f - m.spec_trans)) * ((kInvPi * mixf(fd, ss, m.subsurface)) * m.rgb + fsheen);
+}
+
+RPT_DEV v3 eval_spec_reflection(const Mat& m, float eta, v3 spec_col, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:368
+{
+    pdf = 0.0f;
+    if (l.z <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    float fm = disney_fresnel(m, eta, dot3(l, h), dot3(v, h));
+    v3 f = mix3(spec_col, mk3(1.0f, 1.0f, 1.0f), fm);
+    float d = gtr2aniso(h.z, h.x, h.y, m.ax, m.ay);
+    float g1 = smithganiso(__builtin_fabsf(v.z), v.x, v.y, m.ax, m.ay);
+    float g2 = g1 * smithganiso(__builtin_fabsf(l.z), l.x, l.y, m.ax, m.ay);
+    pdf = g1 * d / (4.0f * v.z);
+    return divs3((d * g2) * f, 4.0f * l.z * v.z);
+}
+
+RPT_DEV v3 eval_spec_refraction(const Mat& m, float eta, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:384
+{
+    pdf = 0.0f;
+    if (l.z >= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    float vdh = dot3(v, h), ldh = dot3(l, h);
+    float f = dielectric_fresnel(__builtin_fabsf(vdh), eta);
+    float d = gtr2aniso(h.z, h.x, h.y, m.ax, m.ay);
+    float g1 = smithganiso(__builtin_fabsf(v.z), v.x, v.y, m.ax, m.ay);
+    float g2 = g1 * smithganiso(__builtin_fabsf(l.z), l.x, l.y, m.ax, m.ay);
+    float denom = ldh + vdh * eta;
+    denom *= denom;
+    float eta2 = eta * eta;
+    float jacobian = __builtin_fabsf(ldh) / denom;
+    pdf = g1 * rmax(0.0f, vdh) * d * jacobian / v.z;
+    float s = (1.0f - m.metallic) * m.spec_trans * (1.0f - f) * d * g2 * __builtin_fabsf(vdh) * jacobian * eta2 /
+              __builtin_fabsf(l.z * v.z);
+    return s * mk3(rpt_powf(m.rgb.x, 0.5f), rpt_powf(m.rgb.y, 0.5f), rpt_powf(m.rgb.z, 0.5f));
+}
+
+RPT_DEV v3 eval_clearcoat(const Mat& m, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:404
+{
+    pdf = 0.0f;
+    if (l.z <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    float vdh = dot3(v, h);
+    float fh = dielectric_fresnel(vdh, 1.0f / 1.5f);
+    float f = mixf(0.04f, 1.0f, fh);
+    float d = gtr1(h.z, m.clearcoat_roughness);
+    float g = smithg(l.z, 0.25f) * smithg(v.z, 0.25f);
+    float jacobian = 1.0f / (4.0f * vdh);
+    pdf = d * h.z * jacobian;
+    return (m.clearcoat * f * d * g / (4.0f * l.z * v.z)) * mk3(0.25f, 0.25f, 0.25f);
+}
+
+struct LobeWeights {
+    float diffuse, spec_reflect, spec_refract, clearcoat;
+};
+
+RPT_DEV LobeWeights get_lobe_probabilities(const Mat& m, v3 spec_col, float approx_fresnel)   // tracer.rs:421
+{
+    LobeWeights w;
+    float lum = luminance(m.rgb);
+    w.diffuse = lum * (1.0f - m.metallic) * (1.0f - m.spec_trans);
+    w.spec_reflect = luminance(mix3(spec_col, mk3(1.0f, 1.0f, 1.0f), approx_fresnel));
+    w.spec_refract = (1.0f - approx_fresnel) * (1.0f - m.metallic) * m.spec_trans * lum;
+    w.clearcoat = 0.25f * m.clearcoat * (1.0f - m.metallic);
+    float total = w.diffuse + w.spec_reflect + w.spec_refract + w.clearcoat;
+    w.diffuse /= total;
+    w.spec_reflect /= total;
+    w.spec_refract /= total;
+    w.clearcoat /= total;
+    return w;
+}
+
+// tracer.rs:184-189 / 449-454 / 559-564
+RPT_DEV void onb(v3 n, v3& t, v3& b)
+{
+    v3 up = (__builtin_fabsf(n.z) < 0.999f) ? mk3(0.0f, 0.0f, 1.0f) : mk3(1.0f, 0.0f, 0.0f);
+    t = norm3(cross3(up, n));
+    b = cross3(n, t);
+}
+RPT_DEV v3 to_local(v3 x, v3 y, v3 z, v3 v) { return mk3(dot3(v, x), dot3(v, y), dot3(v, z)); }   // tracer.rs:456
+RPT_DEV v3 to_world(v3 x, v3 y, v3 z, v3 v) { return v.x * x + v.y * y + v.z * z; }               // tracer.rs:460
+RPT_DEV v3 reflect3(v3 i, v3 n) { return i - (mk3(2.0f, 2.0f, 2.0f) * n) * splat3(dot3(n, i)); }  // tracer.rs:464
+RPT_DEV v3 refract3(v3 i, v3 n, float eta)                                                        // tracer.rs:468
+{
+    float ndi = dot3(n, i);
+    float k = 1.0f - eta * eta * (1.0f - ndi * ndi);
+    if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
+    return eta * i - (eta * ndi + __builtin_sqrtf(k)) * n;
+}
+
+// tracer.rs:441-553.  l_io: in = the previous bounce's world-space direction (zeros
+// on the first bounce) which the specular branch reads before overwriting it
+// (tracer.rs:531); out = the sampled world-space direction.
+RPT_DEV v3 disney_sample(const Mat& m, float eta, v3 v, v3 n, v3& l_io, float& pdf, Rng& rng)
+{
+    pdf = 0.0f;
+    v3 f;
+    float r1 = rng.gen();
+    float r2 = rng.gen();
+
+    v3 t, b;
+    onb(n, t, b);
+    v = to_local(t, b, n, v);
+
+    v3 spec_col, sheen_col;
+    get_spec_color(m, eta, spec_col, sheen_col);
+    float approx_fresnel = disney_fresnel(m, eta, v.z, v.z);
+    LobeWeights w = get_lobe_probabilities(m, spec_col, approx_fresnel);
+
+    float cdf0 = w.diffuse;
+    float cdf1 = cdf0 + w.clearcoat;
+
+    v3 l;
+    if (r1 < cdf0) {
+        r1 /= cdf0;
+        l = cosine_sample_hemisphere(r1, r2);
+        v3 h = norm3(l + v);
+        f = eval_diffuse(m, sheen_col, v, l, h, pdf);
+        pdf *= w.diffuse;
+    } else if (r1 < cdf1) {
+        r1 = (r1 - cdf0) / (cdf1 - cdf0);
+        v3 h = sample_gtr1(m.clearcoat_roughness, r1);
+        if (h.z < 0.0f) h = -h;
+        l = norm3(reflect3(-v, h));
+        f = eval_clearcoat(m, v, l, h, pdf);
+        pdf *= w.clearcoat;
+    } else {
+        r1 = (r1 - cdf1) / (1.0f - cdf1);
+        v3 h = sample_ggxvndf(v, m.ax, m.ay, r1, r2);
+        if (h.z < 0.0f) h = -h;
+        float fresnel = disney_fresnel(m, eta, dot3(l_io, h), dot3(v, h));
+        float ff = 1.0f - ((1.0f - fresnel) * m.spec_trans * (1.0f - m.metallic));
+        float rnd = rng.gen();
+        if (rnd < ff) {
+            l = norm3(reflect3(-v, h));
+            f = eval_spec_reflection(m, eta, spec_col, v, l, h, pdf);
+            pdf *= ff;
+        } else {
+            l = norm3(refract3(-v, h, eta));
+            f = eval_spec_refraction(m, eta, v, l, h, pdf);
+            pdf *= 1.0f - ff;
+        }
+        pdf *= w.spec_reflect + w.spec_refract;
+    }
+    l_io = to_world(t, b, n, l);
+    return __builtin_fabsf(dot3(n, l_io)) * f;
+}
+
+// tracer.rs:555-626
+RPT_DEV v3 disney_eval(const Mat& m, float eta, v3 v_world, v3 n, v3 l_world, float& bsdf_pdf)
+{
+    bsdf_pdf = 0.0f;
+    v3 f = mk3(0.0f, 0.0f, 0.0f);
+    v3 t, b;
+    onb(n, t, b);
+    v3 v = to_local(t, b, n, v_world);
+    v3 l = to_local(t, b, n, l_world);
+
+    v3 h;
+    if (l.z > 0.0f) h = norm3(l + v);
+    else h = norm3(l + eta * v);
+    if (h.z < 0.0f) h = -h;
+
+    v3 spec_col, sheen_col;
+    get_spec_color(m, eta, spec_col, sheen_col);
+    float fresnel = disney_fresnel(m, eta, dot3(l, h), dot3(v, h));
+    LobeWeights w = get_lobe_probabilities(m, spec_col, fresnel);
+
+    float pdf;
+    if (w.diffuse > 0.0f && l.z > 0.0f) {
+        f = f + eval_diffuse(m, sheen_col, v, l, h, pdf);
+        bsdf_pdf += pdf * w.diffuse;
+    }
+    if (w.spec_reflect > 0.0f && l.z > 0.0f && v.z > 0.0f) {
+        f = f + eval_spec_reflection(m, eta, spec_col, v, l, h, pdf);
+        bsdf_pdf += pdf * w.spec_reflect;
+    }
+    if (w.spec_refract > 0.0f && l.z < 0.0f) {
+        f = f + eval_spec_refraction(m, eta, v, l, h, pdf);
+        bsdf_pdf += pdf * w.spec_refract;
+    }
+    if (w.clearcoat > 0.0f && l.z > 0.0f && v.z > 0.0f) {
+        f = f + eval_clearcoat(m, v, l, h, pdf);
+        bsdf_pdf += pdf * w.clearcoat;
+    }
+    return __builtin_fabsf(l.z) * f;
+}
+
+}  // namespace rptdev

@@ -1,0 +1,340 @@
+// dev_integrator.h — scene queries and the per-sample path of
+// rust-pathtracer/src/tracer.rs:33-117 for small analytical scenes (SceneSmall).
+#pragma once
+
+#include "dev_bsdf.h"
+#include "dev_scene.h"
+
+namespace rptdev {
+
+struct RayD {
+    v3 o, d;
+};
+
+// analytical.rs:166-190 == scene.rs:39-63
+RPT_DEV bool hit_sphere(const RayD& ray, v3 center, float radius, float& t)
+{
+    v3 l = center - ray.o;
+    float tca = dot3(l, ray.d);
+    float d2 = dot3(l, l) - tca * tca;
+    float radius2 = radius * radius;
+    if (d2 > radius2) return false;
+    float thc = __builtin_sqrtf(radius2 - d2);
+    float t0 = tca - thc;
+    float t1 = tca + thc;
+    if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
+    if (t0 < 0.0f) {
+        t0 = t1;
+        if (t0 < 0.0f) return false;
+    }
+    t = t0;
+    return true;
+}
+
+// analytical.rs:193-204 (normal / point / threshold from the table)
+RPT_DEV bool hit_plane(const RayD& ray, const DevPlane& p, float& t)
+{
+    v3 n = mk3(p.nx, p.ny, p.nz);
+    float denom = dot3(n, ray.d);
+    if (__builtin_fabsf(denom) > p.min_denom) {
+        float tt = dot3(mk3(p.px, p.py, p.pz) - ray.o, n) / denom;
+        if (tt >= 0.0f) { t = tt; return true; }
+    }
+    return false;
+}
+
+// Overlay one material patch on `m` for the lanes where `on` holds: the field
+// writes of analytical.rs:56-58 / 82-85 / 115-116.  The patch and its mask are
+// wave-uniform (SGPRs); only the select is per lane.
+RPT_DEV void apply_patch(Mat& m, const DevMaterial& p, bool on, v3 dir)
+{
+    if (p.mask & RPT_MAT_RGB) { m.rgb.x = on ? p.rgb[0] : m.rgb.x; m.rgb.y = on ? p.rgb[1] : m.rgb.y; m.rgb.z = on ? p.rgb[2] : m.rgb.z; }
+    if (p.mask & RPT_MAT_EMISSION) { m.emission.x = on ? p.emission[0] : m.emission.x; m.emission.y = on ? p.emission[1] : m.emission.y; m.emission.z = on ? p.emission[2] : m.emission.z; }
+    if (p.mask & RPT_MAT_ANISOTROPIC) m.anisotropic = on ? p.anisotropic : m.anisotropic;
+    if (p.mask & RPT_MAT_METALLIC) m.metallic = on ? p.metallic : m.metallic;
+    if (p.mask & RPT_MAT_ROUGHNESS) m.roughness = on ? p.roughness : m.roughness;
+    if (p.mask & RPT_MAT_SUBSURFACE) m.subsurface = on ? p.subsurface : m.subsurface;
+    if (p.mask & RPT_MAT_SPECULAR_TINT) m.specular_tint = on ? p.specular_tint : m.specular_tint;
+    if (p.mask & RPT_MAT_SHEEN) m.sheen = on ? p.sheen : m.sheen;
+    if (p.mask & RPT_MAT_SHEEN_TINT) m.sheen_tint = on ? p.sheen_tint : m.sheen_tint;
+    if (p.mask & RPT_MAT_CLEARCOAT) m.clearcoat = on ? p.clearcoat : m.clearcoat;
+    if (p.mask & RPT_MAT_CLEARCOAT_GLOSS) m.clearcoat_gloss = on ? p.clearcoat_gloss : m.clearcoat_gloss;
+    if (p.mask & RPT_MAT_SPEC_TRANS) m.spec_trans = on ? p.spec_trans : m.spec_trans;
+    if (p.mask & RPT_MAT_IOR) m.ior = on ? p.ior : m.ior;
+    if (p.proc_kind == RPT_PROC_CHECKER_DIR) {                      // analytical.rs:107-115
+        if (on) {
+            float x = dir.x / dir.y * p.proc_params[0] + p.proc_params[1];
+            float y = dir.z / dir.y * p.proc_params[0] + p.proc_params[1];
+            float x1 = rem2(__builtin_floorf(x));
+            float y1 = rem2(__builtin_floorf(y));
+            float c = (rem2(x1 + y1) < 1.0f) ? p.proc_params[2] : p.proc_params[3];
+            m.rgb = mk3(c, c, c);
+        }
+    }
+}
+
+// Path state that survives from one bounce to the next (tracer.rs:51-57):
+// hit_dist is deliberately NOT reset per bounce (scene.rs:66 reads the stale value).
+struct PathState {
+    float hit_dist;            // State.hit_dist, starts at -1 (globals.rs:28)
+    float light_pdf;           // LightSampleRec.pdf written by Scene::sample_lights
+    v3 light_emission;
+    float scatter_pdf;         // ScatterSampleRec.pdf of the previous bounce (MIS, tracer.rs:81)
+};
+
+struct HitInfo {
+    v3 normal;
+    Mat mat;
+    bool is_emitter;
+};
+
+// AnalyticalScene::closest_hit (analytical.rs:36-127) + Scene::sample_lights
+// (scene.rs:36-86) over the tables.  Only the final normal is computed (the
+// reference also computes the normals of accepted-then-superseded primitives,
+// which nothing reads).
+RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, HitInfo& hi)
+{
+    float dist = 3.40282347e+38f;                                   // F::MAX
+    bool hit = false;
+    uint32_t accepted = 0;                                          // bit i: primitive i's material writes happened
+    v3 c = mk3(0.0f, 0.0f, 0.0f);                                   // centre of the winning sphere
+    v3 pn = mk3(0.0f, 0.0f, 0.0f);                                  // normal of the winning plane
+    bool win_plane = false;
+
+    for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+        const DevSphere& s = sc.spheres[i];
+        float t;
+        bool h = hit_sphere(ray, mk3(s.cx, s.cy, s.cz), s.radius, t);
+        bool acc = h && (i == 0 || t < dist);                       // analytical.rs:43 has no distance test for the first one
+        if (acc) {
+            dist = t;
+            c = mk3(s.cx, s.cy, s.cz);
+            win_plane = false;
+            hit = true;
+            accepted |= 1u << i;
+        }
+    }
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        const DevPlane& p = sc.planes[k];
+        float t;
+        bool h = hit_plane(ray, p, t);
+        bool acc = h && ((sc.n_spheres == 0 && k == 0) || t < dist);
+        if (acc) {
+            dist = t;
+            pn = mk3(p.nx, p.ny, p.nz);
+            win_plane = true;
+            hit = true;
+            accepted |= 1u << (kMaxSpheres + k);
+        }
+    }
+    if (hit) {
+        ps.hit_dist = dist;                                         // analytical.rs:48,79,104
+        v3 hp = ray.o + dist * ray.d;                               // ray.at(d)
+        v3 sn = norm3(hp - c);
+        hi.normal = win_plane ? pn : sn;
+    }
+
+    // material = Material::new() then the accepted primitives' writes, in order
+    mat_defaults(hi.mat);
+    for (uint32_t i = 0; i < sc.n_spheres; ++i)
+        apply_patch(hi.mat, sc.materials[sc.spheres[i].material], (accepted >> i) & 1u, ray.d);
+    for (uint32_t k = 0; k < sc.n_planes; ++k)
+        apply_patch(hi.mat, sc.materials[sc.planes[k].material], (accepted >> (kMaxSpheres + k)) & 1u, ray.d);
+
+    // Scene::sample_lights, scene.rs:65-85
+    float ldist = ps.hit_dist;
+    for (uint32_t i = 0; i < sc.n_lights; ++i) {
+        const DevLight& L = sc.lights[i];
+        if (L.type != RPT_LIGHT_SPHERICAL) continue;
+        v3 pos = mk3(L.px, L.py, L.pz);
+        float t;
+        if (hit_sphere(ray, pos, L.radius, t)) {
+            if (t < ldist) {
+                ldist = t;
+                v3 hit_point = ray.o + t * ray.d;
+                float cos_theta = dot3(-ray.d, norm3(hit_point - pos));
+                ps.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
+                ps.light_emission = mk3(L.ex, L.ey, L.ez);
+                hi.is_emitter = true;
+                ps.hit_dist = t;
+                hit = true;
+            }
+        }
+    }
+    return hit;
+}
+
+// AnalyticalScene::any_hit (analytical.rs:130-145); it ignores max_dist unless the
+// scene opts in.
+RPT_DEV bool any_hit(const SceneSmall& sc, const RayD& ray, float max_dist)
+{
+    bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
+    bool occluded = false;
+    for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+        const DevSphere& s = sc.spheres[i];
+        float t;
+        bool h = hit_sphere(ray, mk3(s.cx, s.cy, s.cz), s.radius, t);
+        occluded = occluded || (h && (!use_max || t < max_dist));
+    }
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        float t;
+        bool h = hit_plane(ray, sc.planes[k], t);
+        occluded = occluded || (h && (!use_max || t < max_dist));
+    }
+    return occluded;
+}
+
+// analytical.rs:28-32 + scene.rs:32-34
+RPT_DEV v3 background(const SceneSmall& sc, const RayD& ray)
+{
+    const DevBackground& b = sc.bg;
+    v3 ca = mk3(b.ax, b.ay, b.az);
+    if (b.kind == RPT_BG_CONSTANT) return ca * splat3(b.scale);
+    v3 cb = mk3(b.bx, b.by, b.bz);
+    float t = 0.5f * (ray.d.y + 1.0f);
+    v3 c = (1.0f - t) * ca + t * cb;
+    v3 lin = mk3(rpt_powf(c.x, b.gamma), rpt_powf(c.y, b.gamma), rpt_powf(c.z, b.gamma));
+    return lin * splat3(b.scale);
+}
+
+struct LightSample {
+    v3 normal, emission, direction;
+    float dist, pdf;
+};
+
+// tracer.rs:173-220 (LightType::Spherical; the other types are no-ops there)
+RPT_DEV void sample_light(const SceneSmall& sc, const DevLight& L, v3 scatter_pos, LightSample& ls, Rng& rng)
+{
+    ls.normal = mk3(0.0f, 0.0f, 0.0f); ls.emission = mk3(0.0f, 0.0f, 0.0f); ls.direction = mk3(0.0f, 0.0f, 0.0f);
+    ls.dist = 0.0f; ls.pdf = 0.0f;                                  // LightSampleRec::new, globals.rs:119-129
+    if (L.type != RPT_LIGHT_SPHERICAL) return;
+    float r1 = rng.gen();
+    float r2 = rng.gen();
+    v3 lpos = mk3(L.px, L.py, L.pz);
+    v3 c2s = scatter_pos - lpos;
+    float dist_to_center = len3(c2s);
+    float r = __builtin_sqrtf(rmax(0.0f, 1.0f - r1 * r1));          // uniform_sample_hemisphere
+    float phi = kTwoPi * r2;
+    float sn, cs;
+    rpt_sincosf(phi, &sn, &cs);
+    v3 sampled = mk3(r * cs, r * sn, r1);
+    c2s = divs3(c2s, dist_to_center);
+    v3 t, b;
+    onb(c2s, t, b);
+    sampled = sampled.x * t + sampled.y * b + sampled.z * c2s;
+    v3 surface_pos = lpos + L.radius * sampled;
+    ls.direction = surface_pos - scatter_pos;
+    ls.dist = len3(ls.direction);
+    float dist_sq = ls.dist * ls.dist;
+    ls.direction = divs3(ls.direction, ls.dist);
+    ls.normal = norm3(surface_pos - lpos);
+    ls.emission = sc.n_lights_f * mk3(L.ex, L.ey, L.ez);
+    ls.pdf = dist_sq / (L.area * 0.5f * __builtin_fabsf(dot3(ls.normal, ls.direction)));
+}
+
+// tracer.rs:126-170
+RPT_DEV v3 direct_light(const SceneSmall& sc, const RayD& ray, const Mat& mat, float eta, v3 fhp, v3 ffnormal, Rng& rng)
+{
+    v3 ld = mk3(0.0f, 0.0f, 0.0f);
+    if (sc.n_lights == 0) return ld;
+    v3 scatter_pos = fhp + sc.eps * ffnormal;
+    float random = rng.gen();
+    random = random * sc.n_lights_f;
+    uint32_t index = (uint32_t)random;                              // `as usize`
+    index = (index >= sc.n_lights) ? sc.n_lights - 1u : index;      // the reference would panic; unreachable for n < 2^24
+
+    // light table entry for a per-lane index: select over the (uniform) table
+    DevLight L = sc.lights[0];
+    for (uint32_t i = 1; i < sc.n_lights; ++i) {
+        const DevLight& Li = sc.lights[i];
+        bool pick = (index == i);
+        L.type = pick ? Li.type : L.type;
+        L.px = pick ? Li.px : L.px; L.py = pick ? Li.py : L.py; L.pz = pick ? Li.pz : L.pz;
+        L.ex = pick ? Li.ex : L.ex; L.ey = pick ? Li.ey : L.ey; L.ez = pick ? Li.ez : L.ez;
+        L.radius = pick ? Li.radius : L.radius; L.area = pick ? Li.area : L.area;
+    }
+
+    LightSample ls;
+    sample_light(sc, L, scatter_pos, ls, rng);
+    v3 li = ls.emission;
+    if (dot3(ls.direction, ls.normal) < 0.0f) {
+        RayD shadow{scatter_pos, ls.direction};
+        bool in_shadow = any_hit(sc, shadow, ls.dist - sc.eps);
+        if (!in_shadow) {
+            float bsdf_pdf;
+            v3 f = disney_eval(mat, eta, -ray.d, ffnormal, ls.direction, bsdf_pdf);
+            float mis_weight = 1.0f;
+            if (L.area > 0.0f) mis_weight = power_heuristic(ls.pdf, bsdf_pdf);
+            if (bsdf_pdf > 0.0f) ld = ld + (mis_weight * li) * divs3(f, ls.pdf);
+        }
+    }
+    return ld;
+}
+
+// Camera ray for pixel-relative coordinates (px, py) = coord of tracer.rs:46 and
+// jitter (offx, offy): the per-sample tail of Pinhole::gen_ray (pinhole.rs:56-59).
+RPT_DEV RayD camera_ray(const DevCamera& cam, float px, float py, float offx, float offy)
+{
+    v3 rd = mk3(cam.rdx, cam.rdy, cam.rdz);
+    rd = rd + scale3(mk3(cam.hx, cam.hy, cam.hz), cam.psx * offx + px);
+    rd = rd + scale3(mk3(cam.vx, cam.vy, cam.vz), cam.psy * offy + py);
+    return RayD{mk3(cam.ox, cam.oy, cam.oz), norm3(rd)};
+}
+
+// One pixel-sample: tracer.rs:44-103.  Returns the radiance.
+RPT_DEV v3 trace_sample(const SceneSmall& sc, float px, float py, uint32_t fkey, uint32_t pixel_index)
+{
+    Rng rng;
+    rng.init(fkey, pixel_index);
+    float offx = rng.gen();
+    float offy = rng.gen();
+    RayD ray = camera_ray(sc.cam, px, py, offx, offy);
+
+    v3 radiance = mk3(0.0f, 0.0f, 0.0f);
+    v3 throughput = mk3(1.0f, 1.0f, 1.0f);
+    PathState ps;
+    ps.hit_dist = -1.0f;
+    ps.light_pdf = 0.0f;
+    ps.light_emission = mk3(0.0f, 0.0f, 0.0f);
+    ps.scatter_pdf = 0.0f;
+    v3 scatter_l = mk3(0.0f, 0.0f, 0.0f);                           // ScatterSampleRec.l, zeros before the first bounce
+    bool is_emitter = false;                                        // State.is_emitter, never cleared (tracer.rs:53)
+
+    for (uint32_t bounce = 0; bounce < sc.max_depth; ++bounce) {
+        HitInfo hi;
+        hi.is_emitter = is_emitter;
+        hi.normal = mk3(0.0f, 0.0f, 0.0f);
+        bool hit = closest_hit(sc, ray, ps, hi);
+        is_emitter = hi.is_emitter;
+        if (!hit) {
+            radiance = radiance + background(sc, ray) * throughput;
+            break;
+        }
+        // State::finalize, globals.rs:50-62
+        v3 fhp = ray.o + ps.hit_dist * ray.d;
+        float ndd = dot3(hi.normal, ray.d);
+        v3 ffnormal = (ndd <= 0.0f) ? hi.normal : -hi.normal;
+        mat_finalize(hi.mat);
+        float eta = (dot3(ray.d, hi.normal) < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
+
+        radiance = radiance + hi.mat.emission * throughput;
+        if (is_emitter) {
+            // state.depth > 0 always holds (tracer.rs:57,80): the MIS weight is always applied
+            float mis_weight = power_heuristic(ps.scatter_pdf, ps.light_pdf);
+            radiance = radiance + (mis_weight * ps.light_emission) * throughput;
+            break;
+        }
+        radiance = radiance + direct_light(sc, ray, hi.mat, eta, fhp, ffnormal, rng) * throughput;
+
+        float pdf;
+        v3 f = disney_sample(hi.mat, eta, -ray.d, ffnormal, scatter_l, pdf, rng);
+        ps.scatter_pdf = pdf;
+        if (pdf > 0.0f) throughput = throughput * divs3(f, pdf);
+        else break;
+        ray.d = scatter_l;
+        ray.o = fhp + sc.eps * ray.d;
+    }
+    return radiance;
+}
+
+}  // namespace rptdev

@@ -1,0 +1,107 @@
+// dev_math.h — f32 vector arithmetic and RNG of the HIP integrator (gfx950).
+//
+// Every expression keeps the reference's operation order, because results are
+// compared bit for bit with a CPU restatement: the whole library is compiled with
+// -ffp-contract=off, f32 divide and sqrt are the correctly rounded expansions
+// (hipcc default, -fhip-fp32-correctly-rounded-divide-sqrt), and transcendental
+// functions come from include/rpt_strict_math.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rpt_strict_math.h"
+
+#define RPT_DEV __device__ __forceinline__
+
+namespace rptdev {
+
+// lib.rs:8-10
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 1.0f / 3.14159265358979323846f;
+constexpr float kTwoPi = 3.14159265358979323846f * 2.0f;
+
+struct v3 {
+    float x, y, z;
+};
+
+RPT_DEV v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+RPT_DEV v3 splat3(float s) { return v3{s, s, s}; }                       // F3::new_x, fx.rs:233
+RPT_DEV v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }   // fx.rs:437
+RPT_DEV v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }   // fx.rs:453
+RPT_DEV v3 operator*(v3 a, v3 b) { return v3{a.x * b.x, a.y * b.y, a.z * b.z}; }   // fx.rs:469
+RPT_DEV v3 operator/(v3 a, v3 b) { return v3{a.x / b.x, a.y / b.y, a.z / b.z}; }   // fx.rs:485
+RPT_DEV v3 operator*(float s, v3 a) { return v3{s * a.x, s * a.y, s * a.z}; }      // fx.rs:477 (f32 * F3)
+RPT_DEV v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }                        // fx.rs:509
+RPT_DEV v3 scale3(v3 a, float f) { return v3{a.x * f, a.y * f, a.z * f}; }         // F3::mult_f, fx.rs:346
+RPT_DEV v3 divs3(v3 a, float d) { return v3{a.x / d, a.y / d, a.z / d}; }          // a / F3::new_x(d)
+
+RPT_DEV float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       // fx.rs:335
+RPT_DEV v3 cross3(v3 a, v3 b)                                                      // fx.rs:339
+{
+    return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+RPT_DEV float len3(v3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }   // fx.rs:331
+RPT_DEV v3 norm3(v3 a) { float l = len3(a); return v3{a.x / l, a.y / l, a.z / l}; }      // fx.rs:307 (three divides)
+RPT_DEV v3 mix3(v3 a, v3 b, float v)                                               // math.rs:34
+{
+    return v3{(1.0f - v) * a.x + b.x * v, (1.0f - v) * a.y + b.y * v, (1.0f - v) * a.z + b.z * v};
+}
+RPT_DEV float mixf(float a, float b, float v) { return (1.0f - v) * a + b * v; }   // tracer.rs:229
+
+// f32::max: a NaN operand yields the other one.
+RPT_DEV float rmax(float self, float other)
+{
+    float r = (self > other) ? self : other;
+    r = (other != other) ? self : r;
+    r = (self != self) ? other : r;
+    return r;
+}
+// f32::clamp(0, 1): NaN stays NaN.
+RPT_DEV float clamp01(float x)
+{
+    float r = (x > 1.0f) ? 1.0f : x;
+    return (x < 0.0f) ? 0.0f : r;
+}
+// a % 2.0 for Rust f32 (C fmodf): exact via trunc for every finite a; +-inf and NaN
+// give NaN like fmodf.  (Sign of a zero result can differ from fmodf; callers only
+// compare the result with 1.0.)
+RPT_DEV float rem2(float a) { return a - 2.0f * __builtin_truncf(a * 0.5f); }
+
+// ---- RNG --------------------------------------------------------------------
+// Counter-based replacement for rand::thread_rng (tracer.rs:44): PCG hash of
+// (path key + draw counter); u32 -> f32 as rand 0.8.5 Standard: (u >> 8) * 2^-24.
+RPT_DEV uint32_t pcg_hash(uint32_t v)
+{
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__host__ __device__ inline uint32_t pcg_hash_hd(uint32_t v)
+{
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__host__ __device__ inline uint32_t frame_key_hd(uint64_t seed, uint64_t frame)
+{
+    uint32_t k = pcg_hash_hd((uint32_t)(seed >> 32));
+    k = pcg_hash_hd(k ^ (uint32_t)seed);
+    k = pcg_hash_hd(k ^ (uint32_t)(frame >> 32));
+    k = pcg_hash_hd(k ^ (uint32_t)frame);
+    return k;
+}
+
+struct Rng {
+    uint32_t key;
+    uint32_t counter;
+    RPT_DEV void init(uint32_t fkey, uint32_t pixel_index)
+    {
+        key = pcg_hash(pcg_hash(pixel_index) ^ fkey);
+        counter = 0;
+    }
+    RPT_DEV uint32_t next_u32() { return pcg_hash(key + counter++); }
+    RPT_DEV float gen() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
+};
+
+}  // namespace rptdev

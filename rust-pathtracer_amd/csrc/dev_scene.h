@@ -1,0 +1,93 @@
+// dev_scene.h — device-side scene tables for "small" analytical scenes.
+//
+// A small scene (<= 8 spheres, 4 planes, 4 lights, 12 material patches: the
+// reference's AnalyticalScene is 2/1/1/3) is passed to the kernel BY VALUE in the
+// kernarg segment.  Every table index in the integrator is wave-uniform, so hipcc
+// turns the reads into s_load / SGPR operands: the tables cost no VGPRs, no LDS
+// traffic and no vector-memory instructions ("SGPR-resident
+// scene").  Larger scenes use the LDS-tiled path (dev_scene_large.h).
+#pragma once
+
+#include <stdint.h>
+
+#include "../../include/rpt.h"
+
+namespace rptdev {
+
+constexpr int kMaxSpheres = 8;
+constexpr int kMaxPlanes = 4;
+constexpr int kMaxLights = 4;
+constexpr int kMaxMaterials = 12;
+
+struct DevSphere {
+    float cx, cy, cz, radius;
+    uint32_t material;
+};
+
+struct DevPlane {
+    float nx, ny, nz;
+    float px, py, pz;
+    float min_denom;
+    uint32_t material;
+};
+
+struct DevLight {
+    uint32_t type;
+    float px, py, pz;
+    float ex, ey, ez;
+    float radius, area;
+};
+
+struct DevMaterial {
+    uint32_t mask, proc_kind;
+    float rgb[3], emission[3];
+    float anisotropic, metallic, roughness, subsurface, specular_tint, sheen, sheen_tint;
+    float clearcoat, clearcoat_gloss, spec_trans, ior;
+    float proc_params[4];
+};
+
+// Pinhole::gen_ray (camera/pinhole.rs:38-60) split at its frame-invariant part:
+// everything up to `rd = lower_left - origin` depends only on the camera and the
+// image size, so the host evaluates it once per launch with the same f32
+// operation order and strict tan (rpt_hip.hip, make_camera).
+struct DevCamera {
+    float ox, oy, oz;          // origin
+    float rdx, rdy, rdz;       // lower_left - origin
+    float hx, hy, hz;          // horizontal
+    float vx, vy, vz;          // vertical
+    float psx, psy;            // pixel_size = (1/width, 1/height)
+};
+
+struct DevBackground {
+    uint32_t kind;
+    float ax, ay, az;
+    float bx, by, bz;
+    float gamma, scale;
+};
+
+struct SceneSmall {
+    uint32_t n_spheres, n_planes, n_lights, n_materials;
+    uint32_t flags, max_depth;
+    float eps;
+    float n_lights_f;          // number_of_lights() as F (tracer.rs:138,214)
+    DevCamera cam;
+    DevBackground bg;
+    DevSphere spheres[kMaxSpheres];
+    DevPlane planes[kMaxPlanes];
+    DevLight lights[kMaxLights];
+    DevMaterial materials[kMaxMaterials];
+};
+
+// One launch's worth of render parameters.
+struct RenderParams {
+    float* pixels;             // this rank's tile buffer, rows_local * width RGBA f32
+    uint32_t width, height;    // full image
+    uint32_t rows_local;       // rows in `pixels`
+    uint32_t tile_rows, rank, world;
+    uint32_t spp;
+    uint64_t frames_done;
+    uint64_t seed;
+    uint32_t tiles_x;          // ceil(width / 16)
+};
+
+}  // namespace rptdev

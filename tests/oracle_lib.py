@@ -1,0 +1,146 @@
+"""ctypes wrapper of the CPU oracle (oracle/build/liboracle*.so).  Test infrastructure:
+only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _abi():
+    import sys
+    return sys.modules["rust_pathtracer_amd"]._abi
+
+
+class Oracle:
+    def __init__(self, libname="liboracle.so"):
+        self.lib = C.CDLL(os.path.join(ROOT, "oracle", "build", libname))
+        L = self.lib
+        L.oracle_build_info.restype = C.c_char_p
+        L.oracle_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64,
+                                    C.c_uint32, C.c_uint32, C.c_int]
+        L.oracle_sample_pixels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32,
+                                           C.c_uint64, C.c_void_p]
+        L.oracle_opcount.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.oracle_sphere.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+        L.oracle_plane.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        for name, n in (("oracle_power_heuristic", 2), ("oracle_schlick_fresnel", 1), ("oracle_dielectric_fresnel", 2),
+                        ("oracle_gtr1", 2), ("oracle_smithg", 2), ("oracle_gtr2aniso", 5)):
+            f = getattr(L, name)
+            f.restype = C.c_float
+            f.argtypes = [C.c_float] * n
+        L.oracle_luminance.restype = C.c_float
+        L.oracle_luminance.argtypes = [C.c_void_p]
+        L.oracle_material_defaults.argtypes = [C.c_void_p]
+        L.oracle_material_finalize.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_gen_ray.argtypes = [C.c_void_p] + [C.c_float] * 6 + [C.c_void_p]
+        L.oracle_disney_eval.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_disney_sample.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                           C.c_uint32, C.c_void_p]
+        L.oracle_rng_u32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_rng_f32.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.oracle_math.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        L.oracle_convert_to_u8.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+
+    def build_info(self):
+        return self.lib.oracle_build_info().decode()
+
+    def max_threads(self):
+        return self.lib.oracle_max_threads()
+
+    def scene_analytical(self):
+        d = _abi().rpt_scene_desc()
+        self.lib.oracle_scene_analytical(C.byref(d))
+        return d
+
+    def render(self, desc, width, height, spp, seed=1, frames_done=0, pixels=None, rows=None, threads=0):
+        if pixels is None:
+            pixels = np.zeros((height, width, 4), dtype=np.float32)
+        r0, r1 = rows if rows is not None else (0, height)
+        rc = self.lib.oracle_render(C.byref(desc), pixels.ctypes.data, width, height, frames_done, spp, seed, r0, r1, threads)
+        assert rc == 0
+        return pixels
+
+    def sample_pixels(self, desc, cols, rows, frames, width, height, seed=1):
+        cols = np.ascontiguousarray(cols, dtype=np.uint32)
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        frames = np.ascontiguousarray(frames, dtype=np.uint64)
+        out = np.zeros((len(cols), 3), dtype=np.float32)
+        self.lib.oracle_sample_pixels(C.byref(desc), cols.ctypes.data, rows.ctypes.data, frames.ctypes.data, len(cols), width,
+                                      height, seed, out.ctypes.data)
+        return out
+
+    def opcount(self, desc, width, height, spp, seed=1):
+        c = np.zeros(6, dtype=np.uint64)
+        self.lib.oracle_opcount(C.byref(desc), width, height, spp, seed, c.ctypes.data)
+        return dict(zip(("add", "mul", "div", "sqrt", "transc", "cmp"), (int(v) for v in c)))
+
+    def sphere(self, o, d, c, radius):
+        o, d, c = (np.asarray(v, dtype=np.float32) for v in (o, d, c))
+        t = C.c_float(0)
+        hit = self.lib.oracle_sphere(o.ctypes.data, d.ctypes.data, c.ctypes.data, radius, C.byref(t))
+        return bool(hit), t.value
+
+    def plane(self, o, d, plane):
+        o, d = (np.asarray(v, dtype=np.float32) for v in (o, d))
+        t = C.c_float(0)
+        hit = self.lib.oracle_plane(o.ctypes.data, d.ctypes.data, C.byref(plane), C.byref(t))
+        return bool(hit), t.value
+
+    def luminance(self, c):
+        c = np.asarray(c, dtype=np.float32)
+        return self.lib.oracle_luminance(c.ctypes.data)
+
+    def material_defaults(self):
+        m = np.zeros(17, dtype=np.float32)
+        self.lib.oracle_material_defaults(m.ctypes.data)
+        return m
+
+    def material_finalize(self, m):
+        m = np.ascontiguousarray(m, dtype=np.float32)
+        out = np.zeros(4, dtype=np.float32)
+        self.lib.oracle_material_finalize(m.ctypes.data, out.ctypes.data)
+        return out
+
+    def gen_ray(self, cam, px, py, offx, offy, width, height):
+        cam = np.ascontiguousarray(cam, dtype=np.float32)
+        out = np.zeros(6, dtype=np.float32)
+        self.lib.oracle_gen_ray(cam.ctypes.data, px, py, offx, offy, width, height, out.ctypes.data)
+        return out
+
+    def disney_eval(self, m, eta, v, n, l):
+        m, v, n, l = (np.ascontiguousarray(a, dtype=np.float32) for a in (m, v, n, l))
+        out = np.zeros(4, dtype=np.float32)
+        self.lib.oracle_disney_eval(m.ctypes.data, eta, v.ctypes.data, n.ctypes.data, l.ctypes.data, out.ctypes.data)
+        return out
+
+    def disney_sample(self, m, eta, v, n, l_stale, fkey, pixel, counter):
+        m, v, n, l_stale = (np.ascontiguousarray(a, dtype=np.float32) for a in (m, v, n, l_stale))
+        out = np.zeros(8, dtype=np.float32)
+        self.lib.oracle_disney_sample(m.ctypes.data, eta, v.ctypes.data, n.ctypes.data, l_stale.ctypes.data, fkey, pixel,
+                                      counter, out.ctypes.data)
+        return out
+
+    def rng_u32(self, seed, frame, pixel, n):
+        out = np.zeros(n, dtype=np.uint32)
+        self.lib.oracle_rng_u32(seed, frame, pixel, n, out.ctypes.data)
+        return out
+
+    def rng_f32(self, seed, frame, pixel, n):
+        out = np.zeros(n, dtype=np.float32)
+        self.lib.oracle_rng_f32(seed, frame, pixel, n, out.ctypes.data)
+        return out
+
+    def math(self, fn, a, b=None):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float32)
+        out = np.zeros_like(a)
+        self.lib.oracle_math(fn, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
+        return out
+
+    def convert_to_u8(self, pixels, width, height):
+        pixels = np.ascontiguousarray(pixels, dtype=np.float32)
+        out = np.zeros(width * height * 4, dtype=np.uint8)
+        self.lib.oracle_convert_to_u8(pixels.ctypes.data, out.ctypes.data, width, height)
+        return out

@@ -1,0 +1,253 @@
+"""Parity of the HIP path with the CPU oracle, through the C ABI (needs an MI355X).
+
+Tolerance: NONE.  Both sides compute in f32 with the reference's operation order,
+correctly rounded divide/sqrt and the shared strict libm stand-in, so every pixel must be
+BIT-IDENTICAL (NaNs, if any, in the same places).  BASELINE.json's "per-pixel L2 error
+< 1e-4 after 256 spp" is therefore met with error exactly 0.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def assert_bit_identical(got, want, what=""):
+    got = np.asarray(got, dtype=np.float32)
+    want = np.asarray(want, dtype=np.float32)
+    assert got.shape == want.shape
+    nan_g, nan_w = np.isnan(got), np.isnan(want)
+    assert np.array_equal(nan_g, nan_w), "%s: NaN positions differ (%d vs %d)" % (what, nan_g.sum(), nan_w.sum())
+    ok = nan_g | (bits(got) == bits(want))
+    if not ok.all():
+        idx = np.argwhere(~ok)
+        first = tuple(idx[0])
+        diff = np.abs(got[~ok].astype(np.float64) - want[~ok].astype(np.float64))
+        raise AssertionError("%s: %d of %d values differ; first at %s: got %r want %r; max |diff| %g" %
+                             (what, (~ok).sum(), ok.size, first, got[first], want[first], diff.max()))
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def tracer(rpt, torch_cuda):
+    t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
+    yield t
+    t.close()
+
+
+def _probe(rpt, torch, tracer, fn, a, b=None):
+    ta = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    tb = torch.from_numpy(np.ascontiguousarray(b if b is not None else np.zeros_like(a), dtype=np.float32)).cuda()
+    out = torch.empty_like(ta)
+    stream = torch.cuda.current_stream().cuda_stream
+    rpt._lib.check(rpt.lib().rpt_probe_math(tracer._h, fn, ta.data_ptr(), tb.data_ptr(), out.data_ptr(), ta.numel(),
+                                            C.c_void_p(stream)), tracer._h)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def _random_floats(rng, n):
+    """All f32 bit patterns: uniform over the encodings (covers subnormals, inf, NaN)."""
+    return rng.integers(0, 2 ** 32, size=n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+
+
+@pytest.mark.parametrize("fn,name", [(0, "sin"), (1, "cos")])
+def test_probe_sincos(rpt, torch_cuda, tracer, oracle, fn, name):
+    rng = np.random.default_rng(10 + fn)
+    a = np.concatenate([rng.uniform(0, 2 * np.pi, 2_000_000), rng.uniform(-1e4, 1e4, 1_000_000),
+                        [0.0, -0.0, np.pi, 2 * np.pi, np.inf, -np.inf, np.nan, 1e-40, 6.2831855]]).astype(np.float32)
+    assert_bit_identical(_probe(rpt, torch_cuda, tracer, fn, a), oracle.math(fn, a), name)
+
+
+def test_probe_log2(rpt, torch_cuda, tracer, oracle):
+    rng = np.random.default_rng(12)
+    a = np.concatenate([_random_floats(rng, 2_000_000), rng.uniform(1e-6, 1e-2, 1_000_000).astype(np.float32),
+                        np.array([0.0, -0.0, 1.0, np.inf, -1.0, np.nan, 1e-45, 3.4e38], dtype=np.float32)])
+    assert_bit_identical(_probe(rpt, torch_cuda, tracer, 2, a), oracle.math(2, a), "log2")
+
+
+def test_probe_pow(rpt, torch_cuda, tracer, oracle):
+    rng = np.random.default_rng(13)
+    n = 1_000_000
+    a = np.concatenate([rng.uniform(0, 1.5, n), rng.uniform(1e-6, 1e-2, n), _random_floats(rng, n),
+                        [0.0, -0.0, 1.0, np.inf, -1.0, -8.0, -8.0, np.nan, 2.0, 0.5]]).astype(np.float32)
+    b = np.concatenate([np.full(n, 2.2), rng.uniform(0, 1, n), _random_floats(rng, n),
+                        [0.5, 0.5, np.nan, 2.0, np.inf, 3.0, 0.5, 0.0, 200.0, -200.0]]).astype(np.float32)
+    b[n // 2:n] = 0.4545
+    b[: n // 4] = 0.5
+    assert_bit_identical(_probe(rpt, torch_cuda, tracer, 3, a, b), oracle.math(3, a, b), "pow")
+
+
+def test_probe_div_sqrt_are_correctly_rounded(rpt, torch_cuda, tracer, oracle):
+    rng = np.random.default_rng(14)
+    n = 3_000_000
+    a, b = _random_floats(rng, n), _random_floats(rng, n)
+    assert_bit_identical(_probe(rpt, torch_cuda, tracer, 4, a, b), oracle.math(4, a, b), "div")
+    a2 = np.concatenate([rng.uniform(-4, 4, n), rng.uniform(0, 1e-38, 1000)]).astype(np.float32)
+    b2 = np.concatenate([rng.uniform(-4, 4, n), rng.uniform(0, 1e-38, 1000)]).astype(np.float32)
+    assert_bit_identical(_probe(rpt, torch_cuda, tracer, 4, a2, b2), oracle.math(4, a2, b2), "div (moderate range)")
+    assert_bit_identical(_probe(rpt, torch_cuda, tracer, 5, a), oracle.math(5, a), "sqrt")
+    assert_bit_identical(_probe(rpt, torch_cuda, tracer, 5, np.abs(a2)), oracle.math(5, np.abs(a2)), "sqrt (moderate range)")
+
+
+def test_probe_rng_first_draw(rpt, torch_cuda, tracer, oracle):
+    n = 4096
+    seed, frame = 1, 7
+    a = np.full(n, seed, dtype=np.uint32).view(np.float32)
+    b = np.full(n, frame, dtype=np.uint32).view(np.float32)
+    got = _probe(rpt, torch_cuda, tracer, 6, a, b)
+    want = np.array([oracle.rng_f32(seed, frame, p, 1)[0] for p in range(n)], dtype=np.float32)
+    assert_bit_identical(got, want, "rng")
+
+
+@pytest.mark.parametrize("w,h,spp", [(64, 48, 4), (160, 120, 8), (100, 75, 3), (17, 9, 2)])
+def test_render_matches_oracle(rpt, tracer, oracle, w, h, spp):
+    buf = rpt.ColorBuffer(w, h)
+    tracer.render_n(buf, spp)
+    want = oracle.render(oracle.scene_analytical(), w, h, spp, seed=1)
+    assert buf.frames == spp
+    assert_bit_identical(buf.image(), want, "render %dx%dx%d" % (w, h, spp))
+
+
+def test_render_800x600_1spp_config1(rpt, tracer, oracle):
+    """BASELINE.json configs[0]: the reference's own window size, one render() call."""
+    buf = rpt.ColorBuffer(800, 600)
+    tracer.render(buf)
+    want = oracle.render(oracle.scene_analytical(), 800, 600, 1, seed=1)
+    assert_bit_identical(buf.image(), want, "800x600x1")
+
+
+def test_render_golden_fixture(rpt, tracer):
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "analytical_64x48_spp4_seed1.npy")
+    want = np.load(path)
+    buf = rpt.ColorBuffer(64, 48)
+    tracer.render_n(buf, 4)
+    assert_bit_identical(buf.image(), want, "golden 64x48x4")
+
+
+def test_folded_spp_equals_repeated_render_calls(rpt, tracer):
+    """One launch of S samples == S reference-style render() calls (ColorBuffer.frames semantics)."""
+    w, h = 96, 64
+    a = rpt.ColorBuffer(w, h)
+    for _ in range(6):
+        tracer.render(a)
+    b = rpt.ColorBuffer(w, h)
+    tracer.render_n(b, 6)
+    c = rpt.ColorBuffer(w, h)
+    tracer.render_n(c, 2)
+    tracer.render_n(c, 4)
+    assert a.frames == b.frames == c.frames == 6
+    assert_bit_identical(a.image(), b.image(), "6x1 vs 1x6")
+    assert_bit_identical(a.image(), c.image(), "6x1 vs 2+4")
+
+
+def test_resume_from_frames(rpt, tracer, oracle):
+    """The ColorBuffer is the whole progressive state (buffer.rs:6-14): continuing from frames=5."""
+    w, h = 48, 32
+    desc = oracle.scene_analytical()
+    base = oracle.render(desc, w, h, 5, seed=1)
+    want = oracle.render(desc, w, h, 3, seed=1, frames_done=5, pixels=base.copy())
+    buf = rpt.ColorBuffer(w, h)
+    buf.pixels[:] = base.reshape(-1)
+    buf.frames = 5
+    tracer.render_n(buf, 3)
+    assert_bit_identical(buf.image(), want, "resume")
+
+
+def test_device_buffer_and_seed(rpt, torch_cuda, oracle):
+    w, h, spp = 80, 60, 4
+    t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=0xDEADBEEF12345)
+    buf = rpt.DeviceColorBuffer(w, h)
+    t.render_n(buf, spp)
+    torch_cuda.cuda.synchronize()
+    want = oracle.render(oracle.scene_analytical(), w, h, spp, seed=0xDEADBEEF12345)
+    assert_bit_identical(buf.pixels.cpu().numpy(), want, "device buffer, 64-bit seed")
+    t.close()
+
+
+@pytest.mark.parametrize("world,tile_rows", [(2, 2), (3, 4), (8, 2), (4, 16)])
+def test_row_tiling_is_independent_of_world(rpt, torch_cuda, tracer, world, tile_rows):
+    """Virtual ranks on one GPU: render each rank's tile, concatenate rank-major (what an
+    all-gather returns), untile, and compare with the single-GPU image bit for bit."""
+    from rust_pathtracer_amd import tiling
+    torch = torch_cuda
+    w, h, spp = 72, 54, 3
+    full = rpt.DeviceColorBuffer(w, h)
+    tracer.render_n(full, spp)
+    rows_padded = tiling.padded_rows(h, tile_rows, world)
+    gathered = torch.zeros(world, rows_padded, w, 4, dtype=torch.float32, device="cuda")
+    total = 0
+    for r in range(world):
+        total += tiling.tile_row_count(h, tile_rows, r, world)
+        tracer.render_tile(gathered[r], w, h, 0, spp, tile_rows, r, world)
+    assert total == h
+    img = tiling.untile(gathered, w, h, tile_rows, world, tracer)
+    torch.cuda.synchronize()
+    assert_bit_identical(img.cpu().numpy(), full.pixels.cpu().numpy(), "world=%d" % world)
+
+
+def test_convert_to_u8(rpt, torch_cuda, tracer, oracle):
+    w, h = 64, 48
+    buf = rpt.DeviceColorBuffer(w, h)
+    tracer.render_n(buf, 4)
+    # poke edge cases: negative, > 1, NaN, inf
+    buf.pixels[0, 0] = torch_cuda.tensor([-1.0, 2.0, float("nan"), float("inf")], device="cuda")
+    got = buf.convert_to_u8().cpu().numpy().reshape(-1)
+    want = oracle.convert_to_u8(buf.pixels.cpu().numpy(), w, h)
+    assert np.array_equal(got, want)
+
+
+def test_custom_scene_layered_materials_and_max_dist(rpt, oracle):
+    """A scene that is not the stock one: 3 spheres, 2 planes, 2 lights, emissive patch,
+    transmissive sphere, constant background, any_hit honouring max_dist."""
+    s = rpt.Scene()
+    s.camera = rpt.Pinhole((0.5, 1.0, 4.0), (0.0, 0.2, 0.0), 65.0)
+    s.materials = [
+        rpt.Material(rgb=(0.9, 0.9, 0.9), spec_trans=1.0, roughness=0.02, ior=1.45),
+        rpt.Material(rgb=(0.2, 0.5, 0.9), sheen=0.7, sheen_tint=0.5, subsurface=0.3, roughness=0.6),
+        rpt.Material(rgb=(0.8, 0.7, 0.2), metallic=1.0, anisotropic=0.6, roughness=0.3, specular_tint=0.4),
+        rpt.Material(rgb=(0.5, 0.5, 0.5), roughness=0.9),
+        rpt.Material(emission=(0.3, 0.1, 0.0), rgb=(0.3, 0.3, 0.3)),
+    ]
+    s.spheres = [((-1.4, 0.0, 0.0), 1.0, 0), ((1.0, -0.2, 0.3), 0.8, 1), ((0.0, 0.5, -2.0), 1.5, 2)]
+    s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 1e-4, 3), ((0.0, 0.0, 1.0), (0.0, 0.0, -6.0), 1e-4, 4)]
+    s.lights = [rpt.AnalyticalLight.spherical((3.0, 3.0, 2.0), 0.7, (6.0, 5.0, 4.0)),
+                rpt.AnalyticalLight.spherical((-3.0, 2.5, 1.0), 0.4, (2.0, 3.0, 6.0))]
+    s.background = dict(kind=rpt._abi.RPT_BG_CONSTANT, colour_a=(0.05, 0.06, 0.08), colour_b=(0, 0, 0), gamma=2.2, scale=1.0)
+    s.any_hit_uses_max_dist = True
+    s.max_depth = 6
+    w, h, spp = 96, 72, 4
+    t = rpt.Tracer(s, device=0, seed=3)
+    buf = rpt.ColorBuffer(w, h)
+    t.render_n(buf, spp)
+    want = oracle.render(s.describe(), w, h, spp, seed=3)
+    assert_bit_identical(buf.image(), want, "custom scene")
+    t.close()
+
+
+def test_error_paths(rpt):
+    lib = rpt.lib()
+    h = C.c_void_p()
+    assert lib.rpt_create(C.byref(h), 9999) == rpt._abi.RPT_ERR_INVALID_ARG
+    assert lib.rpt_create(C.byref(h), 0) == 0
+    px = np.zeros(16, dtype=np.float32)
+    assert lib.rpt_render(h, px.ctypes.data, 2, 2, 0, 1, 1, 0) == rpt._abi.RPT_ERR_NO_SCENE
+    assert b"no scene" in lib.rpt_last_error(h)
+    big = rpt.Scene()
+    big.materials = [rpt.Material(rgb=(1, 1, 1))]
+    big.spheres = [((float(i), 0.0, 0.0), 0.4, 0) for i in range(9)]
+    d = big.describe()
+    assert lib.rpt_upload_scene(h, C.byref(d)) == rpt._abi.RPT_ERR_UNSUPPORTED
+    lib.rpt_destroy(h)
