@@ -162,7 +162,10 @@ int rpt_scene_analytical(rpt_scene_desc* out);
 
 /* ---- render flags ---------------------------------------------------------- */
 enum {
-    RPT_RENDER_DEFAULT = 0u
+    RPT_RENDER_DEFAULT      = 0u,
+    /* Use the nested-loop kernel (sample loop outside, bounce loop inside) instead of
+     * the path-regenerating one.  Same image bit for bit; kept for A/B measurement. */
+    RPT_RENDER_NESTED_LOOPS = 1u << 0
 };
 
 /* ---- context --------------------------------------------------------------- */
@@ -188,8 +191,8 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* scene);
 int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height,
                uint64_t frames_done, uint32_t spp, uint64_t seed, uint32_t flags);
 
-/* Same on a DEVICE-resident buffer, asynchronously on `stream` (a hipStream_t, or
- * NULL for the context's stream).  With world > 1 the image is row-tiled: rows are
+/* Same on a DEVICE-resident buffer, asynchronously on `stream` (a hipStream_t; NULL is
+ * HIP's null stream).  With world > 1 the image is row-tiled: rows are
  * dealt in blocks of `tile_rows` rows, block b to rank b % world, and `pixels` is
  * this rank's COMPACT tile buffer (rpt_tile_row_count(...) rows of `width` RGBA
  * pixels).  The RNG is keyed by the global pixel, so the image does not depend on

@@ -13,8 +13,9 @@
  * ops), so gcc on the host and hipcc on the device produce identical bits.
  *
  * Accuracy (tests/test_strict_math.py checks these against mpmath/glibc):
- *   rpt_sincosf : <= 1 ulp for |x| <= 2^15 (the path only uses [0, 2*pi])
- *   rpt_tanf    : <= 2 ulp on the same range (host-only use: camera fov)
+ *   rpt_sincosf : <= 1.5 ulp (abs error < 7.1e-8) on [0, 2*pi], the only range the path
+ *                 uses; abs error < 3e-7 for |x| <= 3e4
+ *   rpt_tanf    : <= 3 ulp on (0, 1.5) (host-only use: camera fov)
  *   rpt_log2f   : f64 core, rounded once to f32 -> correctly rounded in all but
  *                 ~1e-7 of inputs
  *   rpt_powf    : f64 core (log2 abs err 1.5e-12, exp2 rel err 1.4e-14), rounded

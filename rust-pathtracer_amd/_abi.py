@@ -37,6 +37,9 @@ RPT_BG_GRADIENT_Y = 1
 
 RPT_SCENE_ANYHIT_USES_MAX_DIST = 1 << 0
 
+RPT_RENDER_DEFAULT = 0
+RPT_RENDER_NESTED_LOOPS = 1 << 0
+
 RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG = range(7)
 
 F3 = C.c_float * 3

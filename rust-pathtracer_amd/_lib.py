@@ -6,7 +6,7 @@ import os
 from . import _abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librpt_hip.so")
+LIB_PATH = os.environ.get("RPT_LIB", os.path.join(HERE, "librpt_hip.so"))   # RPT_LIB: experiment builds
 
 _lib = None
 
@@ -24,6 +24,14 @@ def lib():
             raise ImportError(
                 "%s not found: build it with `python -m rust_pathtracer_amd.build` or __graft_entry__.build(); "
                 "the product path has no CPU fallback" % LIB_PATH)
+        # torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  If this library were
+        # loaded first it would bind to /opt/rocm's copies and torch would then bring in a second
+        # HSA runtime, which cannot initialise (one /dev/kfd client per process): "no
+        # ROCm-capable device".  Importing torch first makes its runtime the process's only one.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _abi.SYMBOLS.items():
             fn = getattr(l, name)      # AttributeError if the library does not export a declared symbol

@@ -247,6 +247,7 @@ class Tracer:
         self._scene = scene
         self.seed = int(seed)
         self.device = int(device)
+        self.flags = 0                 # RPT_RENDER_* bits
         self._h = C.c_void_p()
         check(lib().rpt_create(C.byref(self._h), self.device))
         self.upload_scene()
@@ -268,7 +269,7 @@ class Tracer:
         if isinstance(buffer, ColorBuffer):
             assert buffer.pixels.dtype == np.float32 and buffer.pixels.size == buffer.width * buffer.height * 4
             check(lib().rpt_render(self._h, buffer.pixels.ctypes.data, buffer.width, buffer.height, buffer.frames,
-                                   spp, self.seed, 0), self._h)
+                                   spp, self.seed, self.flags), self._h)
         else:
             import torch
             px = buffer.pixels
@@ -276,7 +277,7 @@ class Tracer:
             assert (px.device.index or 0) == self.device
             stream = torch.cuda.current_stream(px.device).cuda_stream
             check(lib().rpt_render_device(self._h, px.data_ptr(), buffer.width, buffer.height, buffer.frames, spp,
-                                          self.seed, 0, buffer.height, 0, 1, C.c_void_p(stream)), self._h)
+                                          self.seed, self.flags, buffer.height, 0, 1, C.c_void_p(stream)), self._h)
         buffer.frames += spp                                       # tracer.rs:121
 
     def render_tile(self, tile_pixels, width, height, frames_done, spp, tile_rows, rank, world):
@@ -284,7 +285,7 @@ class Tracer:
         import torch
         assert tile_pixels.is_cuda and tile_pixels.is_contiguous() and tile_pixels.dtype == torch.float32
         stream = torch.cuda.current_stream(tile_pixels.device).cuda_stream
-        check(lib().rpt_render_device(self._h, tile_pixels.data_ptr(), width, height, frames_done, spp, self.seed, 0,
+        check(lib().rpt_render_device(self._h, tile_pixels.data_ptr(), width, height, frames_done, spp, self.seed, self.flags,
                                       tile_rows, rank, world, C.c_void_p(stream)), self._h)
 
     def close(self):

@@ -281,60 +281,94 @@ RPT_DEV RayD camera_ray(const DevCamera& cam, float px, float py, float offx, fl
     return RayD{mk3(cam.ox, cam.oy, cam.oz), norm3(rd)};
 }
 
-// One pixel-sample: tracer.rs:44-103.  Returns the radiance.
+// ---------------------------------------------------------------------------
+// The path as a resumable state machine.
+//
+// tracer.rs:44-103 is "for each sample { for each bounce { ... break ... } }".  Run
+// literally on a 64-wide wave, lanes whose path ended early idle until the longest
+// path of the wave ends (measured: 40 % VALU lane utilisation on the stock scene).
+// Here each lane owns the whole sample loop of its pixel: path_begin() starts a
+// sample, path_bounce() advances it by ONE bounce and says whether the path ended,
+// so the kernel can immediately regenerate a new camera path in that lane.  Each
+// sample's arithmetic and its position in the pixel's running mean are unchanged,
+// so the image is bit-identical to the nested-loop form.
+// ---------------------------------------------------------------------------
+struct PathRegs {
+    RayD ray;
+    v3 radiance, throughput;
+    PathState ps;
+    v3 scatter_l;              // ScatterSampleRec.l (zeros before the first bounce)
+    bool is_emitter;           // State.is_emitter, never cleared within a path (tracer.rs:53)
+    uint32_t bounce;
+    Rng rng;
+};
+
+// tracer.rs:44-57
+RPT_DEV void path_begin(const SceneSmall& sc, PathRegs& p, float px, float py, uint32_t fkey, uint32_t pixel_index)
+{
+    p.rng.init(fkey, pixel_index);
+    float offx = p.rng.gen();
+    float offy = p.rng.gen();
+    p.ray = camera_ray(sc.cam, px, py, offx, offy);
+    p.radiance = mk3(0.0f, 0.0f, 0.0f);
+    p.throughput = mk3(1.0f, 1.0f, 1.0f);
+    p.ps.hit_dist = -1.0f;
+    p.ps.light_pdf = 0.0f;
+    p.ps.light_emission = mk3(0.0f, 0.0f, 0.0f);
+    p.ps.scatter_pdf = 0.0f;
+    p.scatter_l = mk3(0.0f, 0.0f, 0.0f);
+    p.is_emitter = false;
+    p.bounce = 0;
+}
+
+// One iteration of the loop at tracer.rs:61-103.  Returns true when the path is over
+// (miss, emitter, pdf <= 0, or the depth is exhausted) and p.radiance is final.
+RPT_DEV bool path_bounce(const SceneSmall& sc, PathRegs& p)
+{
+    HitInfo hi;
+    hi.is_emitter = p.is_emitter;
+    hi.normal = mk3(0.0f, 0.0f, 0.0f);
+    bool hit = closest_hit(sc, p.ray, p.ps, hi);
+    p.is_emitter = hi.is_emitter;
+    if (!hit) {
+        p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
+        return true;
+    }
+    // State::finalize, globals.rs:50-62
+    v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
+    float ndd = dot3(hi.normal, p.ray.d);
+    v3 ffnormal = (ndd <= 0.0f) ? hi.normal : -hi.normal;
+    mat_finalize(hi.mat);
+    float eta = (ndd < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
+
+    p.radiance = p.radiance + hi.mat.emission * p.throughput;
+    if (p.is_emitter) {
+        // state.depth > 0 always holds (tracer.rs:57,80): the MIS weight is always applied
+        float mis_weight = power_heuristic(p.ps.scatter_pdf, p.ps.light_pdf);
+        p.radiance = p.radiance + (mis_weight * p.ps.light_emission) * p.throughput;
+        return true;
+    }
+    p.radiance = p.radiance + direct_light(sc, p.ray, hi.mat, eta, fhp, ffnormal, p.rng) * p.throughput;
+
+    float pdf;
+    v3 f = disney_sample(hi.mat, eta, -p.ray.d, ffnormal, p.scatter_l, pdf, p.rng);
+    p.ps.scatter_pdf = pdf;
+    if (!(pdf > 0.0f)) return true;
+    p.throughput = p.throughput * divs3(f, pdf);
+    p.ray.d = p.scatter_l;
+    p.ray.o = fhp + sc.eps * p.ray.d;
+    p.bounce += 1;
+    return p.bounce >= sc.max_depth;
+}
+
+// One pixel-sample start to end (the nested-loop form; kept for the A/B kernel).
 RPT_DEV v3 trace_sample(const SceneSmall& sc, float px, float py, uint32_t fkey, uint32_t pixel_index)
 {
-    Rng rng;
-    rng.init(fkey, pixel_index);
-    float offx = rng.gen();
-    float offy = rng.gen();
-    RayD ray = camera_ray(sc.cam, px, py, offx, offy);
-
-    v3 radiance = mk3(0.0f, 0.0f, 0.0f);
-    v3 throughput = mk3(1.0f, 1.0f, 1.0f);
-    PathState ps;
-    ps.hit_dist = -1.0f;
-    ps.light_pdf = 0.0f;
-    ps.light_emission = mk3(0.0f, 0.0f, 0.0f);
-    ps.scatter_pdf = 0.0f;
-    v3 scatter_l = mk3(0.0f, 0.0f, 0.0f);                           // ScatterSampleRec.l, zeros before the first bounce
-    bool is_emitter = false;                                        // State.is_emitter, never cleared (tracer.rs:53)
-
-    for (uint32_t bounce = 0; bounce < sc.max_depth; ++bounce) {
-        HitInfo hi;
-        hi.is_emitter = is_emitter;
-        hi.normal = mk3(0.0f, 0.0f, 0.0f);
-        bool hit = closest_hit(sc, ray, ps, hi);
-        is_emitter = hi.is_emitter;
-        if (!hit) {
-            radiance = radiance + background(sc, ray) * throughput;
-            break;
-        }
-        // State::finalize, globals.rs:50-62
-        v3 fhp = ray.o + ps.hit_dist * ray.d;
-        float ndd = dot3(hi.normal, ray.d);
-        v3 ffnormal = (ndd <= 0.0f) ? hi.normal : -hi.normal;
-        mat_finalize(hi.mat);
-        float eta = (dot3(ray.d, hi.normal) < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
-
-        radiance = radiance + hi.mat.emission * throughput;
-        if (is_emitter) {
-            // state.depth > 0 always holds (tracer.rs:57,80): the MIS weight is always applied
-            float mis_weight = power_heuristic(ps.scatter_pdf, ps.light_pdf);
-            radiance = radiance + (mis_weight * ps.light_emission) * throughput;
-            break;
-        }
-        radiance = radiance + direct_light(sc, ray, hi.mat, eta, fhp, ffnormal, rng) * throughput;
-
-        float pdf;
-        v3 f = disney_sample(hi.mat, eta, -ray.d, ffnormal, scatter_l, pdf, rng);
-        ps.scatter_pdf = pdf;
-        if (pdf > 0.0f) throughput = throughput * divs3(f, pdf);
-        else break;
-        ray.d = scatter_l;
-        ray.o = fhp + sc.eps * ray.d;
-    }
-    return radiance;
+    PathRegs p;
+    path_begin(sc, p, px, py, fkey, pixel_index);
+    if (sc.max_depth == 0) return p.radiance;
+    while (!path_bounce(sc, p)) {}
+    return p.radiance;
 }
 
 }  // namespace rptdev

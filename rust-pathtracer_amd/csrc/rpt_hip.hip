@@ -43,25 +43,30 @@ static uint32_t tile_row_count(uint32_t height, uint32_t tile_rows, uint32_t ran
 // kernels
 // ---------------------------------------------------------------------------
 
-// Megakernel, one thread per pixel, `spp` samples per launch.  A wave covers an 8x8
-// pixel block (coherent paths), a 256-thread workgroup a 16x16 block.  The running
-// mean of tracer.rs:105-117 is carried in registers across the launch's samples and
-// updated with the reference's own expression once per sample, so one launch of S
-// samples is bit-identical to S reference render() calls; the framebuffer is read
-// and written once per launch as float4 (16 B per lane, 128 B per 8-pixel row).
-__global__ __launch_bounds__(256) void render_small_kernel(const SceneSmall sc, const RenderParams rp)
+// Per-pixel setup shared by both render kernels: tracer.rs:34-46.
+struct PixelSetup {
+    bool valid;
+    uint32_t pixel_index;
+    float px, py;                     // coord of tracer.rs:46
+    float4* pix;
+};
+
+RPT_DEV PixelSetup pixel_setup(const RenderParams& rp)
 {
-    const uint32_t tile = blockIdx.x;
+    // A wave covers an 8x8 pixel block (coherent paths), a 256-thread workgroup 16x16.
+    PixelSetup ps;
+    // Bottom rows are dispatched first: in the usual outdoor framing they are the expensive
+    // ones (floor / objects), so the cheap sky tiles fill the tail of the launch (+3 %).
+    const uint32_t tile = gridDim.x - 1u - blockIdx.x;
     const uint32_t tx = tile % rp.tiles_x;
     const uint32_t ty = tile / rp.tiles_x;
     const uint32_t wave = threadIdx.x >> 6;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t col = tx * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t lrow = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
-    if (col >= rp.width || lrow >= rp.rows_local) return;
+    ps.valid = (col < rp.width) && (lrow < rp.rows_local);
     const uint32_t grow = tile_global_row(lrow, rp.tile_rows, rp.rank, rp.world);
-
-    // tracer.rs:34-46: coord of this pixel (j counts rows from the bottom)
+    // j counts rows from the bottom (par_rchunks, tracer.rs:29-37)
     const float W = (float)rp.width;
     const float H = (float)rp.height;
     const uint32_t j = rp.height - 1u - grow;
@@ -69,24 +74,90 @@ __global__ __launch_bounds__(256) void render_small_kernel(const SceneSmall sc, 
     const float y = H - (float)j;
     const float xx = x / W;
     const float yy = y / H;
-    const float px = xx;
-    const float py = 1.0f - yy;
-    const uint32_t pixel_index = grow * rp.width + col;
+    ps.px = xx;
+    ps.py = 1.0f - yy;
+    ps.pixel_index = grow * rp.width + col;
+    ps.pix = reinterpret_cast<float4*>(rp.pixels) + ((size_t)lrow * rp.width + col);
+    return ps;
+}
 
-    float4* pix = reinterpret_cast<float4*>(rp.pixels) + ((size_t)lrow * rp.width + col);
-    float4 acc = *pix;
+// mix_color, tracer.rs:108-113, with color = [r, g, b, 1.0] (tracer.rs:59,105)
+RPT_DEV void blend(float4& acc, v3 rad, float v)
+{
+    acc.x = (1.0f - v) * acc.x + rad.x * v;
+    acc.y = (1.0f - v) * acc.y + rad.y * v;
+    acc.z = (1.0f - v) * acc.z + rad.z * v;
+    acc.w = (1.0f - v) * acc.w + 1.0f * v;
+}
 
+// Megakernel, one thread per pixel, `spp` samples per launch, nested-loop form
+// (sample loop outside, bounce loop inside; lanes whose path ended idle until the
+// wave's longest path ends).  Kept as the A/B baseline for the regenerating kernel.
+// The running mean of tracer.rs:105-117 is carried in registers across the launch's
+// samples and updated with the reference's own expression once per sample, so one
+// launch of S samples is bit-identical to S reference render() calls; the framebuffer
+// is read and written once per launch as float4 (16 B per lane, 128 B per 8-pixel row).
+__global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSmall sc, const RenderParams rp)
+{
+    const PixelSetup ps = pixel_setup(rp);
+    if (!ps.valid) return;
+    float4 acc = *ps.pix;
     for (uint32_t s = 0; s < rp.spp; ++s) {
         const uint64_t frames = rp.frames_done + s;
         const uint32_t fkey = frame_key_hd(rp.seed, frames);
         const float v = 1.0f / (float)(frames + 1);                 // tracer.rs:115
-        const v3 rad = trace_sample(sc, px, py, fkey, pixel_index);
-        acc.x = (1.0f - v) * acc.x + rad.x * v;                     // mix_color, tracer.rs:108-113
-        acc.y = (1.0f - v) * acc.y + rad.y * v;
-        acc.z = (1.0f - v) * acc.z + rad.z * v;
-        acc.w = (1.0f - v) * acc.w + 1.0f * v;
+        const v3 rad = trace_sample(sc, ps.px, ps.py, fkey, ps.pixel_index);
+        blend(acc, rad, v);
     }
-    *pix = acc;
+    *ps.pix = acc;
+}
+
+// The production megakernel: same arithmetic, but each lane runs its pixel's sample
+// loop as a state machine (dev_integrator.h, PathRegs) — when a lane's path ends it
+// blends the sample into its running mean and starts the next camera path at once
+// (path regeneration), so every loop iteration has all unfinished lanes doing one
+// closest-hit query.  The per-sample frame key and blend weight 1/(frames+1) are
+// wave-divergent now (lanes drift apart in sample index), so the workgroup computes
+// them once into LDS tables and lanes index them.
+constexpr uint32_t kMaxSppPerLaunch = 1024;
+
+// Minimum waves per SIMD the register allocator must leave room for (2nd argument of
+// __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
+#ifndef RPT_WAVES_PER_SIMD
+#define RPT_WAVES_PER_SIMD 3
+#endif
+
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_kernel(const SceneSmall sc, const RenderParams rp)
+{
+    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
+    __shared__ float s_weight[kMaxSppPerLaunch];
+    for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
+        const uint64_t frames = rp.frames_done + i;
+        s_fkey[i] = frame_key_hd(rp.seed, frames);
+        s_weight[i] = 1.0f / (float)(frames + 1);                   // tracer.rs:115
+    }
+    __syncthreads();
+
+    const PixelSetup ps = pixel_setup(rp);
+    if (!ps.valid) return;
+    float4 acc = *ps.pix;
+
+    uint32_t s = 0;
+    PathRegs p;
+    path_begin(sc, p, ps.px, ps.py, s_fkey[0], ps.pixel_index);
+    const bool no_bounces = (sc.max_depth == 0);
+    bool ended = no_bounces;
+    for (;;) {
+        if (!ended) ended = path_bounce(sc, p);
+        if (ended) {
+            blend(acc, p.radiance, s_weight[s]);
+            s += 1;
+            if (s >= rp.spp) break;
+            path_begin(sc, p, ps.px, ps.py, s_fkey[s], ps.pixel_index);
+            ended = no_bounces;
+        }
+    }
+    *ps.pix = acc;
 }
 
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
@@ -397,7 +468,6 @@ uint32_t rpt_tile_global_row(uint32_t local_row, uint32_t tile_rows, uint32_t ra
 int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp,
                       uint64_t seed, uint32_t flags, uint32_t tile_rows, uint32_t rank, uint32_t world, void* stream)
 {
-    (void)flags;
     if (!ctx) { set_err(nullptr, "rpt_render_device: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (!ctx->has_scene) { set_err(ctx, "rpt_render_device: no scene uploaded"); return RPT_ERR_NO_SCENE; }
     if (!pixels_dev || width == 0 || height == 0 || world == 0 || rank >= world || tile_rows == 0) {
@@ -428,9 +498,20 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;
     if (nblocks > 0x7FFFFFFFull) { set_err(ctx, "rpt_render_device: grid too large"); return RPT_ERR_INVALID_ARG; }
 
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-    hipLaunchKernelGGL(render_small_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
-    RPT_HIP_CHECK(ctx, hipGetLastError());
+    hipStream_t st = (hipStream_t)stream;
+    // The LDS tables of the regenerating kernel hold kMaxSppPerLaunch samples: larger
+    // batches are split into consecutive launches (the running mean carries over).
+    for (uint32_t done = 0; done < spp;) {
+        const uint32_t chunk = (spp - done > kMaxSppPerLaunch) ? kMaxSppPerLaunch : (spp - done);
+        rp.spp = chunk;
+        rp.frames_done = frames_done + done;
+        if (flags & RPT_RENDER_NESTED_LOOPS)
+            hipLaunchKernelGGL(render_small_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
+        else
+            hipLaunchKernelGGL(render_small_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
+        RPT_HIP_CHECK(ctx, hipGetLastError());
+        done += chunk;
+    }
     return RPT_OK;
 }
 
@@ -465,7 +546,7 @@ int rpt_untile_device(rpt_ctx* ctx, const float* gathered_dev, float* image_dev,
     RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint64_t total = (uint64_t)width * height;
     const uint64_t nblocks = (total + 255) / 256;
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, (const float4*)gathered_dev, (float4*)image_dev, width,
                        height, tile_rows, world, rows_padded);
     RPT_HIP_CHECK(ctx, hipGetLastError());
@@ -479,7 +560,7 @@ int rpt_convert_to_u8_device(rpt_ctx* ctx, const float* pixels_dev, uint8_t* out
     RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint64_t total = (uint64_t)width * height;
     const uint64_t nblocks = (total + 255) / 256;
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(convert_to_u8_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, (const float4*)pixels_dev, (uint32_t*)out_dev, total);
     RPT_HIP_CHECK(ctx, hipGetLastError());
     return RPT_OK;
@@ -489,7 +570,7 @@ int rpt_synchronize(rpt_ctx* ctx, void* stream)
 {
     if (!ctx) { set_err(nullptr, "rpt_synchronize: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    RPT_HIP_CHECK(ctx, hipStreamSynchronize(stream ? (hipStream_t)stream : ctx->stream));
+    RPT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
     return RPT_OK;
 }
 
@@ -500,7 +581,7 @@ int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b
     if (n == 0) return RPT_OK;
     RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const uint64_t nblocks = (n + 255) / 256;
-    hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(probe_math_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, fn, a_dev, b_dev, out_dev, n);
     RPT_HIP_CHECK(ctx, hipGetLastError());
     return RPT_OK;

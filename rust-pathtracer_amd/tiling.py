@@ -50,6 +50,15 @@ def untile(gathered, width, height, tile_rows, world, tracer=None):
     return gathered[src_rank, src_row]
 
 
+def all_gather_tiles(tile, world, group=None):
+    """All-gather equal-size tiles -> [world, rows_padded, width, 4] (rank-major).  The output is
+    allocated in the concatenated form, which both the nccl (RCCL) and gloo backends accept."""
+    import torch.distributed as dist
+    out = torch.empty((world * tile.shape[0],) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
+    dist.all_gather_into_tensor(out, tile, group=group)
+    return out.view((world,) + tuple(tile.shape))
+
+
 class TiledRender:
     """Progressive render of one image over the ranks of a torch.distributed group."""
 
@@ -76,6 +85,5 @@ class TiledRender:
         if self.world == 1:
             return self.tile[: self.height].clone() if self.rows == self.height else untile(
                 self.tile.unsqueeze(0), self.width, self.height, self.tile_rows, 1, self.tracer)
-        out = torch.empty(self.world, self.rows_padded, self.width, 4, dtype=torch.float32, device=self.tile.device)
-        self.dist.all_gather_into_tensor(out, self.tile, group=self.group)
+        out = all_gather_tiles(self.tile, self.world, self.group)
         return untile(out, self.width, self.height, self.tile_rows, self.world, self.tracer)

@@ -1,0 +1,112 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/rpt.h declares, and the
+ctypes mirror of the structs matches the C layout.  No compute calls (CPU only)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "rpt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rpt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(rpt):
+    names = _declared_functions()
+    assert len(names) >= 14
+    lib = C.CDLL(os.path.join(ROOT, "rust-pathtracer_amd", "librpt_hip.so"))
+    for n in names:
+        assert hasattr(lib, n), "librpt_hip.so does not export %s" % n
+    assert sorted(rpt._abi.SYMBOLS) == names, "ctypes mirror and header disagree"
+    assert rpt.lib().rpt_abi_version() == rpt._abi.RPT_ABI_VERSION
+
+
+def test_struct_layout_matches_c(rpt, tmp_path):
+    prog = tmp_path / "layout.c"
+    prog.write_text(r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "rpt.h"
+#define S(t) printf(#t " %zu\n", sizeof(t))
+#define O(t, f) printf(#t "." #f " %zu\n", offsetof(t, f))
+int main(void) {
+  S(rpt_material); S(rpt_sphere); S(rpt_plane); S(rpt_light); S(rpt_camera); S(rpt_background); S(rpt_scene_desc);
+  O(rpt_material, rgb); O(rpt_material, ior); O(rpt_material, proc_params);
+  O(rpt_light, radius); O(rpt_light, area); O(rpt_plane, min_denom);
+  O(rpt_scene_desc, camera); O(rpt_scene_desc, background); O(rpt_scene_desc, eps); O(rpt_scene_desc, spheres);
+  O(rpt_scene_desc, planes); O(rpt_scene_desc, lights); O(rpt_scene_desc, n_materials); O(rpt_scene_desc, materials);
+  return 0; }''')
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)], check=True)
+    out = dict(line.rsplit(" ", 1) for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    A = rpt._abi
+    for name in ("rpt_material", "rpt_sphere", "rpt_plane", "rpt_light", "rpt_camera", "rpt_background", "rpt_scene_desc"):
+        assert C.sizeof(getattr(A, name)) == int(out[name]), name
+    for key, val in out.items():
+        if "." in key:
+            t, f = key.split(".")
+            assert getattr(getattr(A, t), f).offset == int(val), key
+
+
+def test_no_gpu_means_loud_failure_not_fallback(rpt):
+    """Without a device the product refuses to run (this container has no GPU); with one, the
+    call succeeds.  Either way nothing is computed on the CPU."""
+    import torch
+    h = C.c_void_p()
+    rc = rpt.lib().rpt_create(C.byref(h), 0)
+    if torch.cuda.is_available():
+        assert rc == 0
+        rpt.lib().rpt_destroy(h)
+    else:
+        assert rc == rpt._abi.RPT_ERR_NO_DEVICE
+        assert b"no CPU fallback" in rpt.lib().rpt_last_error(None)
+        try:
+            rpt.Tracer(rpt.AnalyticalScene())
+            raise AssertionError("Tracer() must raise without a GPU")
+        except rpt.RptError as e:
+            assert e.status == rpt._abi.RPT_ERR_NO_DEVICE
+
+
+def test_scene_builders_agree(rpt, oracle):
+    """rpt_scene_analytical (product), AnalyticalScene().describe() (host mirror) and the oracle's own
+    transcription of renderer/src/analytical.rs are byte-identical."""
+    def dump(d):
+        out = [d.abi_version, d.flags, bytes(d.camera), bytes(d.background), d.eps, d.max_depth,
+               d.n_spheres, d.n_planes, d.n_lights, d.n_materials]
+        out += [bytes(d.spheres[i]) for i in range(d.n_spheres)] + [bytes(d.planes[i]) for i in range(d.n_planes)]
+        out += [bytes(d.lights[i]) for i in range(d.n_lights)] + [bytes(d.materials[i]) for i in range(d.n_materials)]
+        return out
+    p = rpt._abi.rpt_scene_desc()
+    assert rpt.lib().rpt_scene_analytical(C.byref(p)) == 0
+    s = rpt.AnalyticalScene()
+    assert dump(p) == dump(oracle.scene_analytical()) == dump(s.describe())
+    assert (p.n_spheres, p.n_planes, p.n_lights, p.max_depth) == (2, 1, 1, 4)
+
+
+def test_argument_validation_without_gpu(rpt):
+    lib = rpt.lib()
+    assert lib.rpt_create(None, 0) == rpt._abi.RPT_ERR_INVALID_ARG
+    assert lib.rpt_render(None, None, 1, 1, 0, 1, 1, 0) == rpt._abi.RPT_ERR_INVALID_ARG
+    assert lib.rpt_upload_scene(None, None) == rpt._abi.RPT_ERR_INVALID_ARG
+    assert lib.rpt_scene_analytical(None) == rpt._abi.RPT_ERR_INVALID_ARG
+    lib.rpt_destroy(None)                                     # harmless
+
+
+def test_tile_row_maps(rpt):
+    """Cyclic row-block tiling: every row belongs to exactly one rank, in order within a rank."""
+    from rust_pathtracer_amd import tiling
+    for height, tile_rows, world in ((1080, 2, 8), (1080, 16, 8), (54, 4, 3), (7, 2, 4), (2160, 8, 8), (5, 8, 2), (9, 1, 9)):
+        owner = {}
+        for r in range(world):
+            rows = tiling.tile_global_rows(height, tile_rows, r, world)
+            assert rows == sorted(rows)
+            assert len(rows) == tiling.tile_row_count(height, tile_rows, r, world)
+            for g in rows:
+                assert g not in owner and (g // tile_rows) % world == r
+                owner[g] = r
+        assert sorted(owner) == list(range(height))
+        counts = [tiling.tile_row_count(height, tile_rows, r, world) for r in range(world)]
+        assert max(counts) - min(counts) <= tile_rows
