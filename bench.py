@@ -51,7 +51,7 @@ def cpu_baseline(width, height, budget_s=12.0):
     o.render(desc, width, height, 1, seed=1, pixels=px, threads=threads)     # calibration frame (also warms the threads)
     t1 = time.perf_counter()
     rate = width * height / (t1 - t0)
-    spp = max(1, min(64, int(budget_s * rate / (width * height))))
+    spp = max(1, min(1024, int(budget_s * rate / (width * height))))
     t0 = time.perf_counter()
     o.render(desc, width, height, spp, seed=1, frames_done=1, pixels=px, threads=threads)
     t1 = time.perf_counter()
