@@ -11,7 +11,13 @@ HEADERS = ["dev_math.h", "dev_bsdf.h", "dev_scene.h", "dev_integrator.h",
            os.path.join("..", "..", "include", "rpt.h"), os.path.join("..", "..", "include", "rpt_strict_math.h")]
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
 # fused operations are the explicit fma calls of rpt_strict_math.h.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+# -mllvm -disable-machine-licm: MachineLICM hoists the materialisation of ~70 literal constants (the
+#   f64 polynomial coefficients of rpt_strict_math.h, two VGPRs each) out of the sample loop, where
+#   they stay live for the whole kernel: 183 VGPRs (2 waves/SIMD) with it, 115 without.
+# -fno-slp-vectorize: SLP packs scalar f32 ops into v_pk_mul/add_f32, which issue at half rate on
+#   gfx950 and need paired registers: 115 -> 95 VGPRs and +6 % throughput without it.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
+         "-mllvm", "-disable-machine-licm", "-fPIC", "-shared"]
 
 
 def _hipcc():

@@ -255,22 +255,35 @@ RPT_DEV v3 refract3(v3 i, v3 n, float eta)                                      
     return eta * i - (eta * ndi + __builtin_sqrtf(k)) * n;
 }
 
+// What disney_sample (tracer.rs:449-486) and disney_eval (tracer.rs:559-591) both
+// compute first from the same inputs: the tangent frame of the shading normal, the view
+// vector in it, and the specular / sheen colours.  Built once per bounce and shared.
+struct ShadeFrame {
+    v3 t, b;                   // onb(n)
+    v3 v;                      // to_local(v_world)
+    v3 spec_col, sheen_col;    // get_spec_color
+};
+
+RPT_DEV ShadeFrame make_frame(const Mat& m, float eta, v3 v_world, v3 n)
+{
+    ShadeFrame fr;
+    onb(n, fr.t, fr.b);
+    fr.v = to_local(fr.t, fr.b, n, v_world);
+    get_spec_color(m, eta, fr.spec_col, fr.sheen_col);
+    return fr;
+}
+
 // tracer.rs:441-553.  l_io: in = the previous bounce's world-space direction (zeros
 // on the first bounce) which the specular branch reads before overwriting it
 // (tracer.rs:531); out = the sampled world-space direction.
-RPT_DEV v3 disney_sample(const Mat& m, float eta, v3 v, v3 n, v3& l_io, float& pdf, Rng& rng)
+RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3& l_io, float& pdf, Rng& rng)
 {
     pdf = 0.0f;
     v3 f;
     float r1 = rng.gen();
     float r2 = rng.gen();
 
-    v3 t, b;
-    onb(n, t, b);
-    v = to_local(t, b, n, v);
-
-    v3 spec_col, sheen_col;
-    get_spec_color(m, eta, spec_col, sheen_col);
+    const v3 t = fr.t, b = fr.b, v = fr.v, spec_col = fr.spec_col, sheen_col = fr.sheen_col;
     float approx_fresnel = disney_fresnel(m, eta, v.z, v.z);
     LobeWeights w = get_lobe_probabilities(m, spec_col, approx_fresnel);
 
@@ -314,13 +327,11 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, v3 v, v3 n, v3& l_io, float& p
 }
 
 // tracer.rs:555-626
-RPT_DEV v3 disney_eval(const Mat& m, float eta, v3 v_world, v3 n, v3 l_world, float& bsdf_pdf)
+RPT_DEV v3 disney_eval(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3 l_world, float& bsdf_pdf)
 {
     bsdf_pdf = 0.0f;
     v3 f = mk3(0.0f, 0.0f, 0.0f);
-    v3 t, b;
-    onb(n, t, b);
-    v3 v = to_local(t, b, n, v_world);
+    const v3 t = fr.t, b = fr.b, v = fr.v, spec_col = fr.spec_col, sheen_col = fr.sheen_col;
     v3 l = to_local(t, b, n, l_world);
 
     v3 h;
@@ -328,8 +339,6 @@ RPT_DEV v3 disney_eval(const Mat& m, float eta, v3 v_world, v3 n, v3 l_world, fl
     else h = norm3(l + eta * v);
     if (h.z < 0.0f) h = -h;
 
-    v3 spec_col, sheen_col;
-    get_spec_color(m, eta, spec_col, sheen_col);
     float fresnel = disney_fresnel(m, eta, dot3(l, h), dot3(v, h));
     LobeWeights w = get_lobe_probabilities(m, spec_col, fresnel);
 

@@ -75,10 +75,11 @@ RPT_DEV void apply_patch(Mat& m, const DevMaterial& p, bool on, v3 dir)
 
 // Path state that survives from one bounce to the next (tracer.rs:51-57):
 // hit_dist is deliberately NOT reset per bounce (scene.rs:66 reads the stale value).
+// The reference also keeps light_sample and state.is_emitter alive across bounces
+// (tracer.rs:53-54), but they are only ever read in the bounce that wrote them (an
+// emitter hit ends the path, tracer.rs:77-87), so here they are per-bounce locals.
 struct PathState {
     float hit_dist;            // State.hit_dist, starts at -1 (globals.rs:28)
-    float light_pdf;           // LightSampleRec.pdf written by Scene::sample_lights
-    v3 light_emission;
     float scatter_pdf;         // ScatterSampleRec.pdf of the previous bounce (MIS, tracer.rs:81)
 };
 
@@ -86,6 +87,8 @@ struct HitInfo {
     v3 normal;
     Mat mat;
     bool is_emitter;
+    float light_pdf;           // LightSampleRec.pdf / .emission written by Scene::sample_lights
+    v3 light_emission;
 };
 
 // AnalyticalScene::closest_hit (analytical.rs:36-127) + Scene::sample_lights
@@ -131,7 +134,9 @@ RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, H
         ps.hit_dist = dist;                                         // analytical.rs:48,79,104
         v3 hp = ray.o + dist * ray.d;                               // ray.at(d)
         v3 sn = norm3(hp - c);
-        hi.normal = win_plane ? pn : sn;
+        hi.normal.x = win_plane ? pn.x : sn.x;                      // (per component: a struct select goes through scratch)
+        hi.normal.y = win_plane ? pn.y : sn.y;
+        hi.normal.z = win_plane ? pn.z : sn.z;
     }
 
     // material = Material::new() then the accepted primitives' writes, in order
@@ -153,8 +158,8 @@ RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, H
                 ldist = t;
                 v3 hit_point = ray.o + t * ray.d;
                 float cos_theta = dot3(-ray.d, norm3(hit_point - pos));
-                ps.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
-                ps.light_emission = mk3(L.ex, L.ey, L.ez);
+                hi.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
+                hi.light_emission = mk3(L.ex, L.ey, L.ez);
                 hi.is_emitter = true;
                 ps.hit_dist = t;
                 hit = true;
@@ -233,7 +238,7 @@ RPT_DEV void sample_light(const SceneSmall& sc, const DevLight& L, v3 scatter_po
 }
 
 // tracer.rs:126-170
-RPT_DEV v3 direct_light(const SceneSmall& sc, const RayD& ray, const Mat& mat, float eta, v3 fhp, v3 ffnormal, Rng& rng)
+RPT_DEV v3 direct_light(const SceneSmall& sc, const Mat& mat, float eta, const ShadeFrame& fr, v3 fhp, v3 ffnormal, Rng& rng)
 {
     v3 ld = mk3(0.0f, 0.0f, 0.0f);
     if (sc.n_lights == 0) return ld;
@@ -262,7 +267,7 @@ RPT_DEV v3 direct_light(const SceneSmall& sc, const RayD& ray, const Mat& mat, f
         bool in_shadow = any_hit(sc, shadow, ls.dist - sc.eps);
         if (!in_shadow) {
             float bsdf_pdf;
-            v3 f = disney_eval(mat, eta, -ray.d, ffnormal, ls.direction, bsdf_pdf);
+            v3 f = disney_eval(mat, eta, fr, ffnormal, ls.direction, bsdf_pdf);
             float mis_weight = 1.0f;
             if (L.area > 0.0f) mis_weight = power_heuristic(ls.pdf, bsdf_pdf);
             if (bsdf_pdf > 0.0f) ld = ld + (mis_weight * li) * divs3(f, ls.pdf);
@@ -297,9 +302,8 @@ struct PathRegs {
     RayD ray;
     v3 radiance, throughput;
     PathState ps;
-    v3 scatter_l;              // ScatterSampleRec.l (zeros before the first bounce)
-    bool is_emitter;           // State.is_emitter, never cleared within a path (tracer.rs:53)
-    uint32_t bounce;
+    uint32_t bounce;           // ScatterSampleRec.l needs no register: it is zeros before the first
+                               // bounce and equals ray.d afterwards (tracer.rs:100)
     Rng rng;
 };
 
@@ -313,52 +317,77 @@ RPT_DEV void path_begin(const SceneSmall& sc, PathRegs& p, float px, float py, u
     p.radiance = mk3(0.0f, 0.0f, 0.0f);
     p.throughput = mk3(1.0f, 1.0f, 1.0f);
     p.ps.hit_dist = -1.0f;
-    p.ps.light_pdf = 0.0f;
-    p.ps.light_emission = mk3(0.0f, 0.0f, 0.0f);
     p.ps.scatter_pdf = 0.0f;
-    p.scatter_l = mk3(0.0f, 0.0f, 0.0f);
-    p.is_emitter = false;
     p.bounce = 0;
 }
 
-// One iteration of the loop at tracer.rs:61-103.  Returns true when the path is over
-// (miss, emitter, pdf <= 0, or the depth is exhausted) and p.radiance is final.
-RPT_DEV bool path_bounce(const SceneSmall& sc, PathRegs& p)
+// What a surface hit leaves behind for the shading half of the bounce (State after
+// State::finalize, globals.rs:50-62).
+struct SurfaceHit {
+    Mat mat;
+    v3 ffnormal, fhp;
+    float eta;
+};
+
+// First half of one iteration of the loop at tracer.rs:61-103: closest_hit, the miss
+// and emitter exits (tracer.rs:64-87).  Returns true when a surface was hit and `sh` is
+// filled (shading still to do); false when the path is over and p.radiance is final.
+RPT_DEV bool path_trace(const SceneSmall& sc, PathRegs& p, SurfaceHit& sh)
 {
     HitInfo hi;
-    hi.is_emitter = p.is_emitter;
+    hi.is_emitter = false;
     hi.normal = mk3(0.0f, 0.0f, 0.0f);
+    hi.light_pdf = 0.0f;
+    hi.light_emission = mk3(0.0f, 0.0f, 0.0f);
     bool hit = closest_hit(sc, p.ray, p.ps, hi);
-    p.is_emitter = hi.is_emitter;
     if (!hit) {
         p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
-        return true;
+        return false;
     }
     // State::finalize, globals.rs:50-62
-    v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
+    sh.fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
     float ndd = dot3(hi.normal, p.ray.d);
-    v3 ffnormal = (ndd <= 0.0f) ? hi.normal : -hi.normal;
+    const bool front = (ndd <= 0.0f);
+    sh.ffnormal = mk3(front ? hi.normal.x : -hi.normal.x, front ? hi.normal.y : -hi.normal.y, front ? hi.normal.z : -hi.normal.z);
     mat_finalize(hi.mat);
-    float eta = (ndd < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
+    sh.eta = (ndd < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
+    sh.mat = hi.mat;
 
     p.radiance = p.radiance + hi.mat.emission * p.throughput;
-    if (p.is_emitter) {
+    if (hi.is_emitter) {
         // state.depth > 0 always holds (tracer.rs:57,80): the MIS weight is always applied
-        float mis_weight = power_heuristic(p.ps.scatter_pdf, p.ps.light_pdf);
-        p.radiance = p.radiance + (mis_weight * p.ps.light_emission) * p.throughput;
-        return true;
+        float mis_weight = power_heuristic(p.ps.scatter_pdf, hi.light_pdf);
+        p.radiance = p.radiance + (mis_weight * hi.light_emission) * p.throughput;
+        return false;
     }
-    p.radiance = p.radiance + direct_light(sc, p.ray, hi.mat, eta, fhp, ffnormal, p.rng) * p.throughput;
+    return true;
+}
+
+// Second half (tracer.rs:89-101): next-event estimation, BSDF sampling, next ray.
+// Returns true when the path is over (pdf <= 0 or depth exhausted).
+RPT_DEV bool path_shade(const SceneSmall& sc, PathRegs& p, const SurfaceHit& sh)
+{
+    const ShadeFrame fr = make_frame(sh.mat, sh.eta, -p.ray.d, sh.ffnormal);
+    p.radiance = p.radiance + direct_light(sc, sh.mat, sh.eta, fr, sh.fhp, sh.ffnormal, p.rng) * p.throughput;
 
     float pdf;
-    v3 f = disney_sample(hi.mat, eta, -p.ray.d, ffnormal, p.scatter_l, pdf, p.rng);
+    v3 scatter_l = (p.bounce > 0) ? p.ray.d : mk3(0.0f, 0.0f, 0.0f);   // the stale `l` of tracer.rs:531
+    v3 f = disney_sample(sh.mat, sh.eta, fr, sh.ffnormal, scatter_l, pdf, p.rng);
     p.ps.scatter_pdf = pdf;
     if (!(pdf > 0.0f)) return true;
     p.throughput = p.throughput * divs3(f, pdf);
-    p.ray.d = p.scatter_l;
-    p.ray.o = fhp + sc.eps * p.ray.d;
+    p.ray.d = scatter_l;
+    p.ray.o = sh.fhp + sc.eps * p.ray.d;
     p.bounce += 1;
     return p.bounce >= sc.max_depth;
+}
+
+// One whole iteration of tracer.rs:61-103; true when the path is over.
+RPT_DEV bool path_bounce(const SceneSmall& sc, PathRegs& p)
+{
+    SurfaceHit sh;
+    if (!path_trace(sc, p, sh)) return true;
+    return path_shade(sc, p, sh);
 }
 
 // One pixel-sample start to end (the nested-loop form; kept for the A/B kernel).

@@ -88,6 +88,7 @@ struct RenderParams {
     uint64_t frames_done;
     uint64_t seed;
     uint32_t tiles_x;          // ceil(width / 16)
+    uint32_t shade_threshold;  // lanes that must be waiting before a wave runs the shading block
 };
 
 }  // namespace rptdev

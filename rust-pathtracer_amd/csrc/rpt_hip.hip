@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -48,7 +49,7 @@ struct PixelSetup {
     bool valid;
     uint32_t pixel_index;
     float px, py;                     // coord of tracer.rs:46
-    float4* pix;
+    size_t pix_offset;                // index of this pixel's float4 in the tile buffer
 };
 
 RPT_DEV PixelSetup pixel_setup(const RenderParams& rp)
@@ -77,7 +78,7 @@ RPT_DEV PixelSetup pixel_setup(const RenderParams& rp)
     ps.px = xx;
     ps.py = 1.0f - yy;
     ps.pixel_index = grow * rp.width + col;
-    ps.pix = reinterpret_cast<float4*>(rp.pixels) + ((size_t)lrow * rp.width + col);
+    ps.pix_offset = (size_t)lrow * rp.width + col;
     return ps;
 }
 
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSma
 {
     const PixelSetup ps = pixel_setup(rp);
     if (!ps.valid) return;
-    float4 acc = *ps.pix;
+    float4* pix = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
+    float4 acc = *pix;
     for (uint32_t s = 0; s < rp.spp; ++s) {
         const uint64_t frames = rp.frames_done + s;
         const uint32_t fkey = frame_key_hd(rp.seed, frames);
@@ -109,23 +111,30 @@ __global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSma
         const v3 rad = trace_sample(sc, ps.px, ps.py, fkey, ps.pixel_index);
         blend(acc, rad, v);
     }
-    *ps.pix = acc;
+    *pix = acc;
 }
 
-// The production megakernel: same arithmetic, but each lane runs its pixel's sample
-// loop as a state machine (dev_integrator.h, PathRegs) — when a lane's path ends it
-// blends the sample into its running mean and starts the next camera path at once
-// (path regeneration), so every loop iteration has all unfinished lanes doing one
-// closest-hit query.  The per-sample frame key and blend weight 1/(frames+1) are
-// wave-divergent now (lanes drift apart in sample index), so the workgroup computes
-// them once into LDS tables and lanes index them.
+// The production megakernel.  Same arithmetic per sample, different schedule:
+//  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
+//    PathRegs); when its path ends it blends the sample into its running mean and starts
+//    the next camera path at once (path regeneration);
+//  * a bounce is split into TRACE (closest hit + miss/emitter exits, cheap) and SHADE
+//    (next-event estimation + Disney BSDF sampling, ~3x the instructions).  A lane that
+//    hits a surface parks its SurfaceHit in registers and waits; the wave runs SHADE only
+//    when at least `shade_threshold` lanes are parked (wave ballot + popcount), or nobody
+//    is left to trace.  The expensive block therefore executes with most lanes active,
+//    while the cheap one absorbs the divergence.
+// The per-sample frame key and blend weight 1/(frames+1) are per-lane values now (lanes
+// drift apart in sample index), so the workgroup stages them once in LDS tables.
 constexpr uint32_t kMaxSppPerLaunch = 1024;
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd argument of
 // __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
 #ifndef RPT_WAVES_PER_SIMD
-#define RPT_WAVES_PER_SIMD 3
+#define RPT_WAVES_PER_SIMD 4
 #endif
+
+enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u };
 
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_kernel(const SceneSmall sc, const RenderParams rp)
 {
@@ -140,24 +149,48 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_ke
 
     const PixelSetup ps = pixel_setup(rp);
     if (!ps.valid) return;
-    float4 acc = *ps.pix;
+    float4 acc = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
+
+    if (sc.max_depth == 0) {                                        // no bounce loop at all: radiance is zero
+        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), s_weight[s]);
+        *(reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset) = acc;
+        return;
+    }
 
     uint32_t s = 0;
+    uint32_t state = ST_TRACE;
     PathRegs p;
+    SurfaceHit sh;
     path_begin(sc, p, ps.px, ps.py, s_fkey[0], ps.pixel_index);
-    const bool no_bounces = (sc.max_depth == 0);
-    bool ended = no_bounces;
+
     for (;;) {
-        if (!ended) ended = path_bounce(sc, p);
-        if (ended) {
+        bool ended = false;
+        if (state == ST_TRACE) {
+            if (path_trace(sc, p, sh)) state = ST_SHADE;
+            else ended = true;
+        }
+        if (ended) {                                                // sample finished in TRACE: blend, regenerate
             blend(acc, p.radiance, s_weight[s]);
             s += 1;
-            if (s >= rp.spp) break;
-            path_begin(sc, p, ps.px, ps.py, s_fkey[s], ps.pixel_index);
-            ended = no_bounces;
+            if (s >= rp.spp) state = ST_DONE;
+            else path_begin(sc, p, ps.px, ps.py, s_fkey[s], ps.pixel_index);
+        }
+        const uint64_t m_shade = __ballot(state == ST_SHADE);
+        const uint64_t m_trace = __ballot(state == ST_TRACE);
+        if ((m_shade | m_trace) == 0ull) break;
+        if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_trace == 0ull) {
+            if (state == ST_SHADE) {
+                state = ST_TRACE;
+                if (path_shade(sc, p, sh)) {                        // sample finished in SHADE
+                    blend(acc, p.radiance, s_weight[s]);
+                    s += 1;
+                    if (s >= rp.spp) state = ST_DONE;
+                    else path_begin(sc, p, ps.px, ps.py, s_fkey[s], ps.pixel_index);
+                }
+            }
         }
     }
-    *ps.pix = acc;
+    *(reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset) = acc;
 }
 
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
@@ -292,6 +325,18 @@ static DevCamera make_camera(const rpt_camera& c, float width, float height)
     d.psx = 1.0f / width;
     d.psy = 1.0f / height;
     return d;
+}
+
+// Lanes that must be parked on a surface hit before a wave runs its shading block (1..64).
+// RPT_SHADE_THRESHOLD overrides the default for tuning runs.
+static uint32_t shade_threshold()
+{
+    static const uint32_t v = [] {
+        const char* e = getenv("RPT_SHADE_THRESHOLD");
+        long t = e ? strtol(e, nullptr, 10) : 56;
+        return (uint32_t)(t < 1 ? 1 : (t > 64 ? 64 : t));
+    }();
+    return v;
 }
 
 extern "C" {
@@ -493,6 +538,7 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     rp.frames_done = frames_done;
     rp.seed = seed;
     rp.tiles_x = (width + 15u) / 16u;
+    rp.shade_threshold = shade_threshold();
     if (rp.rows_local == 0) return RPT_OK;
     const uint32_t tiles_y = (rp.rows_local + 15u) / 16u;
     const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;
