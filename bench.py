@@ -155,6 +155,13 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "the path is FP32-VALU bound (no dense contraction, 32/S bytes per sample): see roofline_valu"},
         }
+        # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (committed
+        # under profiles/; bench.py cannot collect counters itself)
+        tj = os.path.join(ROOT, "profiles", "r1", "v2_deferred_shading_5waves", "traffic.json")
+        if world == 1 and os.path.exists(tj):
+            t = json.load(open(tj))
+            out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = "profiles/r1/v2_deferred_shading_5waves/traffic.json (%s)" % t["correction"]
         if world == 1 and not args.no_cpu_baseline:
             cpu, ops = cpu_baseline(width, height)
             out["cpu_baseline"] = cpu

@@ -325,14 +325,18 @@ RPT_DEV void path_begin(const SceneSmall& sc, PathRegs& p, float px, float py, u
 // State::finalize, globals.rs:50-62).
 struct SurfaceHit {
     Mat mat;
-    v3 ffnormal, fhp;
+    v3 ffnormal;
+};
+// ... the rest of it (hit point, eta) is parked in LDS by the kernel: one float4 per lane.
+struct SurfaceHitCold {
+    v3 fhp;
     float eta;
 };
 
 // First half of one iteration of the loop at tracer.rs:61-103: closest_hit, the miss
 // and emitter exits (tracer.rs:64-87).  Returns true when a surface was hit and `sh` is
 // filled (shading still to do); false when the path is over and p.radiance is final.
-RPT_DEV bool path_trace(const SceneSmall& sc, PathRegs& p, SurfaceHit& sh)
+RPT_DEV bool path_trace(const SceneSmall& sc, PathRegs& p, SurfaceHit& sh, SurfaceHitCold& shc)
 {
     HitInfo hi;
     hi.is_emitter = false;
@@ -345,12 +349,12 @@ RPT_DEV bool path_trace(const SceneSmall& sc, PathRegs& p, SurfaceHit& sh)
         return false;
     }
     // State::finalize, globals.rs:50-62
-    sh.fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
+    shc.fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
     float ndd = dot3(hi.normal, p.ray.d);
     const bool front = (ndd <= 0.0f);
     sh.ffnormal = mk3(front ? hi.normal.x : -hi.normal.x, front ? hi.normal.y : -hi.normal.y, front ? hi.normal.z : -hi.normal.z);
     mat_finalize(hi.mat);
-    sh.eta = (ndd < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
+    shc.eta = (ndd < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
     sh.mat = hi.mat;
 
     p.radiance = p.radiance + hi.mat.emission * p.throughput;
@@ -365,19 +369,25 @@ RPT_DEV bool path_trace(const SceneSmall& sc, PathRegs& p, SurfaceHit& sh)
 
 // Second half (tracer.rs:89-101): next-event estimation, BSDF sampling, next ray.
 // Returns true when the path is over (pdf <= 0 or depth exhausted).
-RPT_DEV bool path_shade(const SceneSmall& sc, PathRegs& p, const SurfaceHit& sh)
+// `cold` points at the lane's parked {fhp.xyz, eta} (LDS in the production kernel).  The
+// hit point is read twice on purpose — for the shadow-ray origin and, much later, for the
+// next ray's origin — so that it does not occupy registers across the BSDF code.
+RPT_DEV bool path_shade(const SceneSmall& sc, PathRegs& p, const SurfaceHit& sh, const volatile float4* cold)
 {
-    const ShadeFrame fr = make_frame(sh.mat, sh.eta, -p.ray.d, sh.ffnormal);
-    p.radiance = p.radiance + direct_light(sc, sh.mat, sh.eta, fr, sh.fhp, sh.ffnormal, p.rng) * p.throughput;
+    SurfaceHitCold shc;
+    shc.eta = cold->w;
+    shc.fhp = mk3(cold->x, cold->y, cold->z);
+    const ShadeFrame fr = make_frame(sh.mat, shc.eta, -p.ray.d, sh.ffnormal);
+    p.radiance = p.radiance + direct_light(sc, sh.mat, shc.eta, fr, shc.fhp, sh.ffnormal, p.rng) * p.throughput;
 
     float pdf;
     v3 scatter_l = (p.bounce > 0) ? p.ray.d : mk3(0.0f, 0.0f, 0.0f);   // the stale `l` of tracer.rs:531
-    v3 f = disney_sample(sh.mat, sh.eta, fr, sh.ffnormal, scatter_l, pdf, p.rng);
+    v3 f = disney_sample(sh.mat, shc.eta, fr, sh.ffnormal, scatter_l, pdf, p.rng);
     p.ps.scatter_pdf = pdf;
     if (!(pdf > 0.0f)) return true;
     p.throughput = p.throughput * divs3(f, pdf);
     p.ray.d = scatter_l;
-    p.ray.o = sh.fhp + sc.eps * p.ray.d;
+    p.ray.o = mk3(cold->x, cold->y, cold->z) + sc.eps * p.ray.d;
     p.bounce += 1;
     return p.bounce >= sc.max_depth;
 }
@@ -386,8 +396,10 @@ RPT_DEV bool path_shade(const SceneSmall& sc, PathRegs& p, const SurfaceHit& sh)
 RPT_DEV bool path_bounce(const SceneSmall& sc, PathRegs& p)
 {
     SurfaceHit sh;
-    if (!path_trace(sc, p, sh)) return true;
-    return path_shade(sc, p, sh);
+    SurfaceHitCold shc;
+    if (!path_trace(sc, p, sh, shc)) return true;
+    float4 cold = make_float4(shc.fhp.x, shc.fhp.y, shc.fhp.z, shc.eta);
+    return path_shade(sc, p, sh, &cold);
 }
 
 // One pixel-sample start to end (the nested-loop form; kept for the A/B kernel).

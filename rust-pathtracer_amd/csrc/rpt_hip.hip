@@ -126,12 +126,12 @@ __global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSma
 //    while the cheap one absorbs the divergence.
 // The per-sample frame key and blend weight 1/(frames+1) are per-lane values now (lanes
 // drift apart in sample index), so the workgroup stages them once in LDS tables.
-constexpr uint32_t kMaxSppPerLaunch = 1024;
+constexpr uint32_t kMaxSppPerLaunch = 512;
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd argument of
 // __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
 #ifndef RPT_WAVES_PER_SIMD
-#define RPT_WAVES_PER_SIMD 4
+#define RPT_WAVES_PER_SIMD 5
 #endif
 
 enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u };
@@ -147,13 +147,24 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_ke
     }
     __syncthreads();
 
-    const PixelSetup ps = pixel_setup(rp);
-    if (!ps.valid) return;
-    float4 acc = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
+    // Cold per-lane state lives in LDS, not in VGPRs: the pixel's running mean and its
+    // constants are touched only when a sample ends (once per ~2 bounces), and the seven
+    // registers they would pin are what separates 4 from 5 resident waves per SIMD.
+    __shared__ float4 s_acc[256];                                   // running mean, tracer.rs:105-117
+    __shared__ float4 s_pix[256];                                   // {coord.x, coord.y, bits(pixel_index), -}
+    __shared__ float4 s_hit[256];                                   // parked SurfaceHitCold {fhp, eta}
+    const uint32_t tid = threadIdx.x;
+    {
+        const PixelSetup ps = pixel_setup(rp);
+        if (!ps.valid) return;
+        s_acc[tid] = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
+        s_pix[tid] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
+    }
 
     if (sc.max_depth == 0) {                                        // no bounce loop at all: radiance is zero
+        float4 acc = s_acc[tid];
         for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), s_weight[s]);
-        *(reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset) = acc;
+        *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = acc;
         return;
     }
 
@@ -161,19 +172,35 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_ke
     uint32_t state = ST_TRACE;
     PathRegs p;
     SurfaceHit sh;
-    path_begin(sc, p, ps.px, ps.py, s_fkey[0], ps.pixel_index);
+    {
+        const float4 c = s_pix[tid];
+        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+    }
+
+    // blend the finished sample into the running mean and start the next one (or retire)
+    auto finish_sample = [&]() {
+        float4 acc = s_acc[tid];
+        blend(acc, p.radiance, s_weight[s]);
+        s_acc[tid] = acc;
+        s += 1;
+        if (s >= rp.spp) {
+            state = ST_DONE;
+        } else {
+            const float4 c = s_pix[tid];
+            path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+            state = ST_TRACE;
+        }
+    };
 
     for (;;) {
-        bool ended = false;
         if (state == ST_TRACE) {
-            if (path_trace(sc, p, sh)) state = ST_SHADE;
-            else ended = true;
-        }
-        if (ended) {                                                // sample finished in TRACE: blend, regenerate
-            blend(acc, p.radiance, s_weight[s]);
-            s += 1;
-            if (s >= rp.spp) state = ST_DONE;
-            else path_begin(sc, p, ps.px, ps.py, s_fkey[s], ps.pixel_index);
+            SurfaceHitCold shc;
+            if (path_trace(sc, p, sh, shc)) {
+                s_hit[tid] = make_float4(shc.fhp.x, shc.fhp.y, shc.fhp.z, shc.eta);
+                state = ST_SHADE;
+            } else {
+                finish_sample();
+            }
         }
         const uint64_t m_shade = __ballot(state == ST_SHADE);
         const uint64_t m_trace = __ballot(state == ST_TRACE);
@@ -181,16 +208,11 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_ke
         if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_trace == 0ull) {
             if (state == ST_SHADE) {
                 state = ST_TRACE;
-                if (path_shade(sc, p, sh)) {                        // sample finished in SHADE
-                    blend(acc, p.radiance, s_weight[s]);
-                    s += 1;
-                    if (s >= rp.spp) state = ST_DONE;
-                    else path_begin(sc, p, ps.px, ps.py, s_fkey[s], ps.pixel_index);
-                }
+                if (path_shade(sc, p, sh, &s_hit[tid])) finish_sample();
             }
         }
     }
-    *(reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset) = acc;
+    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
 }
 
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
