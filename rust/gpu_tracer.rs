@@ -1,0 +1,114 @@
+//! Reference-side binding for the MI355X render path (source only: this image has no Rust toolchain,
+//! so this file has not been compiled here; it mirrors include/rpt.h one to one).
+//!
+//! Drop this file into `rust-pathtracer/src/`, add `pub mod gpu_tracer;` to `lib.rs`, link with
+//! `-L <repo>/rust-pathtracer_amd -l rpt_hip`, and replace `Tracer::new(scene)` by
+//! `GpuTracer::new(scene)` in `renderer/src/main.rs:42`.  `pt.render(&mut buffer)` (main.rs:118) and
+//! `buffer.convert_to_u8(frame)` (main.rs:122) stay as they are.
+use crate::prelude::*;
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RptMaterial {
+    pub mask: u32, pub proc_kind: u32,
+    pub rgb: [f32; 3], pub emission: [f32; 3],
+    pub anisotropic: f32, pub metallic: f32, pub roughness: f32, pub subsurface: f32, pub specular_tint: f32,
+    pub sheen: f32, pub sheen_tint: f32, pub clearcoat: f32, pub clearcoat_gloss: f32, pub spec_trans: f32, pub ior: f32,
+    pub proc_params: [f32; 4],
+}
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptSphere { pub center: [f32; 3], pub radius: f32, pub material: u32 }
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptPlane { pub normal: [f32; 3], pub point: [f32; 3], pub min_denom: f32, pub material: u32 }
+#[repr(C)] #[derive(Clone, Copy, Default)]
+pub struct RptLight { pub light_type: u32, pub position: [f32; 3], pub emission: [f32; 3], pub u: [f32; 3], pub v: [f32; 3], pub radius: f32, pub area: f32 }
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptCamera { pub origin: [f32; 3], pub center: [f32; 3], pub fov_deg: f32 }
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptBackground { pub kind: u32, pub colour_a: [f32; 3], pub colour_b: [f32; 3], pub gamma: f32, pub scale: f32 }
+#[repr(C)]
+pub struct RptSceneDesc {
+    pub abi_version: u32, pub flags: u32,
+    pub camera: RptCamera, pub background: RptBackground,
+    pub eps: f32, pub max_depth: u32,
+    pub n_spheres: u32, pub spheres: *const RptSphere,
+    pub n_planes: u32, pub planes: *const RptPlane,
+    pub n_lights: u32, pub lights: *const RptLight,
+    pub n_materials: u32, pub materials: *const RptMaterial,
+}
+
+#[repr(C)] pub struct RptCtx { _private: [u8; 0] }
+
+extern "C" {
+    fn rpt_create(out: *mut *mut RptCtx, device_id: c_int) -> c_int;
+    fn rpt_destroy(ctx: *mut RptCtx);
+    fn rpt_last_error(ctx: *const RptCtx) -> *const c_char;
+    fn rpt_upload_scene(ctx: *mut RptCtx, scene: *const RptSceneDesc) -> c_int;
+    fn rpt_scene_analytical(out: *mut RptSceneDesc) -> c_int;
+    fn rpt_render(ctx: *mut RptCtx, pixels: *mut f32, width: u32, height: u32,
+                  frames_done: u64, spp: u32, seed: u64, flags: u32) -> c_int;
+    #[allow(dead_code)]
+    fn rpt_render_device(ctx: *mut RptCtx, pixels_dev: *mut f32, width: u32, height: u32, frames_done: u64, spp: u32,
+                         seed: u64, flags: u32, tile_rows: u32, rank: u32, world: u32, stream: *mut c_void) -> c_int;
+}
+
+/// A scene that can describe itself as data.  `trait Scene` (scene.rs:5-90) is callbacks and cannot
+/// run on the device; scenes that implement only `Scene` keep using the CPU `Tracer`.
+pub trait GpuScene: Scene {
+    /// The backing arrays must outlive the returned descriptor (keep them in `self`).
+    fn describe(&self) -> RptSceneDesc;
+}
+
+/// Same surface as `Tracer` (tracer.rs:5-19, :22, :629).
+pub struct GpuTracer {
+    ctx: *mut RptCtx,
+    scene: Box<dyn GpuScene>,
+    pub seed: u64,
+}
+
+impl GpuTracer {
+    pub fn new(scene: Box<dyn GpuScene>) -> Self {
+        let mut ctx: *mut RptCtx = std::ptr::null_mut();
+        let rc = unsafe { rpt_create(&mut ctx, 0) };
+        assert!(rc == 0, "rpt_create failed: {}", Self::err(std::ptr::null()));
+        let t = Self { ctx, scene, seed: 1 };
+        t.upload();
+        t
+    }
+
+    fn err(ctx: *const RptCtx) -> String {
+        unsafe { std::ffi::CStr::from_ptr(rpt_last_error(ctx)).to_string_lossy().into_owned() }
+    }
+
+    fn upload(&self) {
+        let desc = self.scene.describe();
+        let rc = unsafe { rpt_upload_scene(self.ctx, &desc) };
+        assert!(rc == 0, "rpt_upload_scene failed: {}", Self::err(self.ctx));
+    }
+
+    /// Render one frame and accumulate into the pixels buffer — the contract of tracer.rs:21-123:
+    /// `buffer.pixels` is updated in place, `buffer.frames` is incremented.
+    pub fn render(&mut self, buffer: &mut ColorBuffer) {
+        self.render_n(buffer, 1);
+    }
+
+    /// `spp` consecutive frames in one launch; bit-identical to calling `render` `spp` times.
+    pub fn render_n(&mut self, buffer: &mut ColorBuffer, spp: u32) {
+        let rc = unsafe {
+            rpt_render(self.ctx, buffer.pixels.as_mut_ptr(), buffer.width as u32, buffer.height as u32,
+                       buffer.frames as u64, spp, self.seed, 0)
+        };
+        assert!(rc == 0, "rpt_render failed: {}", Self::err(self.ctx));
+        buffer.frames += spp as usize;                       // tracer.rs:121
+    }
+
+    /// Return a mutable reference to the scene (tracer.rs:629); call `sync_scene` after mutating it.
+    pub fn scene(&mut self) -> &mut Box<dyn GpuScene> { &mut self.scene }
+    pub fn sync_scene(&mut self) { self.upload(); }
+}
+
+impl Drop for GpuTracer {
+    fn drop(&mut self) { unsafe { rpt_destroy(self.ctx) } }
+}
+
+/// `describe()` for renderer/src/analytical.rs: the library already knows this scene.
+pub fn analytical_scene_desc() -> RptSceneDesc {
+    let mut d = std::mem::MaybeUninit::<RptSceneDesc>::zeroed();
+    unsafe { rpt_scene_analytical(d.as_mut_ptr()); d.assume_init() }
+}
