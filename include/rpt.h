@@ -219,6 +219,10 @@ int rpt_untile_device(rpt_ctx* ctx, const float* gathered_dev, float* image_dev,
 int rpt_convert_to_u8_device(rpt_ctx* ctx, const float* pixels_dev, uint8_t* out_dev,
                              uint32_t width, uint32_t height, void* stream);
 
+/* The same on HOST buffers (upload, convert, download; blocks): what ColorBuffer::convert_to_u8
+ * does for a caller that owns a host ColorBuffer (buffer.rs:55-64, frame = width*height*4 bytes). */
+int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_t width, uint32_t height);
+
 int rpt_synchronize(rpt_ctx* ctx, void* stream);
 
 /* ---- test probes ------------------------------------------------------------

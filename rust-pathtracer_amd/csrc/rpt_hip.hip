@@ -634,6 +634,27 @@ int rpt_convert_to_u8_device(rpt_ctx* ctx, const float* pixels_dev, uint8_t* out
     return RPT_OK;
 }
 
+int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_t width, uint32_t height)
+{
+    if (!ctx) { set_err(nullptr, "rpt_convert_to_u8: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!pixels || !frame || width == 0 || height == 0) { set_err(ctx, "rpt_convert_to_u8: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)width * height;
+    const size_t bytes = n * 16 + n * 4;                              // f32 RGBA in, u8 RGBA out, one allocation
+    if (bytes > ctx->fb_bytes) {
+        if (ctx->fb) { RPT_HIP_CHECK(ctx, hipFree(ctx->fb)); ctx->fb = nullptr; ctx->fb_bytes = 0; }
+        RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fb, bytes));
+        ctx->fb_bytes = bytes;
+    }
+    uint8_t* out_dev = reinterpret_cast<uint8_t*>(ctx->fb) + n * 16;
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->fb, pixels, n * 16, hipMemcpyHostToDevice, ctx->stream));
+    int rc = rpt_convert_to_u8_device(ctx, ctx->fb, out_dev, width, height, ctx->stream);
+    if (rc != RPT_OK) return rc;
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(frame, out_dev, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    RPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RPT_OK;
+}
+
 int rpt_synchronize(rpt_ctx* ctx, void* stream)
 {
     if (!ctx) { set_err(nullptr, "rpt_synchronize: ctx is NULL"); return RPT_ERR_INVALID_ARG; }

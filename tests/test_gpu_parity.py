@@ -251,3 +251,27 @@ def test_error_paths(rpt):
     d = big.describe()
     assert lib.rpt_upload_scene(h, C.byref(d)) == rpt._abi.RPT_ERR_UNSUPPORTED
     lib.rpt_destroy(h)
+
+
+def test_cpp_host_mirror_runs_the_reference_main_loop(rpt, oracle, tmp_path):
+    """include/rpt.hpp (C++ mirror of ColorBuffer / AnalyticalScene / Tracer) driven like
+    renderer/src/main.rs:36-42,118-122 — BASELINE.json configs[0]'s 800x600 frame, host buffers,
+    render + convert_to_u8 per frame — must equal the oracle bit for bit."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "render_cpp")
+    if not os.path.exists(exe):
+        subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "render_cpp.cpp"),
+                        "-L", os.path.join(root, "rust-pathtracer_amd"), "-lrpt_hip",
+                        "-Wl,-rpath," + os.path.join(root, "rust-pathtracer_amd"), "-o", exe], check=True)
+    w, h, frames = 800, 600, 2
+    base = str(tmp_path / "out")
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(root, "rust-pathtracer_amd") + ":" + env.get("LD_LIBRARY_PATH", "")
+    subprocess.run([exe, str(w), str(h), str(frames), base], check=True, env=env)
+    got = np.fromfile(base + ".f32", dtype=np.float32).reshape(h, w, 4)
+    want = oracle.render(oracle.scene_analytical(), w, h, frames, seed=1)
+    assert_bit_identical(got, want, "C++ mirror 800x600x2")
+    got8 = np.fromfile(base + ".u8", dtype=np.uint8)
+    assert np.array_equal(got8, oracle.convert_to_u8(want, w, h))
