@@ -190,7 +190,8 @@ RPT_DEV bool any_hit(const SceneSmall& sc, const RayD& ray, float max_dist)
 }
 
 // analytical.rs:28-32 + scene.rs:32-34
-RPT_DEV v3 background(const SceneSmall& sc, const RayD& ray)
+template <class S>
+RPT_DEV v3 background(const S& sc, const RayD& ray)
 {
     const DevBackground& b = sc.bg;
     v3 ca = mk3(b.ax, b.ay, b.az);
@@ -208,7 +209,8 @@ struct LightSample {
 };
 
 // tracer.rs:173-220 (LightType::Spherical; the other types are no-ops there)
-RPT_DEV void sample_light(const SceneSmall& sc, const DevLight& L, v3 scatter_pos, LightSample& ls, Rng& rng)
+template <class S>
+RPT_DEV void sample_light(const S& sc, const DevLight& L, v3 scatter_pos, LightSample& ls, Rng& rng)
 {
     ls.normal = mk3(0.0f, 0.0f, 0.0f); ls.emission = mk3(0.0f, 0.0f, 0.0f); ls.direction = mk3(0.0f, 0.0f, 0.0f);
     ls.dist = 0.0f; ls.pdf = 0.0f;                                  // LightSampleRec::new, globals.rs:119-129
@@ -237,18 +239,10 @@ RPT_DEV void sample_light(const SceneSmall& sc, const DevLight& L, v3 scatter_po
     ls.pdf = dist_sq / (L.area * 0.5f * __builtin_fabsf(dot3(ls.normal, ls.direction)));
 }
 
-// tracer.rs:126-170
-RPT_DEV v3 direct_light(const SceneSmall& sc, const Mat& mat, float eta, const ShadeFrame& fr, v3 fhp, v3 ffnormal, Rng& rng)
+// Scene::light_at (analytical.rs:148-150) for a per-lane index: a select chain over the
+// (wave-uniform, SGPR-resident) table of a small scene.
+RPT_DEV DevLight light_at(const SceneSmall& sc, uint32_t index)
 {
-    v3 ld = mk3(0.0f, 0.0f, 0.0f);
-    if (sc.n_lights == 0) return ld;
-    v3 scatter_pos = fhp + sc.eps * ffnormal;
-    float random = rng.gen();
-    random = random * sc.n_lights_f;
-    uint32_t index = (uint32_t)random;                              // `as usize`
-    index = (index >= sc.n_lights) ? sc.n_lights - 1u : index;      // the reference would panic; unreachable for n < 2^24
-
-    // light table entry for a per-lane index: select over the (uniform) table
     DevLight L = sc.lights[0];
     for (uint32_t i = 1; i < sc.n_lights; ++i) {
         const DevLight& Li = sc.lights[i];
@@ -258,6 +252,22 @@ RPT_DEV v3 direct_light(const SceneSmall& sc, const Mat& mat, float eta, const S
         L.ex = pick ? Li.ex : L.ex; L.ey = pick ? Li.ey : L.ey; L.ez = pick ? Li.ez : L.ez;
         L.radius = pick ? Li.radius : L.radius; L.area = pick ? Li.area : L.area;
     }
+    return L;
+}
+
+// tracer.rs:126-170
+template <class S>
+RPT_DEV v3 direct_light(const S& sc, const Mat& mat, float eta, const ShadeFrame& fr, v3 fhp, v3 ffnormal, Rng& rng)
+{
+    v3 ld = mk3(0.0f, 0.0f, 0.0f);
+    if (sc.n_lights == 0) return ld;
+    v3 scatter_pos = fhp + sc.eps * ffnormal;
+    float random = rng.gen();
+    random = random * sc.n_lights_f;
+    uint32_t index = (uint32_t)random;                              // `as usize`
+    index = (index >= sc.n_lights) ? sc.n_lights - 1u : index;      // the reference would panic; unreachable for n < 2^24
+
+    const DevLight L = light_at(sc, index);                         // Scene::light_at for a per-lane index
 
     LightSample ls;
     sample_light(sc, L, scatter_pos, ls, rng);
@@ -308,7 +318,8 @@ struct PathRegs {
 };
 
 // tracer.rs:44-57
-RPT_DEV void path_begin(const SceneSmall& sc, PathRegs& p, float px, float py, uint32_t fkey, uint32_t pixel_index)
+template <class S>
+RPT_DEV void path_begin(const S& sc, PathRegs& p, float px, float py, uint32_t fkey, uint32_t pixel_index)
 {
     p.rng.init(fkey, pixel_index);
     float offx = p.rng.gen();
@@ -336,7 +347,8 @@ struct SurfaceHitCold {
 // First half of one iteration of the loop at tracer.rs:61-103: closest_hit, the miss
 // and emitter exits (tracer.rs:64-87).  Returns true when a surface was hit and `sh` is
 // filled (shading still to do); false when the path is over and p.radiance is final.
-RPT_DEV bool path_trace(const SceneSmall& sc, PathRegs& p, SurfaceHit& sh, SurfaceHitCold& shc)
+template <class S>
+RPT_DEV bool path_trace(const S& sc, PathRegs& p, SurfaceHit& sh, SurfaceHitCold& shc)
 {
     HitInfo hi;
     hi.is_emitter = false;
@@ -372,7 +384,8 @@ RPT_DEV bool path_trace(const SceneSmall& sc, PathRegs& p, SurfaceHit& sh, Surfa
 // `cold` points at the lane's parked {fhp.xyz, eta} (LDS in the production kernel).  The
 // hit point is read twice on purpose — for the shadow-ray origin and, much later, for the
 // next ray's origin — so that it does not occupy registers across the BSDF code.
-RPT_DEV bool path_shade(const SceneSmall& sc, PathRegs& p, const SurfaceHit& sh, const volatile float4* cold)
+template <class S>
+RPT_DEV bool path_shade(const S& sc, PathRegs& p, const SurfaceHit& sh, const volatile float4* cold)
 {
     SurfaceHitCold shc;
     shc.eta = cold->w;
@@ -393,7 +406,8 @@ RPT_DEV bool path_shade(const SceneSmall& sc, PathRegs& p, const SurfaceHit& sh,
 }
 
 // One whole iteration of tracer.rs:61-103; true when the path is over.
-RPT_DEV bool path_bounce(const SceneSmall& sc, PathRegs& p)
+template <class S>
+RPT_DEV bool path_bounce(const S& sc, PathRegs& p)
 {
     SurfaceHit sh;
     SurfaceHitCold shc;
@@ -403,7 +417,8 @@ RPT_DEV bool path_bounce(const SceneSmall& sc, PathRegs& p)
 }
 
 // One pixel-sample start to end (the nested-loop form; kept for the A/B kernel).
-RPT_DEV v3 trace_sample(const SceneSmall& sc, float px, float py, uint32_t fkey, uint32_t pixel_index)
+template <class S>
+RPT_DEV v3 trace_sample(const S& sc, float px, float py, uint32_t fkey, uint32_t pixel_index)
 {
     PathRegs p;
     path_begin(sc, p, px, py, fkey, pixel_index);

@@ -15,6 +15,7 @@
 
 #include "../../include/rpt.h"
 #include "dev_integrator.h"
+#include "dev_scene_large.h"
 
 using namespace rptdev;
 
@@ -98,7 +99,8 @@ RPT_DEV void blend(float4& acc, v3 rad, float v)
 // samples and updated with the reference's own expression once per sample, so one
 // launch of S samples is bit-identical to S reference render() calls; the framebuffer
 // is read and written once per launch as float4 (16 B per lane, 128 B per 8-pixel row).
-__global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSmall sc, const RenderParams rp)
+template <class S>
+RPT_DEV void render_nested_body(const S& sc, const RenderParams& rp)
 {
     const PixelSetup ps = pixel_setup(rp);
     if (!ps.valid) return;
@@ -113,6 +115,9 @@ __global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSma
     }
     *pix = acc;
 }
+
+__global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSmall sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void render_large_nested_kernel(const SceneLarge sc, const RenderParams rp) { render_nested_body(sc, rp); }
 
 // The production megakernel.  Same arithmetic per sample, different schedule:
 //  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
@@ -136,7 +141,8 @@ constexpr uint32_t kMaxSppPerLaunch = 512;
 
 enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u };
 
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_kernel(const SceneSmall sc, const RenderParams rp)
+template <class S>
+RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
 {
     __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
@@ -215,6 +221,10 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_ke
     *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
 }
 
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_kernel(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
+// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_large_regen_kernel(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
+
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
 __global__ __launch_bounds__(256) void untile_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
                                                      uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
@@ -284,7 +294,10 @@ struct rpt_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     bool has_scene = false;
+    bool large = false;               // scene exceeds the kernarg tables: SceneLarge + device tables
     SceneSmall scene;                 // camera part is filled per launch (depends on width/height)
+    SceneLarge scene_large;
+    void* tables = nullptr;           // one device allocation holding the large scene's tables
     rpt_camera camera;
     float* fb = nullptr;              // device framebuffer for the host-pointer API
     size_t fb_bytes = 0;
@@ -459,6 +472,7 @@ void rpt_destroy(rpt_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->fb) (void)hipFree(ctx->fb);
+    if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -471,16 +485,77 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         set_err(ctx, "rpt_upload_scene: a table pointer is NULL");
         return RPT_ERR_INVALID_ARG;
     }
-    if (s->n_spheres > (uint32_t)kMaxSpheres || s->n_planes > (uint32_t)kMaxPlanes || s->n_lights > (uint32_t)kMaxLights ||
-        s->n_materials > (uint32_t)kMaxMaterials) {
-        set_err(ctx, "rpt_upload_scene: scene exceeds the small-scene limits (%d spheres, %d planes, %d lights, %d materials)",
-                kMaxSpheres, kMaxPlanes, kMaxLights, kMaxMaterials);
+    const bool large = s->n_spheres > (uint32_t)kMaxSpheres || s->n_lights > (uint32_t)kMaxLights || s->n_materials > (uint32_t)kMaxMaterials;
+    if (s->n_planes > (uint32_t)kMaxPlanes) {
+        set_err(ctx, "rpt_upload_scene: at most %d planes are supported", kMaxPlanes);
         return RPT_ERR_UNSUPPORTED;
     }
     for (uint32_t i = 0; i < s->n_spheres; ++i)
         if (s->spheres[i].material >= s->n_materials) { set_err(ctx, "rpt_upload_scene: sphere %u material out of range", i); return RPT_ERR_INVALID_ARG; }
     for (uint32_t i = 0; i < s->n_planes; ++i)
         if (s->planes[i].material >= s->n_materials) { set_err(ctx, "rpt_upload_scene: plane %u material out of range", i); return RPT_ERR_INVALID_ARG; }
+
+    auto dev_plane = [](const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material}; };
+    auto dev_light = [](const rpt_light& a) { return DevLight{a.type, a.position[0], a.position[1], a.position[2], a.emission[0], a.emission[1], a.emission[2], a.radius, a.area}; };
+    auto dev_material = [](const rpt_material& a) {
+        DevMaterial m;
+        m.mask = a.mask; m.proc_kind = a.proc_kind;
+        for (int k = 0; k < 3; ++k) { m.rgb[k] = a.rgb[k]; m.emission[k] = a.emission[k]; }
+        m.anisotropic = a.anisotropic; m.metallic = a.metallic; m.roughness = a.roughness; m.subsurface = a.subsurface;
+        m.specular_tint = a.specular_tint; m.sheen = a.sheen; m.sheen_tint = a.sheen_tint; m.clearcoat = a.clearcoat;
+        m.clearcoat_gloss = a.clearcoat_gloss; m.spec_trans = a.spec_trans; m.ior = a.ior;
+        for (int k = 0; k < 4; ++k) m.proc_params[k] = a.proc_params[k];
+        return m;
+    };
+    auto dev_background = [](const rpt_background& b) {
+        return DevBackground{b.kind, b.colour_a[0], b.colour_a[1], b.colour_a[2], b.colour_b[0], b.colour_b[1], b.colour_b[2], b.gamma, b.scale};
+    };
+
+    if (large) {
+        // Layered patches need a bit per primitive; large scenes must use full sphere materials.
+        for (uint32_t i = 0; i < s->n_spheres; ++i) {
+            const rpt_material& m = s->materials[s->spheres[i].material];
+            if ((m.mask & RPT_MAT_ALL) != RPT_MAT_ALL || m.proc_kind != RPT_PROC_NONE) {
+                set_err(ctx, "rpt_upload_scene: scenes beyond %d spheres / %d lights / %d materials need full sphere materials "
+                             "(mask == RPT_MAT_ALL, no procedural part); sphere %u does not", kMaxSpheres, kMaxLights, kMaxMaterials, i);
+                return RPT_ERR_UNSUPPORTED;
+            }
+        }
+        RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        const size_t sz_sph = sizeof(float4) * s->n_spheres;
+        const size_t sz_smat = (sizeof(uint32_t) * s->n_spheres + 15) & ~(size_t)15;
+        const size_t sz_lights = (sizeof(DevLight) * (s->n_lights ? s->n_lights : 1) + 15) & ~(size_t)15;
+        const size_t sz_mats = sizeof(DevMaterial) * (s->n_materials ? s->n_materials : 1);
+        std::vector<unsigned char> host(sz_sph + sz_smat + sz_lights + sz_mats, 0);
+        float4* h_sph = reinterpret_cast<float4*>(host.data());
+        uint32_t* h_smat = reinterpret_cast<uint32_t*>(host.data() + sz_sph);
+        DevLight* h_lights = reinterpret_cast<DevLight*>(host.data() + sz_sph + sz_smat);
+        DevMaterial* h_mats = reinterpret_cast<DevMaterial*>(host.data() + sz_sph + sz_smat + sz_lights);
+        for (uint32_t i = 0; i < s->n_spheres; ++i) {
+            h_sph[i] = make_float4(s->spheres[i].center[0], s->spheres[i].center[1], s->spheres[i].center[2], s->spheres[i].radius);
+            h_smat[i] = s->spheres[i].material;
+        }
+        for (uint32_t i = 0; i < s->n_lights; ++i) h_lights[i] = dev_light(s->lights[i]);
+        for (uint32_t i = 0; i < s->n_materials; ++i) h_mats[i] = dev_material(s->materials[i]);
+        if (ctx->tables) { RPT_HIP_CHECK(ctx, hipFree(ctx->tables)); ctx->tables = nullptr; }
+        RPT_HIP_CHECK(ctx, hipMalloc(&ctx->tables, host.size()));
+        RPT_HIP_CHECK(ctx, hipMemcpy(ctx->tables, host.data(), host.size(), hipMemcpyHostToDevice));
+        unsigned char* base = reinterpret_cast<unsigned char*>(ctx->tables);
+        SceneLarge& L = ctx->scene_large;
+        memset(&L, 0, sizeof(L));
+        L.n_spheres = s->n_spheres; L.n_planes = s->n_planes; L.n_lights = s->n_lights; L.n_materials = s->n_materials;
+        L.flags = s->flags; L.max_depth = s->max_depth; L.eps = s->eps; L.n_lights_f = (float)s->n_lights;
+        L.bg = dev_background(s->background);
+        L.spheres = reinterpret_cast<const float4*>(base);
+        L.sphere_material = reinterpret_cast<const uint32_t*>(base + sz_sph);
+        L.lights = reinterpret_cast<const DevLight*>(base + sz_sph + sz_smat);
+        L.materials = reinterpret_cast<const DevMaterial*>(base + sz_sph + sz_smat + sz_lights);
+        for (uint32_t i = 0; i < s->n_planes; ++i) L.planes[i] = dev_plane(s->planes[i]);
+        ctx->camera = s->camera;
+        ctx->large = true;
+        ctx->has_scene = true;
+        return RPT_OK;
+    }
 
     SceneSmall& d = ctx->scene;
     memset(&d, 0, sizeof(d));
@@ -517,6 +592,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         for (int k = 0; k < 4; ++k) m.proc_params[k] = a.proc_params[k];
     }
     ctx->camera = s->camera;
+    ctx->large = false;
     ctx->has_scene = true;
     return RPT_OK;
 }
@@ -549,7 +625,8 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
 
     RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     SceneSmall sc = ctx->scene;
-    sc.cam = make_camera(ctx->camera, (float)width, (float)height);
+    SceneLarge scl = ctx->scene_large;
+    sc.cam = scl.cam = make_camera(ctx->camera, (float)width, (float)height);
 
     RenderParams rp;
     rp.pixels = pixels_dev;
@@ -573,10 +650,11 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
         const uint32_t chunk = (spp - done > kMaxSppPerLaunch) ? kMaxSppPerLaunch : (spp - done);
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
-        if (flags & RPT_RENDER_NESTED_LOOPS)
-            hipLaunchKernelGGL(render_small_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
-        else
-            hipLaunchKernelGGL(render_small_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
+        const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
+        if (ctx->large && nested) hipLaunchKernelGGL(render_large_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scl, rp);
+        else if (ctx->large) hipLaunchKernelGGL(render_large_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scl, rp);
+        else if (nested) hipLaunchKernelGGL(render_small_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
+        else hipLaunchKernelGGL(render_small_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
         RPT_HIP_CHECK(ctx, hipGetLastError());
         done += chunk;
     }

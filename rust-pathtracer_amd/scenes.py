@@ -1,0 +1,67 @@
+"""Project-defined benchmark scenes (BASELINE.json configs 4-5; the reference has only AnalyticalScene).
+
+Everything is generated from the project's PCG hash so the scenes are reproducible in any
+language: u(i) = (pcg(seed + i) >> 8) * 2^-24."""
+from . import _abi
+from .api import AnalyticalLight, Material, Pinhole, Scene
+
+_DEFAULTS = dict(rgb=(1.5, 1.5, 1.5), emission=(0.0, 0.0, 0.0), anisotropic=0.0, metallic=0.0, roughness=0.5,
+                 subsurface=0.0, specular_tint=0.0, sheen=0.0, sheen_tint=0.0, clearcoat=0.0, clearcoat_gloss=0.0,
+                 spec_trans=0.0, ior=1.45)                      # Material::new, material.rs:82-114
+
+
+def full_material(**fields):
+    """A patch that sets every field (mask == RPT_MAT_ALL): what large scenes require for spheres."""
+    d = dict(_DEFAULTS)
+    d.update(fields)
+    return Material(**d)
+
+
+def pcg_hash(v):
+    state = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return ((word >> 22) ^ word) & 0xFFFFFFFF
+
+
+class _U:
+    def __init__(self, seed):
+        self.seed, self.i = seed & 0xFFFFFFFF, 0
+
+    def __call__(self, lo=0.0, hi=1.0):
+        u = (pcg_hash((self.seed + self.i) & 0xFFFFFFFF) >> 8) * 2.0 ** -24
+        self.i += 1
+        return lo + (hi - lo) * u
+
+
+def random_spheres_scene(n_spheres=10000, n_lights=16, seed=0x5EED0005, n_palette=64):
+    """spheres uniform in [-60,60]x[0,12]x[-120,0], radii U[0.3,1.2], a
+    palette of full materials (rgb U[.05,1]^3, roughness U[.02,1], metallic 1 with p=.3, clearcoat 1
+    with p=.2), a checker plane y=-1, spherical lights (r=1, emission 5) on a grid at y=15."""
+    u = _U(seed)
+    s = Scene()
+    s.camera = Pinhole((0.0, 6.0, 14.0), (0.0, 2.0, -40.0), 70.0)
+    s.background = dict(kind=_abi.RPT_BG_GRADIENT_Y, colour_a=(1.0, 1.0, 1.0), colour_b=(0.5, 0.7, 1.0), gamma=2.2, scale=0.5)
+    s.any_hit_uses_max_dist = True
+    s.materials = []
+    for _ in range(n_palette):
+        rgb = (u(0.05, 1.0), u(0.05, 1.0), u(0.05, 1.0))
+        rough = u(0.02, 1.0)
+        metallic = 1.0 if u() < 0.3 else 0.0
+        coat = 1.0 if u() < 0.2 else 0.0
+        s.materials.append(full_material(rgb=rgb, roughness=rough, metallic=metallic, clearcoat=coat, clearcoat_gloss=coat))
+    s.materials.append(Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1)))     # the reference's floor
+    floor = len(s.materials) - 1
+    s.spheres = []
+    for _ in range(n_spheres):
+        c = (u(-60.0, 60.0), u(0.0, 12.0), u(-120.0, 0.0))
+        r = u(0.3, 1.2)
+        s.spheres.append((c, r, int(u() * n_palette) % n_palette))
+    s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, floor)]
+    side = max(1, int(round(n_lights ** 0.5)))
+    s.lights = []
+    for i in range(n_lights):
+        gx, gz = i % side, i // side
+        x = -45.0 + 90.0 * (gx + 0.5) / side
+        z = -105.0 + 90.0 * (gz + 0.5) / side
+        s.lights.append(AnalyticalLight.spherical((x, 15.0, z), 1.0, (5.0, 5.0, 5.0)))
+    return s

@@ -245,10 +245,10 @@ def test_error_paths(rpt):
     px = np.zeros(16, dtype=np.float32)
     assert lib.rpt_render(h, px.ctypes.data, 2, 2, 0, 1, 1, 0) == rpt._abi.RPT_ERR_NO_SCENE
     assert b"no scene" in lib.rpt_last_error(h)
-    big = rpt.Scene()
-    big.materials = [rpt.Material(rgb=(1, 1, 1))]
-    big.spheres = [((float(i), 0.0, 0.0), 0.4, 0) for i in range(9)]
-    d = big.describe()
+    too_many_planes = rpt.Scene()
+    too_many_planes.materials = [rpt.Material(rgb=(1, 1, 1))]
+    too_many_planes.planes = [((0.0, 1.0, 0.0), (0.0, -float(i), 0.0), 1e-4, 0) for i in range(5)]
+    d = too_many_planes.describe()
     assert lib.rpt_upload_scene(h, C.byref(d)) == rpt._abi.RPT_ERR_UNSUPPORTED
     lib.rpt_destroy(h)
 
@@ -275,3 +275,32 @@ def test_cpp_host_mirror_runs_the_reference_main_loop(rpt, oracle, tmp_path):
     assert_bit_identical(got, want, "C++ mirror 800x600x2")
     got8 = np.fromfile(base + ".u8", dtype=np.uint8)
     assert np.array_equal(got8, oracle.convert_to_u8(want, w, h))
+
+
+@pytest.mark.parametrize("n_spheres,n_lights", [(300, 16), (9, 2), (40, 5)])
+def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
+    """BASELINE.json configs[4]'s shape at a size the oracle finishes in seconds: random spheres with
+    full materials, a checker plane, a grid of spherical lights; the kernel streams the tables from HBM."""
+    from rust_pathtracer_amd import scenes
+    s = scenes.random_spheres_scene(n_spheres=n_spheres, n_lights=n_lights, seed=0x5EED0005)
+    w, h, spp = 96, 54, 3
+    t = rpt.Tracer(s, device=0, seed=5)
+    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+        t.flags = flags
+        buf = rpt.ColorBuffer(w, h)
+        t.render_n(buf, spp)
+        want = oracle.render(s.describe(), w, h, spp, seed=5)
+        assert_bit_identical(buf.image(), want, "large scene %d spheres flags=%d" % (n_spheres, flags))
+    t.close()
+
+
+def test_large_scene_needs_full_sphere_materials(rpt):
+    s = rpt.Scene()
+    s.materials = [rpt.Material(rgb=(1, 1, 1))]                    # a partial patch
+    s.spheres = [((float(i), 0.0, 0.0), 0.4, 0) for i in range(9)]
+    h = C.c_void_p()
+    assert rpt.lib().rpt_create(C.byref(h), 0) == 0
+    d = s.describe()
+    assert rpt.lib().rpt_upload_scene(h, C.byref(d)) == rpt._abi.RPT_ERR_UNSUPPORTED
+    assert b"full sphere materials" in rpt.lib().rpt_last_error(h)
+    rpt.lib().rpt_destroy(h)
