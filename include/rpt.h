@@ -137,6 +137,32 @@ typedef struct rpt_background {
     float    scale;
 } rpt_background;
 
+/* ---- procedural SDF object (BASELINE.json configs[3]; the reference has no SDF scene, Readme.md:18) ----
+ * One implicit surface per scene: the polynomial smooth union of a list of primitives,
+ *     d = fold(smin_k) over prims,   smin_k(a,b) = min(a,b) - h*h*k*0.25,  h = max(k - |a-b|, 0) / k
+ * found by sphere marching from t = 0:  p = o + t*d;  hit when sdf(p) < hit_eps * t;  t += sdf(p);
+ * miss after max_steps steps or when t > max_t.  Normal = normalised tetrahedral gradient with step
+ * normal_eps.  The object is tested AFTER the spheres and planes (accepted when nearer) and counts as
+ * an occluder in any_hit.  All arithmetic is f32 in the order written in oracle/rpt_oracle.hpp. */
+enum { RPT_SDF_SPHERE = 0, RPT_SDF_TORUS_Y = 1 };
+
+typedef struct rpt_sdf_prim {
+    uint32_t kind;
+    float    center[3];
+    float    params[2];               /* sphere: {radius, -}; torus around the y axis: {major R, minor r} */
+} rpt_sdf_prim;
+
+typedef struct rpt_sdf {
+    uint32_t n_prims;                 /* 0 = no SDF object; at most 8 */
+    uint32_t max_steps;
+    uint32_t material;
+    float    smooth_k;
+    float    hit_eps;
+    float    max_t;
+    float    normal_eps;
+    const rpt_sdf_prim* prims;
+} rpt_sdf;
+
 enum {                                /* rpt_scene_desc.flags */
     /* Scene::any_hit honours max_dist.  OFF reproduces analytical.rs:130, which
      * ignores it (anything along the shadow ray occludes). */
@@ -154,6 +180,7 @@ typedef struct rpt_scene_desc {
     uint32_t n_planes;    const rpt_plane*    planes;     /* then planes, in order  */
     uint32_t n_lights;    const rpt_light*    lights;     /* then Scene::sample_lights */
     uint32_t n_materials; const rpt_material* materials;
+    rpt_sdf  sdf;                     /* then the SDF object, if any */
 } rpt_scene_desc;
 
 /* Fill `out` with renderer/src/analytical.rs's AnalyticalScene (2 spheres, plane,

@@ -317,6 +317,7 @@ struct Scene {
     std::vector<rpt_plane> planes;
     std::vector<rpt_light> lights;
     std::vector<rpt_material> materials;
+    std::vector<rpt_sdf_prim> sdf_prims;
     Pinhole pinhole;
 
     explicit Scene(const rpt_scene_desc& desc) : d(desc)
@@ -325,6 +326,7 @@ struct Scene {
         planes.assign(desc.planes, desc.planes + desc.n_planes);
         lights.assign(desc.lights, desc.lights + desc.n_lights);
         materials.assign(desc.materials, desc.materials + desc.n_materials);
+        if (desc.sdf.n_prims) sdf_prims.assign(desc.sdf.prims, desc.sdf.prims + desc.sdf.n_prims);
         pinhole.origin = F3(desc.camera.origin[0], desc.camera.origin[1], desc.camera.origin[2]);
         pinhole.center = F3(desc.camera.center[0], desc.camera.center[1], desc.camera.center[2]);
         pinhole.fov = desc.camera.fov_deg;
@@ -376,6 +378,47 @@ struct Scene {
             F c = (f_rem(x1 + y1, 2.0f) < F(1.0f)) ? F(m.proc_params[2]) : F(m.proc_params[3]);
             out.rgb = F3(c, c, c);
         }
+    }
+
+    // ---- procedural SDF object (project-defined: include/rpt.h, rpt_sdf; no reference counterpart) ----
+    F sdf_prim(const rpt_sdf_prim& pr, const F3& p) const
+    {
+        F3 q = p - F3(pr.center[0], pr.center[1], pr.center[2]);
+        if (pr.kind == RPT_SDF_TORUS_Y) {
+            F qx = f_sqrt(q.x * q.x + q.z * q.z) - F(pr.params[0]);
+            return f_sqrt(qx * qx + q.y * q.y) - F(pr.params[1]);
+        }
+        return q.length() - F(pr.params[0]);
+    }
+    F sdf_eval(const F3& p) const
+    {
+        F k(d.sdf.smooth_k);
+        F dd = sdf_prim(sdf_prims[0], p);
+        for (size_t i = 1; i < sdf_prims.size(); ++i) {
+            F b = sdf_prim(sdf_prims[i], p);
+            F h = f_max(k - f_abs(dd - b), 0.0f) / k;
+            F m = (dd < b) ? dd : b;
+            dd = m - h * h * k * F(0.25f);
+        }
+        return dd;
+    }
+    bool sdf_march(const Ray& ray, F& t_out) const
+    {
+        F t(0.0f);
+        for (uint32_t step = 0; step < d.sdf.max_steps; ++step) {
+            F dist = sdf_eval(ray.at(t));
+            if (dist < F(d.sdf.hit_eps) * t) { t_out = t; return true; }
+            t = t + dist;
+            if (t > F(d.sdf.max_t)) break;
+        }
+        return false;
+    }
+    F3 sdf_normal(const F3& p) const
+    {
+        F e(d.sdf.normal_eps);
+        F3 k0(1.0f, -1.0f, -1.0f), k1(-1.0f, -1.0f, 1.0f), k2(-1.0f, 1.0f, -1.0f), k3(1.0f, 1.0f, 1.0f);
+        F3 n = sdf_eval(p + e * k0) * k0 + sdf_eval(p + e * k1) * k1 + sdf_eval(p + e * k2) * k2 + sdf_eval(p + e * k3) * k3;
+        return n.normalize();
     }
 
     // scene.rs:36-86 (default method Scene::sample_lights)
@@ -439,6 +482,19 @@ struct Scene {
             }
             first = false;
         }
+        if (!sdf_prims.empty()) {                                                  // the SDF object, tested last
+            F dd;
+            if (sdf_march(ray, dd)) {
+                if (first || dd < dist) {
+                    state.hit_dist = dd;
+                    state.normal = sdf_normal(ray.at(dd));
+                    apply_material(materials[d.sdf.material], ray, state.material);
+                    hit = true;
+                    dist = dd;
+                }
+            }
+            first = false;
+        }
         if (sample_lights(ray, state, light_sample)) hit = true;                   // analytical.rs:122-124
         return hit;
     }
@@ -455,6 +511,11 @@ struct Scene {
         for (const rpt_plane& p : planes) {
             F dd;
             if (plane(ray, p, dd))
+                if (!use_max || dd < max_dist) return true;
+        }
+        if (!sdf_prims.empty()) {
+            F dd;
+            if (sdf_march(ray, dd))
                 if (!use_max || dd < max_dist) return true;
         }
         return false;

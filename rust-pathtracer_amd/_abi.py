@@ -79,6 +79,19 @@ class rpt_background(C.Structure):
     _fields_ = [("kind", C.c_uint32), ("colour_a", F3), ("colour_b", F3), ("gamma", C.c_float), ("scale", C.c_float)]
 
 
+RPT_SDF_SPHERE = 0
+RPT_SDF_TORUS_Y = 1
+
+
+class rpt_sdf_prim(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("center", F3), ("params", C.c_float * 2)]
+
+
+class rpt_sdf(C.Structure):
+    _fields_ = [("n_prims", C.c_uint32), ("max_steps", C.c_uint32), ("material", C.c_uint32), ("smooth_k", C.c_float),
+                ("hit_eps", C.c_float), ("max_t", C.c_float), ("normal_eps", C.c_float), ("prims", C.POINTER(rpt_sdf_prim))]
+
+
 class rpt_scene_desc(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32), ("flags", C.c_uint32),
@@ -88,6 +101,7 @@ class rpt_scene_desc(C.Structure):
         ("n_planes", C.c_uint32), ("planes", C.POINTER(rpt_plane)),
         ("n_lights", C.c_uint32), ("lights", C.POINTER(rpt_light)),
         ("n_materials", C.c_uint32), ("materials", C.POINTER(rpt_material)),
+        ("sdf", rpt_sdf),
     ]
 
 

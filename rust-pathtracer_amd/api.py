@@ -102,6 +102,7 @@ class Scene:
         self.eps = 0.005         # tracer.rs:16
         self.max_depth = 4       # scene.rs:28-30
         self.any_hit_uses_max_dist = False
+        self.sdf = None          # dict(prims=[(kind, center, (p0, p1))], material, smooth_k, max_steps, hit_eps, max_t, normal_eps)
         self._keep = None
 
     def recursion_depth(self):
@@ -146,7 +147,16 @@ class Scene:
         d.n_planes = len(self.planes); d.planes = C.cast(pl, C.POINTER(_abi.rpt_plane))
         d.n_lights = len(self.lights); d.lights = C.cast(li, C.POINTER(_abi.rpt_light))
         d.n_materials = len(self.materials); d.materials = C.cast(ma, C.POINTER(_abi.rpt_material))
-        self._keep = (sph, pl, li, ma)
+        sd = None
+        if self.sdf:
+            sd = (_abi.rpt_sdf_prim * len(self.sdf["prims"]))()
+            for i, (kind, c, prm) in enumerate(self.sdf["prims"]):
+                sd[i].kind = kind; sd[i].center = _abi.F3(*c); sd[i].params = (C.c_float * 2)(*prm)
+            d.sdf.n_prims = len(self.sdf["prims"]); d.sdf.prims = C.cast(sd, C.POINTER(_abi.rpt_sdf_prim))
+            d.sdf.material = self.sdf["material"]; d.sdf.smooth_k = self.sdf.get("smooth_k", 0.5)
+            d.sdf.max_steps = self.sdf.get("max_steps", 128); d.sdf.hit_eps = self.sdf.get("hit_eps", 1e-3)
+            d.sdf.max_t = self.sdf.get("max_t", 100.0); d.sdf.normal_eps = self.sdf.get("normal_eps", 1e-3)
+        self._keep = (sph, pl, li, ma, sd)
         return d
 
 

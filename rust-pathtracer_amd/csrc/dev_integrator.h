@@ -73,6 +73,53 @@ RPT_DEV void apply_patch(Mat& m, const DevMaterial& p, bool on, v3 dir)
     }
 }
 
+// ---- procedural SDF object (include/rpt.h rpt_sdf; restated in oracle/rpt_oracle.hpp) ----
+RPT_DEV float sdf_prim(const DevSdfPrim& pr, v3 p)
+{
+    v3 q = p - mk3(pr.cx, pr.cy, pr.cz);
+    if (pr.kind == RPT_SDF_TORUS_Y) {
+        float qx = __builtin_sqrtf(q.x * q.x + q.z * q.z) - pr.p0;
+        return __builtin_sqrtf(qx * qx + q.y * q.y) - pr.p1;
+    }
+    return len3(q) - pr.p0;
+}
+
+RPT_DEV float sdf_eval(const DevSdf& sd, v3 p)
+{
+    const float k = sd.smooth_k;
+    float dd = sdf_prim(sd.prims[0], p);
+    for (uint32_t i = 1; i < sd.n_prims; ++i) {
+        float b = sdf_prim(sd.prims[i], p);
+        float h = rmax(k - __builtin_fabsf(dd - b), 0.0f) / k;
+        float m = (dd < b) ? dd : b;
+        dd = m - h * h * k * 0.25f;
+    }
+    return dd;
+}
+
+// Sphere marching.  Lanes leave the loop at different step counts; the loop runs until
+// the wave's last lane is done (no cross-lane compaction inside a bounce: the parked-lane
+// vote of the kernel works at bounce granularity).
+RPT_DEV bool sdf_march(const DevSdf& sd, const RayD& ray, float& t_out)
+{
+    float t = 0.0f;
+    for (uint32_t step = 0; step < sd.max_steps; ++step) {
+        float dist = sdf_eval(sd, ray.o + t * ray.d);
+        if (dist < sd.hit_eps * t) { t_out = t; return true; }
+        t = t + dist;
+        if (t > sd.max_t) break;
+    }
+    return false;
+}
+
+RPT_DEV v3 sdf_normal(const DevSdf& sd, v3 p)
+{
+    const float e = sd.normal_eps;
+    const v3 k0 = mk3(1.0f, -1.0f, -1.0f), k1 = mk3(-1.0f, -1.0f, 1.0f), k2 = mk3(-1.0f, 1.0f, -1.0f), k3 = mk3(1.0f, 1.0f, 1.0f);
+    v3 n = sdf_eval(sd, p + e * k0) * k0 + sdf_eval(sd, p + e * k1) * k1 + sdf_eval(sd, p + e * k2) * k2 + sdf_eval(sd, p + e * k3) * k3;
+    return norm3(n);
+}
+
 // Path state that survives from one bounce to the next (tracer.rs:51-57):
 // hit_dist is deliberately NOT reset per bounce (scene.rs:66 reads the stale value).
 // The reference also keeps light_sample and state.is_emitter alive across bounces
@@ -95,7 +142,8 @@ struct HitInfo {
 // (scene.rs:36-86) over the tables.  Only the final normal is computed (the
 // reference also computes the normals of accepted-then-superseded primitives,
 // which nothing reads).
-RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, HitInfo& hi)
+template <bool SDF>
+RPT_DEV bool closest_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, PathState& ps, HitInfo& hi)
 {
     float dist = 3.40282347e+38f;                                   // F::MAX
     bool hit = false;
@@ -130,13 +178,28 @@ RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, H
             accepted |= 1u << (kMaxSpheres + k);
         }
     }
+    bool win_sdf = false;
+    if (SDF) {                                                      // the SDF object, tested last
+        float t;
+        bool h = sdf_march(*sdf, ray, t);
+        bool acc = h && ((sc.n_spheres == 0 && sc.n_planes == 0) || t < dist);
+        if (acc) {
+            dist = t;
+            win_sdf = true;
+            hit = true;
+            accepted |= 1u << (kMaxSpheres + kMaxPlanes);
+        }
+    }
     if (hit) {
         ps.hit_dist = dist;                                         // analytical.rs:48,79,104
         v3 hp = ray.o + dist * ray.d;                               // ray.at(d)
-        v3 sn = norm3(hp - c);
-        hi.normal.x = win_plane ? pn.x : sn.x;                      // (per component: a struct select goes through scratch)
-        hi.normal.y = win_plane ? pn.y : sn.y;
-        hi.normal.z = win_plane ? pn.z : sn.z;
+        v3 sn;
+        if (SDF && win_sdf) sn = sdf_normal(*sdf, hp);
+        else sn = norm3(hp - c);
+        const bool use_pn = win_plane && !win_sdf;
+        hi.normal.x = use_pn ? pn.x : sn.x;                         // (per component: a struct select goes through scratch)
+        hi.normal.y = use_pn ? pn.y : sn.y;
+        hi.normal.z = use_pn ? pn.z : sn.z;
     }
 
     // material = Material::new() then the accepted primitives' writes, in order
@@ -145,6 +208,8 @@ RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, H
         apply_patch(hi.mat, sc.materials[sc.spheres[i].material], (accepted >> i) & 1u, ray.d);
     for (uint32_t k = 0; k < sc.n_planes; ++k)
         apply_patch(hi.mat, sc.materials[sc.planes[k].material], (accepted >> (kMaxSpheres + k)) & 1u, ray.d);
+    if (SDF)
+        apply_patch(hi.mat, sc.materials[sdf->material], (accepted >> (kMaxSpheres + kMaxPlanes)) & 1u, ray.d);
 
     // Scene::sample_lights, scene.rs:65-85
     float ldist = ps.hit_dist;
@@ -169,9 +234,19 @@ RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, H
     return hit;
 }
 
+RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, HitInfo& hi)
+{
+    return closest_hit_small<false>(sc, nullptr, ray, ps, hi);
+}
+RPT_DEV bool closest_hit(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, HitInfo& hi)
+{
+    return closest_hit_small<true>(sc, &sc.sdf, ray, ps, hi);
+}
+
 // AnalyticalScene::any_hit (analytical.rs:130-145); it ignores max_dist unless the
 // scene opts in.
-RPT_DEV bool any_hit(const SceneSmall& sc, const RayD& ray, float max_dist)
+template <bool SDF>
+RPT_DEV bool any_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, float max_dist)
 {
     bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
     bool occluded = false;
@@ -186,8 +261,15 @@ RPT_DEV bool any_hit(const SceneSmall& sc, const RayD& ray, float max_dist)
         bool h = hit_plane(ray, sc.planes[k], t);
         occluded = occluded || (h && (!use_max || t < max_dist));
     }
+    if (SDF) {
+        float t;
+        bool h = sdf_march(*sdf, ray, t);
+        occluded = occluded || (h && (!use_max || t < max_dist));
+    }
     return occluded;
 }
+RPT_DEV bool any_hit(const SceneSmall& sc, const RayD& ray, float max_dist) { return any_hit_small<false>(sc, nullptr, ray, max_dist); }
+RPT_DEV bool any_hit(const SceneSmallSdf& sc, const RayD& ray, float max_dist) { return any_hit_small<true>(sc, &sc.sdf, ray, max_dist); }
 
 // analytical.rs:28-32 + scene.rs:32-34
 template <class S>

@@ -18,6 +18,7 @@ constexpr int kMaxSpheres = 8;
 constexpr int kMaxPlanes = 4;
 constexpr int kMaxLights = 4;
 constexpr int kMaxMaterials = 12;
+constexpr int kMaxSdfPrims = 8;
 
 struct DevSphere {
     float cx, cy, cz, radius;
@@ -65,6 +66,19 @@ struct DevBackground {
     float gamma, scale;
 };
 
+struct DevSdfPrim {
+    uint32_t kind;
+    float cx, cy, cz;
+    float p0, p1;
+};
+
+// The procedural SDF object (include/rpt.h, rpt_sdf): smooth union of up to 8 primitives.
+struct DevSdf {
+    uint32_t n_prims, max_steps, material;
+    float smooth_k, hit_eps, max_t, normal_eps;
+    DevSdfPrim prims[kMaxSdfPrims];
+};
+
 struct SceneSmall {
     uint32_t n_spheres, n_planes, n_lights, n_materials;
     uint32_t flags, max_depth;
@@ -76,6 +90,12 @@ struct SceneSmall {
     DevPlane planes[kMaxPlanes];
     DevLight lights[kMaxLights];
     DevMaterial materials[kMaxMaterials];
+};
+
+// A small scene that also carries the SDF object: its own type, so that the kernel for plain
+// analytical scenes (the benchmark path) contains no sphere-marching code.
+struct SceneSmallSdf : SceneSmall {
+    DevSdf sdf;
 };
 
 // One launch's worth of render parameters.

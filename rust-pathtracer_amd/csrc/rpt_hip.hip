@@ -118,6 +118,7 @@ RPT_DEV void render_nested_body(const S& sc, const RenderParams& rp)
 
 __global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSmall sc, const RenderParams rp) { render_nested_body(sc, rp); }
 __global__ __launch_bounds__(256) void render_large_nested_kernel(const SceneLarge sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void render_sdf_nested_kernel(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(sc, rp); }
 
 // The production megakernel.  Same arithmetic per sample, different schedule:
 //  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
@@ -224,6 +225,8 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_kernel(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_large_regen_kernel(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
+// Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_sdf_regen_kernel(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
 
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
 __global__ __launch_bounds__(256) void untile_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
@@ -295,7 +298,7 @@ struct rpt_ctx {
     hipStream_t stream = nullptr;
     bool has_scene = false;
     bool large = false;               // scene exceeds the kernarg tables: SceneLarge + device tables
-    SceneSmall scene;                 // camera part is filled per launch (depends on width/height)
+    SceneSmallSdf scene;              // camera part is filled per launch (depends on width/height); sdf.n_prims == 0: plain
     SceneLarge scene_large;
     void* tables = nullptr;           // one device allocation holding the large scene's tables
     rpt_camera camera;
@@ -511,6 +514,15 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         return DevBackground{b.kind, b.colour_a[0], b.colour_a[1], b.colour_a[2], b.colour_b[0], b.colour_b[1], b.colour_b[2], b.gamma, b.scale};
     };
 
+    if (s->sdf.n_prims) {
+        if (s->sdf.n_prims > (uint32_t)kMaxSdfPrims || !s->sdf.prims || s->sdf.material >= s->n_materials || !(s->sdf.smooth_k > 0.0f)) {
+            set_err(ctx, "rpt_upload_scene: bad SDF object (1..%d prims, material in range, smooth_k > 0)", kMaxSdfPrims);
+            return RPT_ERR_INVALID_ARG;
+        }
+        for (uint32_t i = 0; i < s->sdf.n_prims; ++i)
+            if (s->sdf.prims[i].kind > RPT_SDF_TORUS_Y) { set_err(ctx, "rpt_upload_scene: unknown SDF primitive kind"); return RPT_ERR_INVALID_ARG; }
+        if (large) { set_err(ctx, "rpt_upload_scene: the SDF object is only supported in small scenes"); return RPT_ERR_UNSUPPORTED; }
+    }
     if (large) {
         // Layered patches need a bit per primitive; large scenes must use full sphere materials.
         for (uint32_t i = 0; i < s->n_spheres; ++i) {
@@ -557,7 +569,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         return RPT_OK;
     }
 
-    SceneSmall& d = ctx->scene;
+    SceneSmallSdf& d = ctx->scene;
     memset(&d, 0, sizeof(d));
     d.n_spheres = s->n_spheres; d.n_planes = s->n_planes; d.n_lights = s->n_lights; d.n_materials = s->n_materials;
     d.flags = s->flags;
@@ -590,6 +602,12 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         m.specular_tint = a.specular_tint; m.sheen = a.sheen; m.sheen_tint = a.sheen_tint; m.clearcoat = a.clearcoat;
         m.clearcoat_gloss = a.clearcoat_gloss; m.spec_trans = a.spec_trans; m.ior = a.ior;
         for (int k = 0; k < 4; ++k) m.proc_params[k] = a.proc_params[k];
+    }
+    d.sdf.n_prims = s->sdf.n_prims; d.sdf.max_steps = s->sdf.max_steps; d.sdf.material = s->sdf.material;
+    d.sdf.smooth_k = s->sdf.smooth_k; d.sdf.hit_eps = s->sdf.hit_eps; d.sdf.max_t = s->sdf.max_t; d.sdf.normal_eps = s->sdf.normal_eps;
+    for (uint32_t i = 0; i < s->sdf.n_prims; ++i) {
+        const rpt_sdf_prim& a = s->sdf.prims[i];
+        d.sdf.prims[i] = DevSdfPrim{a.kind, a.center[0], a.center[1], a.center[2], a.params[0], a.params[1]};
     }
     ctx->camera = s->camera;
     ctx->large = false;
@@ -624,9 +642,11 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     if (world == 1) tile_rows = height;                              // one block: local row == global row
 
     RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    SceneSmall sc = ctx->scene;
+    SceneSmallSdf scs = ctx->scene;
     SceneLarge scl = ctx->scene_large;
-    sc.cam = scl.cam = make_camera(ctx->camera, (float)width, (float)height);
+    scs.cam = scl.cam = make_camera(ctx->camera, (float)width, (float)height);
+    const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
+    const bool has_sdf = !ctx->large && scs.sdf.n_prims > 0;
 
     RenderParams rp;
     rp.pixels = pixels_dev;
@@ -653,6 +673,8 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
         const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
         if (ctx->large && nested) hipLaunchKernelGGL(render_large_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scl, rp);
         else if (ctx->large) hipLaunchKernelGGL(render_large_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scl, rp);
+        else if (has_sdf && nested) hipLaunchKernelGGL(render_sdf_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scs, rp);
+        else if (has_sdf) hipLaunchKernelGGL(render_sdf_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scs, rp);
         else if (nested) hipLaunchKernelGGL(render_small_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
         else hipLaunchKernelGGL(render_small_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
         RPT_HIP_CHECK(ctx, hipGetLastError());

@@ -65,3 +65,25 @@ def random_spheres_scene(n_spheres=10000, n_lights=16, seed=0x5EED0005, n_palett
         z = -105.0 + 90.0 * (gz + 0.5) / side
         s.lights.append(AnalyticalLight.spherical((x, 15.0, z), 1.0, (5.0, 5.0, 5.0)))
     return s
+
+
+def sdf_scene():
+    """BASELINE.json configs[3] (project-defined; the reference has no SDF scene, Readme.md:18): a
+    sphere-marched blob — the polynomial smooth union of two spheres and a torus — over the reference's
+    checker plane, next to one analytical clearcoat sphere, lit by the reference's spherical light."""
+    s = Scene()
+    s.camera = Pinhole((0.0, 0.6, 3.6), (0.0, 0.0, 0.0), 70.0)
+    s.background = dict(kind=_abi.RPT_BG_GRADIENT_Y, colour_a=(1.0, 1.0, 1.0), colour_b=(0.5, 0.7, 1.0), gamma=2.2, scale=0.5)
+    s.lights = [AnalyticalLight.spherical((3.0, 2.0, 2.0), 1.0, (3.0, 3.0, 3.0))]
+    s.materials = [
+        Material(rgb=(0.2, 0.55, 0.9), roughness=0.35, clearcoat=1.0, clearcoat_gloss=0.8),      # the blob
+        Material(rgb=(1.0, 0.186, 0.0), clearcoat=1.0, clearcoat_gloss=1.0, roughness=0.1),      # analytical sphere
+        Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1)),                           # floor
+    ]
+    s.spheres = [((1.9, -0.4, -0.3), 0.6, 1)]
+    s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2)]
+    s.sdf = dict(prims=[(_abi.RPT_SDF_SPHERE, (-0.9, -0.2, 0.0), (0.8, 0.0)),
+                        (_abi.RPT_SDF_SPHERE, (0.1, 0.15, 0.2), (0.55, 0.0)),
+                        (_abi.RPT_SDF_TORUS_Y, (-0.3, -0.55, 0.1), (1.25, 0.22))],
+                 material=0, smooth_k=0.35, max_steps=128, hit_eps=1e-3, max_t=60.0, normal_eps=1e-3)
+    return s

@@ -261,7 +261,8 @@ def test_cpp_host_mirror_runs_the_reference_main_loop(rpt, oracle, tmp_path):
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "examples", "render_cpp")
-    if not os.path.exists(exe):
+    deps = [os.path.join(root, "include", "rpt.h"), os.path.join(root, "include", "rpt.hpp"), os.path.join(root, "examples", "render_cpp.cpp")]
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
         subprocess.run(["g++", "-std=c++17", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "render_cpp.cpp"),
                         "-L", os.path.join(root, "rust-pathtracer_amd"), "-lrpt_hip",
                         "-Wl,-rpath," + os.path.join(root, "rust-pathtracer_amd"), "-o", exe], check=True)
@@ -304,3 +305,19 @@ def test_large_scene_needs_full_sphere_materials(rpt):
     assert rpt.lib().rpt_upload_scene(h, C.byref(d)) == rpt._abi.RPT_ERR_UNSUPPORTED
     assert b"full sphere materials" in rpt.lib().rpt_last_error(h)
     rpt.lib().rpt_destroy(h)
+
+
+def test_sdf_scene_matches_oracle(rpt, oracle):
+    """BASELINE.json configs[3]: sphere-marched smooth-union blob (divergent march lengths), analytical
+    sphere, checker plane, spherical light — bit-identical to the oracle in both kernel forms."""
+    from rust_pathtracer_amd import scenes
+    s = scenes.sdf_scene()
+    w, h, spp = 128, 72, 4
+    t = rpt.Tracer(s, device=0, seed=9)
+    want = oracle.render(s.describe(), w, h, spp, seed=9)
+    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+        t.flags = flags
+        buf = rpt.ColorBuffer(w, h)
+        t.render_n(buf, spp)
+        assert_bit_identical(buf.image(), want, "sdf scene flags=%d" % flags)
+    t.close()

@@ -238,3 +238,28 @@ def test_convert_to_u8(oracle):
     assert list(out[1]) == [0, 255, 0, 255]                       # pow(-1, .4545) = NaN -> 0; saturating casts
     assert out[2, 0] == int((np.float64(np.float32(0.2176)) ** np.float64(np.float32(0.4545))) * 255.0)
     assert out[2, 3] == int(np.float32(0.999) * np.float32(255.0))
+
+
+def test_sdf_object_known_answers(oracle, rpt):
+    """The project-defined SDF object (include/rpt.h rpt_sdf): a single unit sphere, no smoothing
+    partner, seen head-on from z = 3 must be hit at t = 2 like the analytical sphere (to the march
+    tolerance hit_eps * t), with the analytical normal, so both scenes render nearly the same image."""
+    def scene(use_sdf):
+        s = rpt.Scene()
+        s.camera = rpt.Pinhole((0.0, 0.0, 3.0), (0.0, 0.0, 0.0), 40.0)
+        s.background = dict(kind=rpt._abi.RPT_BG_CONSTANT, colour_a=(0.3, 0.3, 0.3), colour_b=(0, 0, 0), gamma=2.2, scale=1.0)
+        s.materials = [rpt.Material(rgb=(0.8, 0.8, 0.8), roughness=1.0)]
+        s.lights = [rpt.AnalyticalLight.spherical((0.0, 4.0, 3.0), 0.5, (20.0, 20.0, 20.0))]
+        if use_sdf:
+            s.sdf = dict(prims=[(rpt._abi.RPT_SDF_SPHERE, (0.0, 0.0, 0.0), (1.0, 0.0))], material=0, smooth_k=0.25,
+                         max_steps=128, hit_eps=1e-4, max_t=50.0, normal_eps=1e-3)
+        else:
+            s.spheres = [((0.0, 0.0, 0.0), 1.0, 0)]
+        return s
+    a = oracle.render(scene(True).describe(), 48, 48, 64, seed=4)[..., :3]
+    b = oracle.render(scene(False).describe(), 48, 48, 64, seed=4)[..., :3]
+    assert not np.isnan(a).any()
+    assert abs(a.mean() - b.mean()) < 0.02 * b.mean()
+    assert np.abs(a[16:32, 16:32].mean(axis=(0, 1)) - b[16:32, 16:32].mean(axis=(0, 1))).max() < 0.03
+    # outside the silhouette both are the constant background
+    assert np.allclose(a[0, 0], 0.3, atol=1e-6) and np.array_equal(a[0, 0], b[0, 0])
