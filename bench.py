@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
+    ap.add_argument("--smoke-shared-gpu", action="store_true",
+                    help="TEST ONLY: all ranks use cuda:0 and the gloo backend (RCCL rejects duplicate devices), to exercise "
+                         "the N>1 code path on a 1-GPU box; the numbers mean nothing")
     args = ap.parse_args()
 
     import torch
@@ -90,11 +93,16 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     dist = None
+    if args.smoke_shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.smoke_shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     width, height = frame_size(world)
     tracer = rpt.Tracer(rpt.AnalyticalScene(), device=local_rank, seed=1)
