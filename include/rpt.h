@@ -102,6 +102,7 @@ typedef struct rpt_plane {            /* analytical.rs:193-204 generalised: dot(
     float    point[3];
     float    min_denom;               /* reject |dot(n,d)| <= min_denom (1e-4 in the reference) */
     uint32_t material;
+    float    max_t;                   /* > 0: also reject t > max_t (a floor of finite reach); 0 = the reference's infinite plane */
 } rpt_plane;
 
 enum { RPT_LIGHT_RECTANGULAR = 0, RPT_LIGHT_SPHERICAL = 1, RPT_LIGHT_DISTANT = 2 };  /* globals.rs:69-73 */
@@ -261,6 +262,11 @@ enum {
 };
 int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b_dev,
                    float* out_dev, uint64_t n, void* stream);
+
+/* Ray queries against the uploaded LARGE scene's spheres, for testing the acceleration structure:
+ * rays_dev = n x {origin[3], direction[3], max_dist}; out_dev = n x {t (f32 bits), nearest sphere index
+ * or 0xFFFFFFFF, any_hit (0/1) with max_dist honoured}.  use_grid = 0 forces the brute-force loops. */
+int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint64_t n, uint32_t use_grid, void* stream);
 
 #ifdef __cplusplus
 }

@@ -135,6 +135,22 @@ int oracle_sample_pixels(const rpt_scene_desc* desc, const uint32_t* cols, const
     return 0;
 }
 
+// The rays (closest_hit: max_dist = -1; any_hit: its max_dist) one pixel-sample queries, 7 floats each.
+int oracle_sample_rays(const rpt_scene_desc* desc, uint32_t col, uint32_t row, uint64_t frame, uint32_t width, uint32_t height,
+                       uint64_t seed, float* out, uint32_t max_rays)
+{
+    Scene scene(*desc);
+    Tracer tracer(scene);
+    std::vector<float> log;
+    g_ray_log = &log;
+    tracer.sample_pixel(col, row, width, height, frame_key(seed, frame));
+    g_ray_log = nullptr;
+    uint32_t n = (uint32_t)(log.size() / 7);
+    if (n > max_rays) n = max_rays;
+    std::memcpy(out, log.data(), (size_t)n * 7 * sizeof(float));
+    return (int)n;
+}
+
 // Count floating-point operations over a render (RPT_OPCOUNT build; zeros otherwise).
 // counts = {add, mul, div, sqrt, transcendental, compare}
 int oracle_opcount(const rpt_scene_desc* desc, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t* counts)

@@ -282,7 +282,7 @@ inline bool plane(const Ray& ray, const rpt_plane& p, F& t_out)
     F denom = dot(normal, ray.direction);
     if (f_abs(denom) > F(p.min_denom)) {
         F t = dot(F3(p.point[0], p.point[1], p.point[2]) - ray.origin, normal) / denom;
-        if (t >= F(0.0f)) { t_out = t; return true; }
+        if (t >= F(0.0f) && (!(p.max_t > 0.0f) || t <= F(p.max_t))) { t_out = t; return true; }   // max_t: project extension, 0 in the reference
     }
     return false;
 }
@@ -310,6 +310,10 @@ struct Pinhole {                                                                
         return Ray(origin, rd.normalize());
     }
 };
+
+// Debug aid for tests: when set, every closest_hit / any_hit query appends {o, d, max_dist} (max_dist = -1
+// for closest_hit) so a test can replay the exact rays of a pixel-sample through the device probes.
+inline thread_local std::vector<float>* g_ray_log = nullptr;
 
 struct Scene {
     rpt_scene_desc d;
@@ -451,6 +455,7 @@ struct Scene {
     // (analytical.rs:43 has no `d < dist` test); the others only when nearer.
     bool closest_hit(const Ray& ray, State& state, LightSampleRec& light_sample) const
     {
+        if (g_ray_log) for (float v : {raw(ray.origin.x), raw(ray.origin.y), raw(ray.origin.z), raw(ray.direction.x), raw(ray.direction.y), raw(ray.direction.z), -1.0f}) g_ray_log->push_back(v);
         F dist(3.40282347e+38f);                                                   // F::MAX, analytical.rs:38
         bool hit = false;
         bool first = true;
@@ -502,6 +507,7 @@ struct Scene {
     // analytical.rs:130-145; max_dist is ignored there (flag off)
     bool any_hit(const Ray& ray, F max_dist) const
     {
+        if (g_ray_log) for (float v : {raw(ray.origin.x), raw(ray.origin.y), raw(ray.origin.z), raw(ray.direction.x), raw(ray.direction.y), raw(ray.direction.z), raw(max_dist)}) g_ray_log->push_back(v);
         bool use_max = (d.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
         for (const rpt_sphere& s : spheres) {
             F dd;

@@ -63,7 +63,7 @@ class rpt_sphere(C.Structure):
 
 
 class rpt_plane(C.Structure):
-    _fields_ = [("normal", F3), ("point", F3), ("min_denom", C.c_float), ("material", C.c_uint32)]
+    _fields_ = [("normal", F3), ("point", F3), ("min_denom", C.c_float), ("material", C.c_uint32), ("max_t", C.c_float)]
 
 
 class rpt_light(C.Structure):
@@ -123,5 +123,6 @@ SYMBOLS = {
     "rpt_convert_to_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rpt_convert_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "rpt_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_probe_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "rpt_probe_math": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 }

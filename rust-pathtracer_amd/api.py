@@ -95,7 +95,7 @@ class Scene:
     def __init__(self):
         self.camera = Pinhole()
         self.spheres = []        # (center, radius, material_index)
-        self.planes = []         # (normal, point, min_denom, material_index)
+        self.planes = []         # (normal, point, min_denom, material_index[, max_t])
         self.lights = []         # AnalyticalLight
         self.materials = []      # Material
         self.background = dict(kind=_abi.RPT_BG_CONSTANT, colour_a=(0.0, 0.0, 0.0), colour_b=(0.0, 0.0, 0.0), gamma=2.2, scale=1.0)
@@ -134,8 +134,10 @@ class Scene:
         for i, (c, r, m) in enumerate(self.spheres):
             sph[i].center = _abi.F3(*c); sph[i].radius = r; sph[i].material = m
         pl = (_abi.rpt_plane * max(1, len(self.planes)))()
-        for i, (n, p, md, m) in enumerate(self.planes):
+        for i, pln in enumerate(self.planes):
+            n, p, md, m = pln[:4]
             pl[i].normal = _abi.F3(*n); pl[i].point = _abi.F3(*p); pl[i].min_denom = md; pl[i].material = m
+            pl[i].max_t = pln[4] if len(pln) > 4 else 0.0
         li = (_abi.rpt_light * max(1, len(self.lights)))()
         for i, L in enumerate(self.lights):
             li[i].type = L.light_type; li[i].position = _abi.F3(*L.position); li[i].emission = _abi.F3(*L.emission)

@@ -38,7 +38,7 @@ RPT_DEV bool hit_plane(const RayD& ray, const DevPlane& p, float& t)
     float denom = dot3(n, ray.d);
     if (__builtin_fabsf(denom) > p.min_denom) {
         float tt = dot3(mk3(p.px, p.py, p.pz) - ray.o, n) / denom;
-        if (tt >= 0.0f) { t = tt; return true; }
+        if (tt >= 0.0f && (!(p.max_t > 0.0f) || tt <= p.max_t)) { t = tt; return true; }
     }
     return false;
 }

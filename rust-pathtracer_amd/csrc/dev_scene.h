@@ -30,6 +30,7 @@ struct DevPlane {
     float px, py, pz;
     float min_denom;
     uint32_t material;
+    float max_t;               // > 0: finite reach (project extension); 0: the reference's infinite plane
 };
 
 struct DevLight {

@@ -34,6 +34,16 @@ struct SceneLarge {
     const DevLight* lights;
     const DevMaterial* materials;
     DevPlane planes[kMaxPlanes];
+    // Uniform grid over the spheres (built on the host at upload, rpt_hip.hip build_grid):
+    // cell (ix,iy,iz) -> items[cell_start[c] .. cell_start[c+1]) = indices of the spheres whose
+    // padded bounding box overlaps the cell, ascending.  use_grid == 0: brute-force streaming.
+    uint32_t use_grid;
+    uint32_t gn[3];
+    float gmin[3], gmax[3], cell_size[3], inv_cell_size[3];
+    float gcenter[3];
+    float safe_r2;                    // rays starting farther than sqrt(safe_r2) from gcenter use the brute-force loop
+    const uint32_t* cell_start;
+    const uint32_t* cell_items;
 };
 
 // Wave-uniform table reads: plain dwords through the constant address space, which the
@@ -77,16 +87,113 @@ RPT_DEV DevLight light_at(const SceneLarge& sc, uint32_t index)     // per-lane 
     return sc.lights[index];
 }
 
-// AnalyticalScene::closest_hit + Scene::sample_lights, as in dev_integrator.h, for N spheres.
-RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, HitInfo& hi)
-{
-    float dist = 3.40282347e+38f;
-    bool hit = false;
-    uint32_t best = 0xFFFFFFFFu;                                    // nearest sphere so far
-    uint32_t accepted_planes = 0;
-    v3 pn = mk3(0.0f, 0.0f, 0.0f);
-    bool win_plane = false;
+// ---------------------------------------------------------------------------
+// Grid traversal (3D DDA).  The brute-force loop accepts sphere i when it is hit and
+// (i == 0 or t < dist), i.e. it ends with the hit of smallest t, lowest index on ties
+// (and sphere 0 unconditionally if it is hit first).  Visiting spheres in grid order gives the
+// same winner with the acceptance rule  t < dist || (t == dist && i < best); sphere 0 is
+// tested up front exactly like the loop does.  A sphere is registered in every cell its
+// bounding box overlaps, and the box is PADDED by how far outside the sphere a line can pass and
+// still be called a hit by the reference's f32 test: d2 = l.l - tca*tca cancels catastrophically,
+// with an absolute error of about 4e-7 * |l|^2, so from 250 units away a line 0.1 outside a
+// 0.3-radius sphere can "hit" it — and the brute-force loop (the semantics to reproduce) reports
+// that.  The padding covers every origin within sqrt(safe_r2) of the grid centre (host:
+// build_grid); rays that start farther away (grazing floor hits tens of thousands of units out,
+// where the test is pure noise) take the brute-force loop instead.
+// ---------------------------------------------------------------------------
+struct GridWalk {
+    int ix, iy, iz;
+    int sx, sy, sz;
+    float tmx, tmy, tmz;       // t at which the ray leaves the current cell along each axis
+    float tdx, tdy, tdz;
+    float t_end;               // t at which the ray leaves the grid
+    bool alive;
+};
 
+RPT_DEV GridWalk grid_begin(const SceneLarge& sc, const RayD& ray)
+{
+    GridWalk g;
+    g.alive = false;
+    // slab test against the grid box, from t = 0
+    float t0 = 0.0f, t1 = 3.40282347e+38f;
+    const float o[3] = {ray.o.x, ray.o.y, ray.o.z};
+    const float d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (d[a] != 0.0f) {
+            float inv = 1.0f / d[a];
+            float ta = (sc.gmin[a] - o[a]) * inv;
+            float tb = (sc.gmax[a] - o[a]) * inv;
+            float lo = ta < tb ? ta : tb;
+            float hi = ta < tb ? tb : ta;
+            t0 = lo > t0 ? lo : t0;
+            t1 = hi < t1 ? hi : t1;
+        } else {
+            ok = ok && (o[a] >= sc.gmin[a]) && (o[a] <= sc.gmax[a]);
+        }
+    }
+    if (!ok || !(t0 <= t1)) return g;
+    g.t_end = t1;
+    int cell[3], step[3];
+    float tmax[3], tdel[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float p = o[a] + t0 * d[a];
+        int c = (int)__builtin_floorf((p - sc.gmin[a]) * sc.inv_cell_size[a]);
+        const int n = (int)sc.gn[a];
+        c = c < 0 ? 0 : (c > n - 1 ? n - 1 : c);
+        cell[a] = c;
+        if (d[a] > 0.0f) {
+            step[a] = 1;
+            tmax[a] = (sc.gmin[a] + (float)(c + 1) * sc.cell_size[a] - o[a]) / d[a];
+            tdel[a] = sc.cell_size[a] / d[a];
+        } else if (d[a] < 0.0f) {
+            step[a] = -1;
+            tmax[a] = (sc.gmin[a] + (float)c * sc.cell_size[a] - o[a]) / d[a];
+            tdel[a] = -sc.cell_size[a] / d[a];
+        } else {
+            step[a] = 0;
+            tmax[a] = 3.40282347e+38f;
+            tdel[a] = 3.40282347e+38f;
+        }
+    }
+    g.ix = cell[0]; g.iy = cell[1]; g.iz = cell[2];
+    g.sx = step[0]; g.sy = step[1]; g.sz = step[2];
+    g.tmx = tmax[0]; g.tmy = tmax[1]; g.tmz = tmax[2];
+    g.tdx = tdel[0]; g.tdy = tdel[1]; g.tdz = tdel[2];
+    g.alive = true;
+    return g;
+}
+
+RPT_DEV uint32_t grid_cell_index(const SceneLarge& sc, const GridWalk& g)
+{
+    return ((uint32_t)g.iz * sc.gn[1] + (uint32_t)g.iy) * sc.gn[0] + (uint32_t)g.ix;
+}
+
+// t at which the ray leaves the current cell
+RPT_DEV float grid_cell_exit(const GridWalk& g)
+{
+    float m = g.tmx < g.tmy ? g.tmx : g.tmy;
+    return m < g.tmz ? m : g.tmz;
+}
+
+RPT_DEV void grid_step(const SceneLarge& sc, GridWalk& g)
+{
+    if (g.tmx <= g.tmy && g.tmx <= g.tmz) { g.ix += g.sx; g.tmx += g.tdx; g.alive = (g.ix >= 0) && (g.ix < (int)sc.gn[0]); }
+    else if (g.tmy <= g.tmz) { g.iy += g.sy; g.tmy += g.tdy; g.alive = (g.iy >= 0) && (g.iy < (int)sc.gn[1]); }
+    else { g.iz += g.sz; g.tmz += g.tdz; g.alive = (g.iz >= 0) && (g.iz < (int)sc.gn[2]); }
+}
+
+// nearest sphere along the ray (dist/best in-out), equivalent to the ordered loop over all spheres
+RPT_DEV bool grid_usable(const SceneLarge& sc, const RayD& ray)
+{
+    const float dx = ray.o.x - sc.gcenter[0], dy = ray.o.y - sc.gcenter[1], dz = ray.o.z - sc.gcenter[2];
+    return (dx * dx + dy * dy + dz * dz) <= sc.safe_r2;              // false for NaN origins too
+}
+
+RPT_DEV void brute_closest_sphere(const SceneLarge& sc, const RayD& ray, float& dist, uint32_t& best, bool& hit)
+{
     for (uint32_t i = 0; i < sc.n_spheres; ++i) {
         const float4 s = sphere_uniform(sc, i);
         float t;
@@ -98,6 +205,84 @@ RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, H
             hit = true;
         }
     }
+}
+
+RPT_DEV bool brute_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max, float max_dist)
+{
+    bool occluded = false;
+    for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+        const float4 s = sphere_uniform(sc, i);
+        float t;
+        bool h = hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t);
+        occluded = occluded || (h && (!use_max || t < max_dist));
+    }
+    return occluded;
+}
+
+RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& dist, uint32_t& best, bool& hit)
+{
+    if (!grid_usable(sc, ray)) { brute_closest_sphere(sc, ray, dist, best, hit); return; }
+    {   // sphere 0: accepted whenever it is hit (analytical.rs:43)
+        const float4 s = sphere_uniform(sc, 0);
+        float t;
+        if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; hit = true; }
+    }
+    GridWalk g = grid_begin(sc, ray);
+    // a DDA crosses at most nx+ny+nz cells; the bound guarantees every wave leaves the loop
+    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
+        const uint32_t c = grid_cell_index(sc, g);
+        const uint32_t k0 = sc.cell_start[c], k1 = sc.cell_start[c + 1];
+        for (uint32_t k = k0; k < k1; ++k) {
+            const uint32_t i = sc.cell_items[k];
+            if (i == 0u) continue;
+            const float4 s = sc.spheres[i];
+            float t;
+            if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) {
+                if (t < dist || (t == dist && i < best)) { dist = t; best = i; hit = true; }
+            }
+        }
+        const float t_exit = grid_cell_exit(g);
+        if (hit && dist <= t_exit) break;                           // nothing beyond this cell can be nearer
+        if (t_exit > g.t_end) break;
+        grid_step(sc, g);
+    }
+}
+
+RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max, float max_dist)
+{
+    if (!grid_usable(sc, ray)) return brute_any_sphere(sc, ray, use_max, max_dist);
+    GridWalk g = grid_begin(sc, ray);
+    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
+        const uint32_t c = grid_cell_index(sc, g);
+        const uint32_t k0 = sc.cell_start[c], k1 = sc.cell_start[c + 1];
+        for (uint32_t k = k0; k < k1; ++k) {
+            const float4 s = sc.spheres[sc.cell_items[k]];
+            float t;
+            if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (!use_max || t < max_dist)) return true;
+        }
+        const float t_exit = grid_cell_exit(g);
+        if (t_exit > g.t_end) break;
+        if (use_max && t_exit > max_dist) {
+            // a sphere entirely beyond max_dist cannot occlude; one straddling this cell was tested
+            break;
+        }
+        grid_step(sc, g);
+    }
+    return false;
+}
+
+// AnalyticalScene::closest_hit + Scene::sample_lights, as in dev_integrator.h, for N spheres.
+RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, HitInfo& hi)
+{
+    float dist = 3.40282347e+38f;
+    bool hit = false;
+    uint32_t best = 0xFFFFFFFFu;                                    // nearest sphere so far
+    uint32_t accepted_planes = 0;
+    v3 pn = mk3(0.0f, 0.0f, 0.0f);
+    bool win_plane = false;
+
+    if (sc.use_grid) grid_closest_sphere(sc, ray, dist, best, hit);
+    else brute_closest_sphere(sc, ray, dist, best, hit);
     for (uint32_t k = 0; k < sc.n_planes; ++k) {
         const DevPlane& p = sc.planes[k];
         float t;
@@ -167,13 +352,7 @@ RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, H
 RPT_DEV bool any_hit(const SceneLarge& sc, const RayD& ray, float max_dist)
 {
     bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
-    bool occluded = false;
-    for (uint32_t i = 0; i < sc.n_spheres; ++i) {
-        const float4 s = sphere_uniform(sc, i);
-        float t;
-        bool h = hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t);
-        occluded = occluded || (h && (!use_max || t < max_dist));
-    }
+    bool occluded = sc.use_grid ? grid_any_sphere(sc, ray, use_max, max_dist) : brute_any_sphere(sc, ray, use_max, max_dist);
     for (uint32_t k = 0; k < sc.n_planes; ++k) {
         float t;
         bool h = hit_plane(ray, sc.planes[k], t);

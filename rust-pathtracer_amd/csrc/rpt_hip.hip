@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
@@ -290,6 +292,34 @@ __global__ __launch_bounds__(256) void probe_math_kernel(uint32_t fn, const floa
     out[i] = r;
 }
 
+__global__ __launch_bounds__(256) void probe_rays_kernel(const SceneLarge sc, const float* __restrict__ rays, uint32_t* __restrict__ out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + i * 7;
+    RayD ray{mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])};
+    float dist = 3.40282347e+38f;
+    uint32_t best = 0xFFFFFFFFu;
+    bool hit = false;
+    bool any;
+    if (sc.use_grid) {
+        grid_closest_sphere(sc, ray, dist, best, hit);
+        any = grid_any_sphere(sc, ray, true, r[6]);
+    } else {
+        any = false;
+        for (uint32_t k = 0; k < sc.n_spheres; ++k) {
+            const float4 s = sphere_uniform(sc, k);
+            float t;
+            bool h = hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t);
+            if (h && (k == 0 || t < dist)) { dist = t; best = k; hit = true; }
+            any = any || (h && t < r[6]);
+        }
+    }
+    out[i * 3 + 0] = rpt_f2u(dist);
+    out[i * 3 + 1] = best;
+    out[i * 3 + 2] = any ? 1u : 0u;
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -365,6 +395,86 @@ static DevCamera make_camera(const rpt_camera& c, float width, float height)
     return d;
 }
 
+// Uniform grid over the spheres of a large scene (dev_scene_large.h).  Cell size targets ~2 spheres
+// per cell.  Every sphere is listed in each cell its PADDED bounding box overlaps; the padding is the
+// distance outside the sphere at which the reference's f32 ray/sphere test (d2 = l.l - tca^2 <= r^2,
+// absolute error ~4e-7 |l|^2) can still report a hit, for ray origins within `safe_r` of the grid
+// centre, doubled for safety, plus 1e-3 cell sizes for the DDA's own rounding.
+struct HostGrid {
+    uint32_t n[3];
+    float gmin[3], gmax[3], cs[3], inv_cs[3];
+    float center[3], safe_r2;
+    std::vector<uint32_t> cell_start, items;
+};
+
+static HostGrid build_grid(const rpt_sphere* sph, uint32_t count)
+{
+    HostGrid g;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = 0; i < count; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], (double)sph[i].center[a] - sph[i].radius);
+            hi[a] = std::max(hi[a], (double)sph[i].center[a] + sph[i].radius);
+        }
+    double ext[3], vol = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        double pad = 1e-3 * (hi[a] - lo[a]) + 1e-3;
+        lo[a] -= pad; hi[a] += pad;
+        ext[a] = hi[a] - lo[a];
+        vol *= ext[a];
+    }
+    const double target = std::cbrt(vol / (count / 2.0 + 1.0));       // cell edge for ~2 spheres per cell
+    for (int a = 0; a < 3; ++a) {
+        double n = std::ceil(ext[a] / target);
+        n = n < 1 ? 1 : (n > 128 ? 128 : n);
+        g.n[a] = (uint32_t)n;
+        g.gmin[a] = (float)lo[a];
+        g.cs[a] = (float)(ext[a] / n);
+        g.inv_cs[a] = 1.0f / g.cs[a];
+        g.gmax[a] = g.gmin[a] + (float)g.n[a] * g.cs[a];
+    }
+    const size_t ncell = (size_t)g.n[0] * g.n[1] * g.n[2];
+    double half_diag = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        g.center[a] = (float)(0.5 * (lo[a] + hi[a]));
+        half_diag += 0.25 * ext[a] * ext[a];
+    }
+    half_diag = std::sqrt(half_diag);
+    const double safe_r = 6.0 * half_diag;
+    g.safe_r2 = (float)(safe_r * safe_r);
+    const double max_l = safe_r + half_diag;                        // |sphere centre - ray origin| for usable rays
+    const double d2_err = 1.2e-6 * max_l * max_l;                   // bound on the f32 error of l.l - tca*tca
+    auto range = [&](const rpt_sphere& s, int a, int& c0, int& c1) {
+        const double r = s.radius;
+        const double pad = (std::sqrt(r * r + d2_err) - r) + 1e-3 * g.cs[a];
+        c0 = (int)std::floor(((double)s.center[a] - s.radius - pad - g.gmin[a]) / g.cs[a]);
+        c1 = (int)std::floor(((double)s.center[a] + s.radius + pad - g.gmin[a]) / g.cs[a]);
+        c0 = std::max(0, std::min((int)g.n[a] - 1, c0));
+        c1 = std::max(0, std::min((int)g.n[a] - 1, c1));
+    };
+    g.cell_start.assign(ncell + 1, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<uint32_t> cursor;
+        if (pass == 1) {
+            for (size_t c = 0; c < ncell; ++c) g.cell_start[c + 1] += g.cell_start[c];      // counts -> exclusive prefix sums
+            cursor.assign(g.cell_start.begin(), g.cell_start.end() - 1);
+            g.items.assign(g.cell_start[ncell], 0);
+        }
+        for (uint32_t i = 0; i < count; ++i) {                                               // ascending sphere index within a cell
+            int x0, x1, y0, y1, z0, z1;
+            range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) {
+                        const size_t c = ((size_t)z * g.n[1] + y) * g.n[0] + x;
+                        if (pass == 0) g.cell_start[c + 1] += 1;
+                        else g.items[cursor[c]++] = i;
+                    }
+        }
+    }
+    return g;
+}
+
 // Lanes that must be parked on a surface hit before a wave runs its shading block (1..64).
 // RPT_SHADE_THRESHOLD overrides the default for tuning runs.
 static uint32_t shade_threshold()
@@ -399,7 +509,7 @@ int rpt_scene_analytical(rpt_scene_desc* out)
 
     spheres[0] = rpt_sphere{{-1.1f, 0.0f, 0.0f}, 1.0f, 0};           // analytical.rs:41
     spheres[1] = rpt_sphere{{1.1f, 0.0f, 0.0f}, 1.0f, 1};            // analytical.rs:70
-    planes[0] = rpt_plane{{0.0f, 1.0f, 0.0f}, {0.0f, -1.0f, 0.0f}, 0.0001f, 2};   // analytical.rs:194-198
+    planes[0] = rpt_plane{{0.0f, 1.0f, 0.0f}, {0.0f, -1.0f, 0.0f}, 0.0001f, 2, 0.0f};   // analytical.rs:194-198
 
     mats[0].mask = RPT_MAT_RGB | RPT_MAT_ROUGHNESS | RPT_MAT_METALLIC;              // analytical.rs:56-58
     mats[0].rgb[0] = mats[0].rgb[1] = mats[0].rgb[2] = 1.0f;
@@ -498,7 +608,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
     for (uint32_t i = 0; i < s->n_planes; ++i)
         if (s->planes[i].material >= s->n_materials) { set_err(ctx, "rpt_upload_scene: plane %u material out of range", i); return RPT_ERR_INVALID_ARG; }
 
-    auto dev_plane = [](const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material}; };
+    auto dev_plane = [](const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; };
     auto dev_light = [](const rpt_light& a) { return DevLight{a.type, a.position[0], a.position[1], a.position[2], a.emission[0], a.emission[1], a.emission[2], a.radius, a.area}; };
     auto dev_material = [](const rpt_material& a) {
         DevMaterial m;
@@ -538,7 +648,13 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         const size_t sz_smat = (sizeof(uint32_t) * s->n_spheres + 15) & ~(size_t)15;
         const size_t sz_lights = (sizeof(DevLight) * (s->n_lights ? s->n_lights : 1) + 15) & ~(size_t)15;
         const size_t sz_mats = sizeof(DevMaterial) * (s->n_materials ? s->n_materials : 1);
-        std::vector<unsigned char> host(sz_sph + sz_smat + sz_lights + sz_mats, 0);
+        const bool use_grid = s->n_spheres >= 64 && !getenv("RPT_NO_GRID");
+        HostGrid grid;
+        if (use_grid) grid = build_grid(s->spheres, s->n_spheres);
+        const size_t sz_tables = (sz_sph + sz_smat + sz_lights + sz_mats + 15) & ~(size_t)15;
+        const size_t sz_cstart = (sizeof(uint32_t) * grid.cell_start.size() + 15) & ~(size_t)15;
+        const size_t sz_items = sizeof(uint32_t) * grid.items.size();
+        std::vector<unsigned char> host(sz_tables + sz_cstart + sz_items, 0);
         float4* h_sph = reinterpret_cast<float4*>(host.data());
         uint32_t* h_smat = reinterpret_cast<uint32_t*>(host.data() + sz_sph);
         DevLight* h_lights = reinterpret_cast<DevLight*>(host.data() + sz_sph + sz_smat);
@@ -549,6 +665,10 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         }
         for (uint32_t i = 0; i < s->n_lights; ++i) h_lights[i] = dev_light(s->lights[i]);
         for (uint32_t i = 0; i < s->n_materials; ++i) h_mats[i] = dev_material(s->materials[i]);
+        if (use_grid) {
+            memcpy(host.data() + sz_tables, grid.cell_start.data(), sizeof(uint32_t) * grid.cell_start.size());
+            memcpy(host.data() + sz_tables + sz_cstart, grid.items.data(), sz_items);
+        }
         if (ctx->tables) { RPT_HIP_CHECK(ctx, hipFree(ctx->tables)); ctx->tables = nullptr; }
         RPT_HIP_CHECK(ctx, hipMalloc(&ctx->tables, host.size()));
         RPT_HIP_CHECK(ctx, hipMemcpy(ctx->tables, host.data(), host.size(), hipMemcpyHostToDevice));
@@ -563,6 +683,17 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         L.lights = reinterpret_cast<const DevLight*>(base + sz_sph + sz_smat);
         L.materials = reinterpret_cast<const DevMaterial*>(base + sz_sph + sz_smat + sz_lights);
         for (uint32_t i = 0; i < s->n_planes; ++i) L.planes[i] = dev_plane(s->planes[i]);
+        L.use_grid = use_grid ? 1u : 0u;
+        if (use_grid) {
+            for (int a = 0; a < 3; ++a) {
+                L.gn[a] = grid.n[a]; L.gmin[a] = grid.gmin[a]; L.gmax[a] = grid.gmax[a];
+                L.cell_size[a] = grid.cs[a]; L.inv_cell_size[a] = grid.inv_cs[a];
+                L.gcenter[a] = grid.center[a];
+            }
+            L.safe_r2 = grid.safe_r2;
+            L.cell_start = reinterpret_cast<const uint32_t*>(base + sz_tables);
+            L.cell_items = reinterpret_cast<const uint32_t*>(base + sz_tables + sz_cstart);
+        }
         ctx->camera = s->camera;
         ctx->large = true;
         ctx->has_scene = true;
@@ -587,7 +718,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
     }
     for (uint32_t i = 0; i < s->n_planes; ++i) {
         const rpt_plane& a = s->planes[i];
-        d.planes[i] = DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material};
+        d.planes[i] = DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t};
     }
     for (uint32_t i = 0; i < s->n_lights; ++i) {
         const rpt_light& a = s->lights[i];
@@ -760,6 +891,21 @@ int rpt_synchronize(rpt_ctx* ctx, void* stream)
     if (!ctx) { set_err(nullptr, "rpt_synchronize: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     RPT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
+    return RPT_OK;
+}
+
+int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint64_t n, uint32_t use_grid, void* stream)
+{
+    if (!ctx) { set_err(nullptr, "rpt_probe_rays: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!ctx->has_scene || !ctx->large) { set_err(ctx, "rpt_probe_rays: needs an uploaded large scene"); return RPT_ERR_NO_SCENE; }
+    if (!rays_dev || !out_dev) { set_err(ctx, "rpt_probe_rays: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    if (n == 0) return RPT_OK;
+    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    SceneLarge sc = ctx->scene_large;
+    if (!use_grid) sc.use_grid = 0;
+    const uint64_t nblocks = (n + 255) / 256;
+    hipLaunchKernelGGL(probe_rays_kernel, dim3((uint32_t)nblocks), dim3(256), 0, (hipStream_t)stream, sc, rays_dev, out_dev, n);
+    RPT_HIP_CHECK(ctx, hipGetLastError());
     return RPT_OK;
 }
 

@@ -17,7 +17,7 @@ pub struct RptMaterial {
     pub proc_params: [f32; 4],
 }
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptSphere { pub center: [f32; 3], pub radius: f32, pub material: u32 }
-#[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptPlane { pub normal: [f32; 3], pub point: [f32; 3], pub min_denom: f32, pub material: u32 }
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptPlane { pub normal: [f32; 3], pub point: [f32; 3], pub min_denom: f32, pub material: u32, pub max_t: f32 }
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct RptLight { pub light_type: u32, pub position: [f32; 3], pub emission: [f32; 3], pub u: [f32; 3], pub v: [f32; 3], pub radius: f32, pub area: f32 }
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptCamera { pub origin: [f32; 3], pub center: [f32; 3], pub fov_deg: f32 }

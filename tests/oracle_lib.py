@@ -71,6 +71,12 @@ class Oracle:
                                       height, seed, out.ctypes.data)
         return out
 
+    def sample_rays(self, desc, col, row, frame, width, height, seed=1, max_rays=64):
+        out = np.zeros((max_rays, 7), dtype=np.float32)
+        self.lib.oracle_sample_rays.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_uint32]
+        n = self.lib.oracle_sample_rays(C.byref(desc), col, row, frame, width, height, seed, out.ctypes.data, max_rays)
+        return out[:n]
+
     def opcount(self, desc, width, height, spp, seed=1):
         c = np.zeros(6, dtype=np.uint64)
         self.lib.oracle_opcount(C.byref(desc), width, height, spp, seed, c.ctypes.data)

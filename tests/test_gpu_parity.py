@@ -278,7 +278,7 @@ def test_cpp_host_mirror_runs_the_reference_main_loop(rpt, oracle, tmp_path):
     assert np.array_equal(got8, oracle.convert_to_u8(want, w, h))
 
 
-@pytest.mark.parametrize("n_spheres,n_lights", [(300, 16), (9, 2), (40, 5)])
+@pytest.mark.parametrize("n_spheres,n_lights", [(300, 16), (9, 2), (40, 5), (3000, 16), (64, 1)])
 def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
     """BASELINE.json configs[4]'s shape at a size the oracle finishes in seconds: random spheres with
     full materials, a checker plane, a grid of spherical lights; the kernel streams the tables from HBM."""
@@ -320,4 +320,42 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
         assert_bit_identical(buf.image(), want, "sdf scene flags=%d" % flags)
+    t.close()
+
+
+@pytest.mark.parametrize("n_spheres", [64, 3000])
+def test_grid_queries_equal_brute_force(rpt, torch_cuda, n_spheres):
+    """The uniform grid must answer exactly like the reference's ordered loop over all spheres: nearest t
+    (bitwise), winning index, and any-hit, for rays from everywhere — floor points, sphere surfaces at
+    grazing angles, the camera, and origins tens of thousands of units away, where the f32 sphere test is
+    noise and the grid hands the ray to the brute-force loop."""
+    from rust_pathtracer_amd import scenes
+    torch = torch_cuda
+    s = scenes.random_spheres_scene(n_spheres=n_spheres, n_lights=16, seed=0x5EED0005)
+    t = rpt.Tracer(s, device=0, seed=5)
+    rng = np.random.default_rng(n_spheres)
+    N = 1_000_000
+    sph = np.array([list(c) + [r] for c, r, m in s.spheres], dtype=np.float32)
+    pick = rng.integers(0, n_spheres, N)
+    nrm = rng.normal(size=(N, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    o = sph[pick, :3] + (sph[pick, 3:4] + 0.005) * nrm
+    third = N // 3
+    o[:third] = np.stack([rng.uniform(-70, 70, third), np.full(third, -0.995), rng.uniform(-130, 10, third)], axis=1)
+    o[third:third + 1000] = (0.0, 6.0, 14.0)
+    d = rng.normal(size=(N, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tang = np.cross(nrm, d); tang /= np.linalg.norm(tang, axis=1, keepdims=True) + 1e-30
+    graz = tang + nrm * rng.normal(scale=0.02, size=(N, 1)); graz /= np.linalg.norm(graz, axis=1, keepdims=True)
+    d[2 * third:] = graz[2 * third:]
+    far = rng.integers(0, N, N // 10)
+    o[far] = o[far] - d[far] * rng.uniform(50.0, 60000.0, (len(far), 1))
+    maxd = rng.uniform(0.5, 150.0, N); maxd[far] = rng.uniform(10.0, 1e5, len(far))
+    rays = torch.from_numpy(np.concatenate([o, d, maxd[:, None]], axis=1).astype(np.float32)).cuda()
+    res = []
+    for use_grid in (1, 0):
+        out = torch.zeros(N, 3, dtype=torch.int32, device="cuda")
+        rpt._lib.check(rpt.lib().rpt_probe_rays(t._h, rays.data_ptr(), out.data_ptr(), N, use_grid, None), t._h)
+        torch.cuda.synchronize()
+        res.append(out.cpu().numpy())
+    assert (res[1][:, 1] != -1).sum() > N // 20 and res[1][:, 2].sum() > N // 20      # the sample does hit things
+    assert np.array_equal(res[0], res[1])
     t.close()
