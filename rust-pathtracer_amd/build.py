@@ -6,8 +6,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpt_hip.so")
-SOURCES = ["rpt_hip.hip"]
-HEADERS = ["dev_math.h", "dev_bsdf.h", "dev_scene.h", "dev_integrator.h",
+SOURCES = ["kernels.hip", "capi.hip"]
+HEADERS = ["dev_math.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_large.h", "dev_integrator.h", "launch.h", "host_scene.h",
            os.path.join("..", "..", "include", "rpt.h"), os.path.join("..", "..", "include", "rpt_strict_math.h")]
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
 # fused operations are the explicit fma calls of rpt_strict_math.h.

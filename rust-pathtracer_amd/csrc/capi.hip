@@ -1,328 +1,27 @@
-// rpt_hip.hip — HIP kernels (gfx950) and the C ABI of include/rpt.h.
+// capi.hip — the C ABI of include/rpt.h: contexts, scene upload, launches.  Host code only; the kernels
+// and their launch wrappers are in kernels.hip (launch.h).
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared (see
-// build.py).  There is NO CPU fallback in this library: without a HIP device every
-// entry point that computes returns RPT_ERR_NO_DEVICE / RPT_ERR_HIP.
+// There is NO CPU fallback: without a gfx950 device every entry point that computes returns
+// RPT_ERR_NO_DEVICE / RPT_ERR_HIP.
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
-#include <algorithm>
-#include <cmath>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/rpt.h"
-#include "dev_integrator.h"
-#include "dev_scene_large.h"
+#include "host_scene.h"
+#include "launch.h"
 
 using namespace rptdev;
+using rpthost::HostGrid;
+using rpthost::build_grid;
+using rpthost::make_camera;
 
-// ---------------------------------------------------------------------------
-// cyclic row-block tiling (multi-GPU): block b of `tile_rows` rows -> rank b % world
-// ---------------------------------------------------------------------------
-__host__ __device__ static inline uint32_t tile_global_row(uint32_t local_row, uint32_t tile_rows, uint32_t rank, uint32_t world)
-{
-    uint32_t lb = local_row / tile_rows;
-    return (lb * world + rank) * tile_rows + (local_row % tile_rows);
-}
-
-static uint32_t tile_row_count(uint32_t height, uint32_t tile_rows, uint32_t rank, uint32_t world)
-{
-    if (tile_rows == 0 || world == 0 || rank >= world) return 0;
-    uint32_t nblocks = (height + tile_rows - 1) / tile_rows;        // last block may be short
-    uint32_t rows = 0;
-    for (uint32_t b = rank; b < nblocks; b += world) {
-        uint32_t start = b * tile_rows;
-        uint32_t n = (start + tile_rows <= height) ? tile_rows : (height - start);
-        rows += n;
-    }
-    return rows;
-}
-
-// ---------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------
-
-// Per-pixel setup shared by both render kernels: tracer.rs:34-46.
-struct PixelSetup {
-    bool valid;
-    uint32_t pixel_index;
-    float px, py;                     // coord of tracer.rs:46
-    size_t pix_offset;                // index of this pixel's float4 in the tile buffer
-};
-
-RPT_DEV PixelSetup pixel_setup(const RenderParams& rp)
-{
-    // A wave covers an 8x8 pixel block (coherent paths), a 256-thread workgroup 16x16.
-    PixelSetup ps;
-    // Bottom rows are dispatched first: in the usual outdoor framing they are the expensive
-    // ones (floor / objects), so the cheap sky tiles fill the tail of the launch (+3 %).
-    const uint32_t tile = gridDim.x - 1u - blockIdx.x;
-    const uint32_t tx = tile % rp.tiles_x;
-    const uint32_t ty = tile / rp.tiles_x;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t col = tx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t lrow = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
-    ps.valid = (col < rp.width) && (lrow < rp.rows_local);
-    const uint32_t grow = tile_global_row(lrow, rp.tile_rows, rp.rank, rp.world);
-    // j counts rows from the bottom (par_rchunks, tracer.rs:29-37)
-    const float W = (float)rp.width;
-    const float H = (float)rp.height;
-    const uint32_t j = rp.height - 1u - grow;
-    const float x = (float)col;
-    const float y = H - (float)j;
-    const float xx = x / W;
-    const float yy = y / H;
-    ps.px = xx;
-    ps.py = 1.0f - yy;
-    ps.pixel_index = grow * rp.width + col;
-    ps.pix_offset = (size_t)lrow * rp.width + col;
-    return ps;
-}
-
-// mix_color, tracer.rs:108-113, with color = [r, g, b, 1.0] (tracer.rs:59,105)
-RPT_DEV void blend(float4& acc, v3 rad, float v)
-{
-    acc.x = (1.0f - v) * acc.x + rad.x * v;
-    acc.y = (1.0f - v) * acc.y + rad.y * v;
-    acc.z = (1.0f - v) * acc.z + rad.z * v;
-    acc.w = (1.0f - v) * acc.w + 1.0f * v;
-}
-
-// Megakernel, one thread per pixel, `spp` samples per launch, nested-loop form
-// (sample loop outside, bounce loop inside; lanes whose path ended idle until the
-// wave's longest path ends).  Kept as the A/B baseline for the regenerating kernel.
-// The running mean of tracer.rs:105-117 is carried in registers across the launch's
-// samples and updated with the reference's own expression once per sample, so one
-// launch of S samples is bit-identical to S reference render() calls; the framebuffer
-// is read and written once per launch as float4 (16 B per lane, 128 B per 8-pixel row).
-template <class S>
-RPT_DEV void render_nested_body(const S& sc, const RenderParams& rp)
-{
-    const PixelSetup ps = pixel_setup(rp);
-    if (!ps.valid) return;
-    float4* pix = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
-    float4 acc = *pix;
-    for (uint32_t s = 0; s < rp.spp; ++s) {
-        const uint64_t frames = rp.frames_done + s;
-        const uint32_t fkey = frame_key_hd(rp.seed, frames);
-        const float v = 1.0f / (float)(frames + 1);                 // tracer.rs:115
-        const v3 rad = trace_sample(sc, ps.px, ps.py, fkey, ps.pixel_index);
-        blend(acc, rad, v);
-    }
-    *pix = acc;
-}
-
-__global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSmall sc, const RenderParams rp) { render_nested_body(sc, rp); }
-__global__ __launch_bounds__(256) void render_large_nested_kernel(const SceneLarge sc, const RenderParams rp) { render_nested_body(sc, rp); }
-__global__ __launch_bounds__(256) void render_sdf_nested_kernel(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(sc, rp); }
-
-// The production megakernel.  Same arithmetic per sample, different schedule:
-//  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
-//    PathRegs); when its path ends it blends the sample into its running mean and starts
-//    the next camera path at once (path regeneration);
-//  * a bounce is split into TRACE (closest hit + miss/emitter exits, cheap) and SHADE
-//    (next-event estimation + Disney BSDF sampling, ~3x the instructions).  A lane that
-//    hits a surface parks its SurfaceHit in registers and waits; the wave runs SHADE only
-//    when at least `shade_threshold` lanes are parked (wave ballot + popcount), or nobody
-//    is left to trace.  The expensive block therefore executes with most lanes active,
-//    while the cheap one absorbs the divergence.
-// The per-sample frame key and blend weight 1/(frames+1) are per-lane values now (lanes
-// drift apart in sample index), so the workgroup stages them once in LDS tables.
-constexpr uint32_t kMaxSppPerLaunch = 512;
-
-// Minimum waves per SIMD the register allocator must leave room for (2nd argument of
-// __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
-#ifndef RPT_WAVES_PER_SIMD
-#define RPT_WAVES_PER_SIMD 5
-#endif
-
-enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u };
-
-template <class S>
-RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
-{
-    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
-    __shared__ float s_weight[kMaxSppPerLaunch];
-    for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
-        const uint64_t frames = rp.frames_done + i;
-        s_fkey[i] = frame_key_hd(rp.seed, frames);
-        s_weight[i] = 1.0f / (float)(frames + 1);                   // tracer.rs:115
-    }
-    __syncthreads();
-
-    // Cold per-lane state lives in LDS, not in VGPRs: the pixel's running mean and its
-    // constants are touched only when a sample ends (once per ~2 bounces), and the seven
-    // registers they would pin are what separates 4 from 5 resident waves per SIMD.
-    __shared__ float4 s_acc[256];                                   // running mean, tracer.rs:105-117
-    __shared__ float4 s_pix[256];                                   // {coord.x, coord.y, bits(pixel_index), -}
-    __shared__ float4 s_hit[256];                                   // parked SurfaceHitCold {fhp, eta}
-    const uint32_t tid = threadIdx.x;
-    {
-        const PixelSetup ps = pixel_setup(rp);
-        if (!ps.valid) return;
-        s_acc[tid] = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
-        s_pix[tid] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
-    }
-
-    if (sc.max_depth == 0) {                                        // no bounce loop at all: radiance is zero
-        float4 acc = s_acc[tid];
-        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), s_weight[s]);
-        *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = acc;
-        return;
-    }
-
-    uint32_t s = 0;
-    uint32_t state = ST_TRACE;
-    PathRegs p;
-    SurfaceHit sh;
-    {
-        const float4 c = s_pix[tid];
-        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
-    }
-
-    // blend the finished sample into the running mean and start the next one (or retire)
-    auto finish_sample = [&]() {
-        float4 acc = s_acc[tid];
-        blend(acc, p.radiance, s_weight[s]);
-        s_acc[tid] = acc;
-        s += 1;
-        if (s >= rp.spp) {
-            state = ST_DONE;
-        } else {
-            const float4 c = s_pix[tid];
-            path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
-            state = ST_TRACE;
-        }
-    };
-
-    for (;;) {
-        if (state == ST_TRACE) {
-            SurfaceHitCold shc;
-            if (path_trace(sc, p, sh, shc)) {
-                s_hit[tid] = make_float4(shc.fhp.x, shc.fhp.y, shc.fhp.z, shc.eta);
-                state = ST_SHADE;
-            } else {
-                finish_sample();
-            }
-        }
-        const uint64_t m_shade = __ballot(state == ST_SHADE);
-        const uint64_t m_trace = __ballot(state == ST_TRACE);
-        if ((m_shade | m_trace) == 0ull) break;
-        if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_trace == 0ull) {
-            if (state == ST_SHADE) {
-                state = ST_TRACE;
-                if (path_shade(sc, p, sh, &s_hit[tid])) finish_sample();
-            }
-        }
-    }
-    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
-}
-
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_kernel(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
-// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_large_regen_kernel(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
-// Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_sdf_regen_kernel(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
-
-// Scatter rank-major gathered tiles into the full image (one float4 per thread).
-__global__ __launch_bounds__(256) void untile_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
-                                                     uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
-                                                     uint32_t rows_padded)
-{
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t total = (uint64_t)width * height;
-    if (idx >= total) return;
-    const uint32_t grow = (uint32_t)(idx / width);
-    const uint32_t col = (uint32_t)(idx % width);
-    const uint32_t gb = grow / tile_rows;
-    const uint32_t rank = gb % world;
-    const uint32_t lrow = (gb / world) * tile_rows + (grow % tile_rows);
-    image[idx] = gathered[((uint64_t)rank * rows_padded + lrow) * width + col];
-}
-
-// Rust `as u8`: saturating, NaN -> 0, truncation toward zero.
-RPT_DEV uint32_t as_u8(float x)
-{
-    if (!(x == x)) return 0u;
-    if (x <= 0.0f) return 0u;
-    if (x >= 255.0f) return 255u;
-    return (uint32_t)x;
-}
-
-// ColorBuffer::convert_to_u8, buffer.rs:55-64
-__global__ __launch_bounds__(256) void convert_to_u8_kernel(const float4* __restrict__ pixels, uint32_t* __restrict__ out, uint64_t n)
-{
-    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n) return;
-    const float4 p = pixels[idx];
-    const uint32_t r = as_u8(rpt_powf(p.x, 0.4545f) * 255.0f);
-    const uint32_t g = as_u8(rpt_powf(p.y, 0.4545f) * 255.0f);
-    const uint32_t b = as_u8(rpt_powf(p.z, 0.4545f) * 255.0f);
-    const uint32_t a = as_u8(p.w * 255.0f);
-    out[idx] = r | (g << 8) | (b << 16) | (a << 24);
-}
-
-__global__ __launch_bounds__(256) void probe_math_kernel(uint32_t fn, const float* __restrict__ a, const float* __restrict__ b,
-                                                         float* __restrict__ out, uint64_t n)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float r = 0.0f;
-    switch (fn) {
-    case RPT_PROBE_SIN: r = rpt_sinf(a[i]); break;
-    case RPT_PROBE_COS: r = rpt_cosf(a[i]); break;
-    case RPT_PROBE_LOG2: r = rpt_log2f(a[i]); break;
-    case RPT_PROBE_POW: r = rpt_powf(a[i], b[i]); break;
-    case RPT_PROBE_DIV: r = a[i] / b[i]; break;
-    case RPT_PROBE_SQRT: r = __builtin_sqrtf(a[i]); break;
-    case RPT_PROBE_RNG: {                                            // a = seed bits, b = frame bits, i = pixel; first draw
-        Rng rng;
-        rng.init(frame_key_hd((uint64_t)rpt_f2u(a[i]), (uint64_t)rpt_f2u(b[i])), (uint32_t)i);
-        r = rng.gen();
-        break;
-    }
-    default: break;
-    }
-    out[i] = r;
-}
-
-__global__ __launch_bounds__(256) void probe_rays_kernel(const SceneLarge sc, const float* __restrict__ rays, uint32_t* __restrict__ out, uint64_t n)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* r = rays + i * 7;
-    RayD ray{mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])};
-    float dist = 3.40282347e+38f;
-    uint32_t best = 0xFFFFFFFFu;
-    bool hit = false;
-    bool any;
-    if (sc.use_grid) {
-        grid_closest_sphere(sc, ray, dist, best, hit);
-        any = grid_any_sphere(sc, ray, true, r[6]);
-    } else {
-        any = false;
-        for (uint32_t k = 0; k < sc.n_spheres; ++k) {
-            const float4 s = sphere_uniform(sc, k);
-            float t;
-            bool h = hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t);
-            if (h && (k == 0 || t < dist)) { dist = t; best = k; hit = true; }
-            any = any || (h && t < r[6]);
-        }
-    }
-    out[i * 3 + 0] = rpt_f2u(dist);
-    out[i * 3 + 1] = best;
-    out[i * 3 + 2] = any ? 1u : 0u;
-}
-
-// ---------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------
 struct rpt_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -359,121 +58,21 @@ static void set_err(rpt_ctx* ctx, const char* fmt, ...)
         }                                                                                         \
     } while (0)
 
-// Frame-invariant part of Pinhole::gen_ray (camera/pinhole.rs:38-54), evaluated on the
-// host with the reference's f32 operation order (this file is compiled with
-// -ffp-contract=off) and the strict tan.
-static DevCamera make_camera(const rpt_camera& c, float width, float height)
-{
-    struct h3 { float x, y, z; };
-    auto sub = [](h3 a, h3 b) { return h3{a.x - b.x, a.y - b.y, a.z - b.z}; };
-    auto mulf = [](h3 a, float f) { return h3{a.x * f, a.y * f, a.z * f}; };
-    auto cross = [](h3 a, h3 b) { return h3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
-
-    const float ratio = width / height;
-    const float half_width = rpt_tanf((c.fov_deg * (3.14159265358979323846f / 180.0f)) * 0.5f);   // f32::to_radians
-    const float half_height = half_width / ratio;
-    const h3 origin{c.origin[0], c.origin[1], c.origin[2]};
-    const h3 center{c.center[0], c.center[1], c.center[2]};
-    const h3 up{0.0f, 1.0f, 0.0f};
-    h3 w = sub(origin, center);
-    const float wl = __builtin_sqrtf(w.x * w.x + w.y * w.y + w.z * w.z);
-    w = h3{w.x / wl, w.y / wl, w.z / wl};
-    const h3 u = cross(up, w);
-    const h3 v = cross(w, u);
-    const h3 lower_left = sub(sub(sub(origin, mulf(u, half_width)), mulf(v, half_height)), w);
-    const h3 horizontal = mulf(u, half_width * 2.0f);
-    const h3 vertical = mulf(v, half_height * 2.0f);
-    const h3 rd = sub(lower_left, origin);
-
-    DevCamera d;
-    d.ox = origin.x; d.oy = origin.y; d.oz = origin.z;
-    d.rdx = rd.x; d.rdy = rd.y; d.rdz = rd.z;
-    d.hx = horizontal.x; d.hy = horizontal.y; d.hz = horizontal.z;
-    d.vx = vertical.x; d.vy = vertical.y; d.vz = vertical.z;
-    d.psx = 1.0f / width;
-    d.psy = 1.0f / height;
-    return d;
-}
-
-// Uniform grid over the spheres of a large scene (dev_scene_large.h).  Cell size targets ~2 spheres
-// per cell.  Every sphere is listed in each cell its PADDED bounding box overlaps; the padding is the
-// distance outside the sphere at which the reference's f32 ray/sphere test (d2 = l.l - tca^2 <= r^2,
-// absolute error ~4e-7 |l|^2) can still report a hit, for ray origins within `safe_r` of the grid
-// centre, doubled for safety, plus 1e-3 cell sizes for the DDA's own rounding.
-struct HostGrid {
-    uint32_t n[3];
-    float gmin[3], gmax[3], cs[3], inv_cs[3];
-    float center[3], safe_r2;
-    std::vector<uint32_t> cell_start, items;
+// Every entry point runs on its context's device and puts the caller's current device back afterwards
+// (the caller may be a torch process with its own idea of the current device).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t status;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        status = (prev == device) ? hipSuccess : hipSetDevice(device);
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
-
-static HostGrid build_grid(const rpt_sphere* sph, uint32_t count)
-{
-    HostGrid g;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (uint32_t i = 0; i < count; ++i)
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], (double)sph[i].center[a] - sph[i].radius);
-            hi[a] = std::max(hi[a], (double)sph[i].center[a] + sph[i].radius);
-        }
-    double ext[3], vol = 1.0;
-    for (int a = 0; a < 3; ++a) {
-        double pad = 1e-3 * (hi[a] - lo[a]) + 1e-3;
-        lo[a] -= pad; hi[a] += pad;
-        ext[a] = hi[a] - lo[a];
-        vol *= ext[a];
-    }
-    const double target = std::cbrt(vol / (count / 2.0 + 1.0));       // cell edge for ~2 spheres per cell
-    for (int a = 0; a < 3; ++a) {
-        double n = std::ceil(ext[a] / target);
-        n = n < 1 ? 1 : (n > 128 ? 128 : n);
-        g.n[a] = (uint32_t)n;
-        g.gmin[a] = (float)lo[a];
-        g.cs[a] = (float)(ext[a] / n);
-        g.inv_cs[a] = 1.0f / g.cs[a];
-        g.gmax[a] = g.gmin[a] + (float)g.n[a] * g.cs[a];
-    }
-    const size_t ncell = (size_t)g.n[0] * g.n[1] * g.n[2];
-    double half_diag = 0.0;
-    for (int a = 0; a < 3; ++a) {
-        g.center[a] = (float)(0.5 * (lo[a] + hi[a]));
-        half_diag += 0.25 * ext[a] * ext[a];
-    }
-    half_diag = std::sqrt(half_diag);
-    const double safe_r = 6.0 * half_diag;
-    g.safe_r2 = (float)(safe_r * safe_r);
-    const double max_l = safe_r + half_diag;                        // |sphere centre - ray origin| for usable rays
-    const double d2_err = 1.2e-6 * max_l * max_l;                   // bound on the f32 error of l.l - tca*tca
-    auto range = [&](const rpt_sphere& s, int a, int& c0, int& c1) {
-        const double r = s.radius;
-        const double pad = (std::sqrt(r * r + d2_err) - r) + 1e-3 * g.cs[a];
-        c0 = (int)std::floor(((double)s.center[a] - s.radius - pad - g.gmin[a]) / g.cs[a]);
-        c1 = (int)std::floor(((double)s.center[a] + s.radius + pad - g.gmin[a]) / g.cs[a]);
-        c0 = std::max(0, std::min((int)g.n[a] - 1, c0));
-        c1 = std::max(0, std::min((int)g.n[a] - 1, c1));
-    };
-    g.cell_start.assign(ncell + 1, 0);
-    for (int pass = 0; pass < 2; ++pass) {
-        std::vector<uint32_t> cursor;
-        if (pass == 1) {
-            for (size_t c = 0; c < ncell; ++c) g.cell_start[c + 1] += g.cell_start[c];      // counts -> exclusive prefix sums
-            cursor.assign(g.cell_start.begin(), g.cell_start.end() - 1);
-            g.items.assign(g.cell_start[ncell], 0);
-        }
-        for (uint32_t i = 0; i < count; ++i) {                                               // ascending sphere index within a cell
-            int x0, x1, y0, y1, z0, z1;
-            range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
-            for (int z = z0; z <= z1; ++z)
-                for (int y = y0; y <= y1; ++y)
-                    for (int x = x0; x <= x1; ++x) {
-                        const size_t c = ((size_t)z * g.n[1] + y) * g.n[0] + x;
-                        if (pass == 0) g.cell_start[c + 1] += 1;
-                        else g.items[cursor[c]++] = i;
-                    }
-        }
-    }
-    return g;
-}
+#define RPT_ON_DEVICE(ctx)                 \
+    DeviceGuard guard_((ctx)->device);     \
+    RPT_HIP_CHECK(ctx, guard_.status)
 
 // Lanes that must be parked on a surface hit before a wave runs its shading block (1..64).
 // RPT_SHADE_THRESHOLD overrides the default for tuning runs.
@@ -571,10 +170,13 @@ int rpt_create(rpt_ctx** out, int device_id)
     rpt_ctx* ctx = new (std::nothrow) rpt_ctx();
     if (!ctx) return RPT_ERR_HIP;
     ctx->device = device_id;
-    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-        set_err(nullptr, "rpt_create: cannot create a stream on device %d", device_id);
-        delete ctx;
-        return RPT_ERR_HIP;
+    {
+        DeviceGuard guard(device_id);
+        if (guard.status != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            set_err(nullptr, "rpt_create: cannot create a stream on device %d", device_id);
+            delete ctx;
+            return RPT_ERR_HIP;
+        }
     }
     *out = ctx;
     return RPT_OK;
@@ -583,7 +185,7 @@ int rpt_create(rpt_ctx** out, int device_id)
 void rpt_destroy(rpt_ctx* ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx->device);
     if (ctx->fb) (void)hipFree(ctx->fb);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -643,7 +245,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
                 return RPT_ERR_UNSUPPORTED;
             }
         }
-        RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+        RPT_ON_DEVICE(ctx);
         const size_t sz_sph = sizeof(float4) * s->n_spheres;
         const size_t sz_smat = (sizeof(uint32_t) * s->n_spheres + 15) & ~(size_t)15;
         const size_t sz_lights = (sizeof(DevLight) * (s->n_lights ? s->n_lights : 1) + 15) & ~(size_t)15;
@@ -772,20 +374,16 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     if (spp == 0) return RPT_OK;
     if (world == 1) tile_rows = height;                              // one block: local row == global row
 
-    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RPT_ON_DEVICE(ctx);
     SceneSmallSdf scs = ctx->scene;
     SceneLarge scl = ctx->scene_large;
     scs.cam = scl.cam = make_camera(ctx->camera, (float)width, (float)height);
-    const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
-    const bool has_sdf = !ctx->large && scs.sdf.n_prims > 0;
 
     RenderParams rp;
     rp.pixels = pixels_dev;
     rp.width = width; rp.height = height;
     rp.rows_local = tile_row_count(height, tile_rows, rank, world);
     rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
-    rp.spp = spp;
-    rp.frames_done = frames_done;
     rp.seed = seed;
     rp.tiles_x = (width + 15u) / 16u;
     rp.shade_threshold = shade_threshold();
@@ -794,21 +392,14 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;
     if (nblocks > 0x7FFFFFFFull) { set_err(ctx, "rpt_render_device: grid too large"); return RPT_ERR_INVALID_ARG; }
 
-    hipStream_t st = (hipStream_t)stream;
-    // The LDS tables of the regenerating kernel hold kMaxSppPerLaunch samples: larger
-    // batches are split into consecutive launches (the running mean carries over).
+    // The LDS tables of the regenerating kernel hold a bounded number of samples: larger batches are
+    // split into consecutive launches (the running mean carries over in the framebuffer).
+    const uint32_t max_chunk = rptlaunch::max_spp_per_launch();
     for (uint32_t done = 0; done < spp;) {
-        const uint32_t chunk = (spp - done > kMaxSppPerLaunch) ? kMaxSppPerLaunch : (spp - done);
+        const uint32_t chunk = (spp - done > max_chunk) ? max_chunk : (spp - done);
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
-        const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
-        if (ctx->large && nested) hipLaunchKernelGGL(render_large_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scl, rp);
-        else if (ctx->large) hipLaunchKernelGGL(render_large_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scl, rp);
-        else if (has_sdf && nested) hipLaunchKernelGGL(render_sdf_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scs, rp);
-        else if (has_sdf) hipLaunchKernelGGL(render_sdf_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, scs, rp);
-        else if (nested) hipLaunchKernelGGL(render_small_nested_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
-        else hipLaunchKernelGGL(render_small_regen_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, sc, rp);
-        RPT_HIP_CHECK(ctx, hipGetLastError());
+        RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, (flags & RPT_RENDER_NESTED_LOOPS) != 0, rp, (uint32_t)nblocks, (hipStream_t)stream));
         done += chunk;
     }
     return RPT_OK;
@@ -820,7 +411,7 @@ int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height, uin
     if (!ctx) { set_err(nullptr, "rpt_render: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (!pixels || width == 0 || height == 0) { set_err(ctx, "rpt_render: invalid argument"); return RPT_ERR_INVALID_ARG; }
     if (!ctx->has_scene) { set_err(ctx, "rpt_render: no scene uploaded"); return RPT_ERR_NO_SCENE; }
-    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RPT_ON_DEVICE(ctx);
     const size_t bytes = (size_t)width * height * 4 * sizeof(float);
     if (bytes > ctx->fb_bytes) {
         if (ctx->fb) { RPT_HIP_CHECK(ctx, hipFree(ctx->fb)); ctx->fb = nullptr; ctx->fb_bytes = 0; }
@@ -842,13 +433,8 @@ int rpt_untile_device(rpt_ctx* ctx, const float* gathered_dev, float* image_dev,
     if (!gathered_dev || !image_dev || width == 0 || height == 0 || tile_rows == 0 || world == 0) { set_err(ctx, "rpt_untile_device: invalid argument"); return RPT_ERR_INVALID_ARG; }
     for (uint32_t r = 0; r < world; ++r)
         if (tile_row_count(height, tile_rows, r, world) > rows_padded) { set_err(ctx, "rpt_untile_device: rows_padded %u too small", rows_padded); return RPT_ERR_INVALID_ARG; }
-    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint64_t total = (uint64_t)width * height;
-    const uint64_t nblocks = (total + 255) / 256;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, (const float4*)gathered_dev, (float4*)image_dev, width,
-                       height, tile_rows, world, rows_padded);
-    RPT_HIP_CHECK(ctx, hipGetLastError());
+    RPT_ON_DEVICE(ctx);
+    RPT_HIP_CHECK(ctx, rptlaunch::untile(gathered_dev, image_dev, width, height, tile_rows, world, rows_padded, (hipStream_t)stream));
     return RPT_OK;
 }
 
@@ -856,12 +442,8 @@ int rpt_convert_to_u8_device(rpt_ctx* ctx, const float* pixels_dev, uint8_t* out
 {
     if (!ctx) { set_err(nullptr, "rpt_convert_to_u8_device: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (!pixels_dev || !out_dev || width == 0 || height == 0) { set_err(ctx, "rpt_convert_to_u8_device: invalid argument"); return RPT_ERR_INVALID_ARG; }
-    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint64_t total = (uint64_t)width * height;
-    const uint64_t nblocks = (total + 255) / 256;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(convert_to_u8_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, (const float4*)pixels_dev, (uint32_t*)out_dev, total);
-    RPT_HIP_CHECK(ctx, hipGetLastError());
+    RPT_ON_DEVICE(ctx);
+    RPT_HIP_CHECK(ctx, rptlaunch::convert_to_u8(pixels_dev, out_dev, (uint64_t)width * height, (hipStream_t)stream));
     return RPT_OK;
 }
 
@@ -869,7 +451,7 @@ int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_
 {
     if (!ctx) { set_err(nullptr, "rpt_convert_to_u8: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (!pixels || !frame || width == 0 || height == 0) { set_err(ctx, "rpt_convert_to_u8: invalid argument"); return RPT_ERR_INVALID_ARG; }
-    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RPT_ON_DEVICE(ctx);
     const size_t n = (size_t)width * height;
     const size_t bytes = n * 16 + n * 4;                              // f32 RGBA in, u8 RGBA out, one allocation
     if (bytes > ctx->fb_bytes) {
@@ -889,7 +471,7 @@ int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_
 int rpt_synchronize(rpt_ctx* ctx, void* stream)
 {
     if (!ctx) { set_err(nullptr, "rpt_synchronize: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
-    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
     return RPT_OK;
 }
@@ -900,12 +482,10 @@ int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint6
     if (!ctx->has_scene || !ctx->large) { set_err(ctx, "rpt_probe_rays: needs an uploaded large scene"); return RPT_ERR_NO_SCENE; }
     if (!rays_dev || !out_dev) { set_err(ctx, "rpt_probe_rays: invalid argument"); return RPT_ERR_INVALID_ARG; }
     if (n == 0) return RPT_OK;
-    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    RPT_ON_DEVICE(ctx);
     SceneLarge sc = ctx->scene_large;
     if (!use_grid) sc.use_grid = 0;
-    const uint64_t nblocks = (n + 255) / 256;
-    hipLaunchKernelGGL(probe_rays_kernel, dim3((uint32_t)nblocks), dim3(256), 0, (hipStream_t)stream, sc, rays_dev, out_dev, n);
-    RPT_HIP_CHECK(ctx, hipGetLastError());
+    RPT_HIP_CHECK(ctx, rptlaunch::probe_rays(sc, rays_dev, out_dev, n, (hipStream_t)stream));
     return RPT_OK;
 }
 
@@ -914,11 +494,8 @@ int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b
     if (!ctx) { set_err(nullptr, "rpt_probe_math: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (!a_dev || !b_dev || !out_dev || fn > RPT_PROBE_RNG) { set_err(ctx, "rpt_probe_math: invalid argument"); return RPT_ERR_INVALID_ARG; }
     if (n == 0) return RPT_OK;
-    RPT_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    const uint64_t nblocks = (n + 255) / 256;
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(probe_math_kernel, dim3((uint32_t)nblocks), dim3(256), 0, st, fn, a_dev, b_dev, out_dev, n);
-    RPT_HIP_CHECK(ctx, hipGetLastError());
+    RPT_ON_DEVICE(ctx);
+    RPT_HIP_CHECK(ctx, rptlaunch::probe_math(fn, a_dev, b_dev, out_dev, n, (hipStream_t)stream));
     return RPT_OK;
 }
 

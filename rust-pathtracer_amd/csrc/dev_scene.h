@@ -51,7 +51,7 @@ struct DevMaterial {
 // Pinhole::gen_ray (camera/pinhole.rs:38-60) split at its frame-invariant part:
 // everything up to `rd = lower_left - origin` depends only on the camera and the
 // image size, so the host evaluates it once per launch with the same f32
-// operation order and strict tan (rpt_hip.hip, make_camera).
+// operation order and strict tan (host_scene.h, make_camera).
 struct DevCamera {
     float ox, oy, oz;          // origin
     float rdx, rdy, rdz;       // lower_left - origin

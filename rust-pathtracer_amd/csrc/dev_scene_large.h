@@ -34,7 +34,7 @@ struct SceneLarge {
     const DevLight* lights;
     const DevMaterial* materials;
     DevPlane planes[kMaxPlanes];
-    // Uniform grid over the spheres (built on the host at upload, rpt_hip.hip build_grid):
+    // Uniform grid over the spheres (built on the host at upload, host_scene.h build_grid):
     // cell (ix,iy,iz) -> items[cell_start[c] .. cell_start[c+1]) = indices of the spheres whose
     // padded bounding box overlaps the cell, ascending.  use_grid == 0: brute-force streaming.
     uint32_t use_grid;

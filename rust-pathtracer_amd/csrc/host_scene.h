@@ -1,0 +1,134 @@
+// host_scene.h — host-side preparation of the scene tables: the frame-invariant camera basis and the
+// uniform grid of large scenes.  Plain C++ (compiled with -ffp-contract=off like everything else).
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/rpt.h"
+#include "../../include/rpt_strict_math.h"
+#include "dev_scene.h"
+
+namespace rpthost {
+
+using rptdev::DevCamera;
+
+// Frame-invariant part of Pinhole::gen_ray (camera/pinhole.rs:38-54), evaluated on the
+// host with the reference's f32 operation order (this file is compiled with
+// -ffp-contract=off) and the strict tan.
+inline DevCamera make_camera(const rpt_camera& c, float width, float height)
+{
+    struct h3 { float x, y, z; };
+    auto sub = [](h3 a, h3 b) { return h3{a.x - b.x, a.y - b.y, a.z - b.z}; };
+    auto mulf = [](h3 a, float f) { return h3{a.x * f, a.y * f, a.z * f}; };
+    auto cross = [](h3 a, h3 b) { return h3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+
+    const float ratio = width / height;
+    const float half_width = rpt_tanf((c.fov_deg * (3.14159265358979323846f / 180.0f)) * 0.5f);   // f32::to_radians
+    const float half_height = half_width / ratio;
+    const h3 origin{c.origin[0], c.origin[1], c.origin[2]};
+    const h3 center{c.center[0], c.center[1], c.center[2]};
+    const h3 up{0.0f, 1.0f, 0.0f};
+    h3 w = sub(origin, center);
+    const float wl = __builtin_sqrtf(w.x * w.x + w.y * w.y + w.z * w.z);
+    w = h3{w.x / wl, w.y / wl, w.z / wl};
+    const h3 u = cross(up, w);
+    const h3 v = cross(w, u);
+    const h3 lower_left = sub(sub(sub(origin, mulf(u, half_width)), mulf(v, half_height)), w);
+    const h3 horizontal = mulf(u, half_width * 2.0f);
+    const h3 vertical = mulf(v, half_height * 2.0f);
+    const h3 rd = sub(lower_left, origin);
+
+    DevCamera d;
+    d.ox = origin.x; d.oy = origin.y; d.oz = origin.z;
+    d.rdx = rd.x; d.rdy = rd.y; d.rdz = rd.z;
+    d.hx = horizontal.x; d.hy = horizontal.y; d.hz = horizontal.z;
+    d.vx = vertical.x; d.vy = vertical.y; d.vz = vertical.z;
+    d.psx = 1.0f / width;
+    d.psy = 1.0f / height;
+    return d;
+}
+
+// Uniform grid over the spheres of a large scene (dev_scene_large.h).  Cell size targets ~2 spheres
+// per cell.  Every sphere is listed in each cell its PADDED bounding box overlaps; the padding is the
+// distance outside the sphere at which the reference's f32 ray/sphere test (d2 = l.l - tca^2 <= r^2,
+// absolute error ~4e-7 |l|^2) can still report a hit, for ray origins within `safe_r` of the grid
+// centre, doubled for safety, plus 1e-3 cell sizes for the DDA's own rounding.
+struct HostGrid {
+    uint32_t n[3];
+    float gmin[3], gmax[3], cs[3], inv_cs[3];
+    float center[3], safe_r2;
+    std::vector<uint32_t> cell_start, items;
+};
+
+inline HostGrid build_grid(const rpt_sphere* sph, uint32_t count)
+{
+    HostGrid g;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (uint32_t i = 0; i < count; ++i)
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], (double)sph[i].center[a] - sph[i].radius);
+            hi[a] = std::max(hi[a], (double)sph[i].center[a] + sph[i].radius);
+        }
+    double ext[3], vol = 1.0;
+    for (int a = 0; a < 3; ++a) {
+        double pad = 1e-3 * (hi[a] - lo[a]) + 1e-3;
+        lo[a] -= pad; hi[a] += pad;
+        ext[a] = hi[a] - lo[a];
+        vol *= ext[a];
+    }
+    const double target = std::cbrt(vol / (count / 2.0 + 1.0));       // cell edge for ~2 spheres per cell
+    for (int a = 0; a < 3; ++a) {
+        double n = std::ceil(ext[a] / target);
+        n = n < 1 ? 1 : (n > 128 ? 128 : n);
+        g.n[a] = (uint32_t)n;
+        g.gmin[a] = (float)lo[a];
+        g.cs[a] = (float)(ext[a] / n);
+        g.inv_cs[a] = 1.0f / g.cs[a];
+        g.gmax[a] = g.gmin[a] + (float)g.n[a] * g.cs[a];
+    }
+    const size_t ncell = (size_t)g.n[0] * g.n[1] * g.n[2];
+    double half_diag = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        g.center[a] = (float)(0.5 * (lo[a] + hi[a]));
+        half_diag += 0.25 * ext[a] * ext[a];
+    }
+    half_diag = std::sqrt(half_diag);
+    const double safe_r = 6.0 * half_diag;
+    g.safe_r2 = (float)(safe_r * safe_r);
+    const double max_l = safe_r + half_diag;                        // |sphere centre - ray origin| for usable rays
+    const double d2_err = 1.2e-6 * max_l * max_l;                   // bound on the f32 error of l.l - tca*tca
+    auto range = [&](const rpt_sphere& s, int a, int& c0, int& c1) {
+        const double r = s.radius;
+        const double pad = (std::sqrt(r * r + d2_err) - r) + 1e-3 * g.cs[a];
+        c0 = (int)std::floor(((double)s.center[a] - s.radius - pad - g.gmin[a]) / g.cs[a]);
+        c1 = (int)std::floor(((double)s.center[a] + s.radius + pad - g.gmin[a]) / g.cs[a]);
+        c0 = std::max(0, std::min((int)g.n[a] - 1, c0));
+        c1 = std::max(0, std::min((int)g.n[a] - 1, c1));
+    };
+    g.cell_start.assign(ncell + 1, 0);
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<uint32_t> cursor;
+        if (pass == 1) {
+            for (size_t c = 0; c < ncell; ++c) g.cell_start[c + 1] += g.cell_start[c];      // counts -> exclusive prefix sums
+            cursor.assign(g.cell_start.begin(), g.cell_start.end() - 1);
+            g.items.assign(g.cell_start[ncell], 0);
+        }
+        for (uint32_t i = 0; i < count; ++i) {                                               // ascending sphere index within a cell
+            int x0, x1, y0, y1, z0, z1;
+            range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) {
+                        const size_t c = ((size_t)z * g.n[1] + y) * g.n[0] + x;
+                        if (pass == 0) g.cell_start[c + 1] += 1;
+                        else g.items[cursor[c]++] = i;
+                    }
+        }
+    }
+    return g;
+}
+
+}  // namespace rpthost

@@ -1,0 +1,340 @@
+// kernels.hip — every __global__ kernel of the library (gfx950) and the host-side launch wrappers
+// declared in launch.h.  The C ABI lives in capi.hip.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-licm
+// (build.py).  There is NO CPU fallback anywhere in this library.
+#include <hip/hip_runtime.h>
+
+#include "../../include/rpt.h"
+#include "dev_integrator.h"
+#include "dev_scene_large.h"
+#include "launch.h"
+
+using namespace rptdev;
+
+
+// ---------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------
+
+// Per-pixel setup shared by both render kernels: tracer.rs:34-46.
+struct PixelSetup {
+    bool valid;
+    uint32_t pixel_index;
+    float px, py;                     // coord of tracer.rs:46
+    size_t pix_offset;                // index of this pixel's float4 in the tile buffer
+};
+
+RPT_DEV PixelSetup pixel_setup(const RenderParams& rp)
+{
+    // A wave covers an 8x8 pixel block (coherent paths), a 256-thread workgroup 16x16.
+    PixelSetup ps;
+    // Bottom rows are dispatched first: in the usual outdoor framing they are the expensive
+    // ones (floor / objects), so the cheap sky tiles fill the tail of the launch (+3 %).
+    const uint32_t tile = gridDim.x - 1u - blockIdx.x;
+    const uint32_t tx = tile % rp.tiles_x;
+    const uint32_t ty = tile / rp.tiles_x;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t col = tx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t lrow = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
+    ps.valid = (col < rp.width) && (lrow < rp.rows_local);
+    const uint32_t grow = tile_global_row(lrow, rp.tile_rows, rp.rank, rp.world);
+    // j counts rows from the bottom (par_rchunks, tracer.rs:29-37)
+    const float W = (float)rp.width;
+    const float H = (float)rp.height;
+    const uint32_t j = rp.height - 1u - grow;
+    const float x = (float)col;
+    const float y = H - (float)j;
+    const float xx = x / W;
+    const float yy = y / H;
+    ps.px = xx;
+    ps.py = 1.0f - yy;
+    ps.pixel_index = grow * rp.width + col;
+    ps.pix_offset = (size_t)lrow * rp.width + col;
+    return ps;
+}
+
+// mix_color, tracer.rs:108-113, with color = [r, g, b, 1.0] (tracer.rs:59,105)
+RPT_DEV void blend(float4& acc, v3 rad, float v)
+{
+    acc.x = (1.0f - v) * acc.x + rad.x * v;
+    acc.y = (1.0f - v) * acc.y + rad.y * v;
+    acc.z = (1.0f - v) * acc.z + rad.z * v;
+    acc.w = (1.0f - v) * acc.w + 1.0f * v;
+}
+
+// Megakernel, one thread per pixel, `spp` samples per launch, nested-loop form
+// (sample loop outside, bounce loop inside; lanes whose path ended idle until the
+// wave's longest path ends).  Kept as the A/B baseline for the regenerating kernel.
+// The running mean of tracer.rs:105-117 is carried in registers across the launch's
+// samples and updated with the reference's own expression once per sample, so one
+// launch of S samples is bit-identical to S reference render() calls; the framebuffer
+// is read and written once per launch as float4 (16 B per lane, 128 B per 8-pixel row).
+template <class S>
+RPT_DEV void render_nested_body(const S& sc, const RenderParams& rp)
+{
+    const PixelSetup ps = pixel_setup(rp);
+    if (!ps.valid) return;
+    float4* pix = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
+    float4 acc = *pix;
+    for (uint32_t s = 0; s < rp.spp; ++s) {
+        const uint64_t frames = rp.frames_done + s;
+        const uint32_t fkey = frame_key_hd(rp.seed, frames);
+        const float v = 1.0f / (float)(frames + 1);                 // tracer.rs:115
+        const v3 rad = trace_sample(sc, ps.px, ps.py, fkey, ps.pixel_index);
+        blend(acc, rad, v);
+    }
+    *pix = acc;
+}
+
+__global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSmall sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void render_large_nested_kernel(const SceneLarge sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void render_sdf_nested_kernel(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(sc, rp); }
+
+// The production megakernel.  Same arithmetic per sample, different schedule:
+//  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
+//    PathRegs); when its path ends it blends the sample into its running mean and starts
+//    the next camera path at once (path regeneration);
+//  * a bounce is split into TRACE (closest hit + miss/emitter exits, cheap) and SHADE
+//    (next-event estimation + Disney BSDF sampling, ~3x the instructions).  A lane that
+//    hits a surface parks its SurfaceHit in registers and waits; the wave runs SHADE only
+//    when at least `shade_threshold` lanes are parked (wave ballot + popcount), or nobody
+//    is left to trace.  The expensive block therefore executes with most lanes active,
+//    while the cheap one absorbs the divergence.
+// The per-sample frame key and blend weight 1/(frames+1) are per-lane values now (lanes
+// drift apart in sample index), so the workgroup stages them once in LDS tables.
+constexpr uint32_t kMaxSppPerLaunch = 512;
+
+// Minimum waves per SIMD the register allocator must leave room for (2nd argument of
+// __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
+#ifndef RPT_WAVES_PER_SIMD
+#define RPT_WAVES_PER_SIMD 5
+#endif
+
+enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u };
+
+template <class S>
+RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
+{
+    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
+    __shared__ float s_weight[kMaxSppPerLaunch];
+    for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
+        const uint64_t frames = rp.frames_done + i;
+        s_fkey[i] = frame_key_hd(rp.seed, frames);
+        s_weight[i] = 1.0f / (float)(frames + 1);                   // tracer.rs:115
+    }
+    __syncthreads();
+
+    // Cold per-lane state lives in LDS, not in VGPRs: the pixel's running mean and its
+    // constants are touched only when a sample ends (once per ~2 bounces), and the seven
+    // registers they would pin are what separates 4 from 5 resident waves per SIMD.
+    __shared__ float4 s_acc[256];                                   // running mean, tracer.rs:105-117
+    __shared__ float4 s_pix[256];                                   // {coord.x, coord.y, bits(pixel_index), -}
+    __shared__ float4 s_hit[256];                                   // parked SurfaceHitCold {fhp, eta}
+    const uint32_t tid = threadIdx.x;
+    {
+        const PixelSetup ps = pixel_setup(rp);
+        if (!ps.valid) return;
+        s_acc[tid] = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
+        s_pix[tid] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
+    }
+
+    if (sc.max_depth == 0) {                                        // no bounce loop at all: radiance is zero
+        float4 acc = s_acc[tid];
+        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), s_weight[s]);
+        *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = acc;
+        return;
+    }
+
+    uint32_t s = 0;
+    uint32_t state = ST_TRACE;
+    PathRegs p;
+    SurfaceHit sh;
+    {
+        const float4 c = s_pix[tid];
+        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+    }
+
+    // blend the finished sample into the running mean and start the next one (or retire)
+    auto finish_sample = [&]() {
+        float4 acc = s_acc[tid];
+        blend(acc, p.radiance, s_weight[s]);
+        s_acc[tid] = acc;
+        s += 1;
+        if (s >= rp.spp) {
+            state = ST_DONE;
+        } else {
+            const float4 c = s_pix[tid];
+            path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+            state = ST_TRACE;
+        }
+    };
+
+    for (;;) {
+        if (state == ST_TRACE) {
+            SurfaceHitCold shc;
+            if (path_trace(sc, p, sh, shc)) {
+                s_hit[tid] = make_float4(shc.fhp.x, shc.fhp.y, shc.fhp.z, shc.eta);
+                state = ST_SHADE;
+            } else {
+                finish_sample();
+            }
+        }
+        const uint64_t m_shade = __ballot(state == ST_SHADE);
+        const uint64_t m_trace = __ballot(state == ST_TRACE);
+        if ((m_shade | m_trace) == 0ull) break;
+        if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_trace == 0ull) {
+            if (state == ST_SHADE) {
+                state = ST_TRACE;
+                if (path_shade(sc, p, sh, &s_hit[tid])) finish_sample();
+            }
+        }
+    }
+    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
+}
+
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_kernel(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
+// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_large_regen_kernel(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
+// Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_sdf_regen_kernel(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
+
+// Scatter rank-major gathered tiles into the full image (one float4 per thread).
+__global__ __launch_bounds__(256) void untile_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
+                                                     uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
+                                                     uint32_t rows_padded)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = (uint64_t)width * height;
+    if (idx >= total) return;
+    const uint32_t grow = (uint32_t)(idx / width);
+    const uint32_t col = (uint32_t)(idx % width);
+    const uint32_t gb = grow / tile_rows;
+    const uint32_t rank = gb % world;
+    const uint32_t lrow = (gb / world) * tile_rows + (grow % tile_rows);
+    image[idx] = gathered[((uint64_t)rank * rows_padded + lrow) * width + col];
+}
+
+// Rust `as u8`: saturating, NaN -> 0, truncation toward zero.
+RPT_DEV uint32_t as_u8(float x)
+{
+    if (!(x == x)) return 0u;
+    if (x <= 0.0f) return 0u;
+    if (x >= 255.0f) return 255u;
+    return (uint32_t)x;
+}
+
+// ColorBuffer::convert_to_u8, buffer.rs:55-64
+__global__ __launch_bounds__(256) void convert_to_u8_kernel(const float4* __restrict__ pixels, uint32_t* __restrict__ out, uint64_t n)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const float4 p = pixels[idx];
+    const uint32_t r = as_u8(rpt_powf(p.x, 0.4545f) * 255.0f);
+    const uint32_t g = as_u8(rpt_powf(p.y, 0.4545f) * 255.0f);
+    const uint32_t b = as_u8(rpt_powf(p.z, 0.4545f) * 255.0f);
+    const uint32_t a = as_u8(p.w * 255.0f);
+    out[idx] = r | (g << 8) | (b << 16) | (a << 24);
+}
+
+__global__ __launch_bounds__(256) void probe_math_kernel(uint32_t fn, const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.0f;
+    switch (fn) {
+    case RPT_PROBE_SIN: r = rpt_sinf(a[i]); break;
+    case RPT_PROBE_COS: r = rpt_cosf(a[i]); break;
+    case RPT_PROBE_LOG2: r = rpt_log2f(a[i]); break;
+    case RPT_PROBE_POW: r = rpt_powf(a[i], b[i]); break;
+    case RPT_PROBE_DIV: r = a[i] / b[i]; break;
+    case RPT_PROBE_SQRT: r = __builtin_sqrtf(a[i]); break;
+    case RPT_PROBE_RNG: {                                            // a = seed bits, b = frame bits, i = pixel; first draw
+        Rng rng;
+        rng.init(frame_key_hd((uint64_t)rpt_f2u(a[i]), (uint64_t)rpt_f2u(b[i])), (uint32_t)i);
+        r = rng.gen();
+        break;
+    }
+    default: break;
+    }
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(256) void probe_rays_kernel(const SceneLarge sc, const float* __restrict__ rays, uint32_t* __restrict__ out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + i * 7;
+    RayD ray{mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])};
+    float dist = 3.40282347e+38f;
+    uint32_t best = 0xFFFFFFFFu;
+    bool hit = false;
+    bool any;
+    if (sc.use_grid) {
+        grid_closest_sphere(sc, ray, dist, best, hit);
+        any = grid_any_sphere(sc, ray, true, r[6]);
+    } else {
+        any = false;
+        for (uint32_t k = 0; k < sc.n_spheres; ++k) {
+            const float4 s = sphere_uniform(sc, k);
+            float t;
+            bool h = hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t);
+            if (h && (k == 0 || t < dist)) { dist = t; best = k; hit = true; }
+            any = any || (h && t < r[6]);
+        }
+    }
+    out[i * 3 + 0] = rpt_f2u(dist);
+    out[i * 3 + 1] = best;
+    out[i * 3 + 2] = any ? 1u : 0u;
+}
+
+// ---------------------------------------------------------------------------
+// launch wrappers (launch.h)
+// ---------------------------------------------------------------------------
+namespace rptlaunch {
+
+uint32_t max_spp_per_launch() { return kMaxSppPerLaunch; }
+
+hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, bool nested, const RenderParams& rp, uint32_t nblocks, hipStream_t st)
+{
+    const bool has_sdf = !large && scs.sdf.n_prims > 0;
+    const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
+    if (large && nested) hipLaunchKernelGGL(render_large_nested_kernel, dim3(nblocks), dim3(256), 0, st, scl, rp);
+    else if (large) hipLaunchKernelGGL(render_large_regen_kernel, dim3(nblocks), dim3(256), 0, st, scl, rp);
+    else if (has_sdf && nested) hipLaunchKernelGGL(render_sdf_nested_kernel, dim3(nblocks), dim3(256), 0, st, scs, rp);
+    else if (has_sdf) hipLaunchKernelGGL(render_sdf_regen_kernel, dim3(nblocks), dim3(256), 0, st, scs, rp);
+    else if (nested) hipLaunchKernelGGL(render_small_nested_kernel, dim3(nblocks), dim3(256), 0, st, sc, rp);
+    else hipLaunchKernelGGL(render_small_regen_kernel, dim3(nblocks), dim3(256), 0, st, sc, rp);
+    return hipGetLastError();
+}
+
+hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
+                  uint32_t rows_padded, hipStream_t st)
+{
+    const uint64_t total = (uint64_t)width * height;
+    hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, (const float4*)gathered, (float4*)image,
+                       width, height, tile_rows, world, rows_padded);
+    return hipGetLastError();
+}
+
+hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st)
+{
+    hipLaunchKernelGGL(convert_to_u8_kernel, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, (uint32_t*)out, n_pixels);
+    return hipGetLastError();
+}
+
+hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(probe_math_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, fn, a, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t probe_rays(const SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st)
+{
+    hipLaunchKernelGGL(probe_rays_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, sc, rays, out, n);
+    return hipGetLastError();
+}
+
+}  // namespace rptlaunch

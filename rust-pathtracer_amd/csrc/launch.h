@@ -1,0 +1,48 @@
+// launch.h — the seam between the host-side C ABI (capi.hip) and the kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dev_scene.h"
+#include "dev_scene_large.h"
+
+namespace rptdev {
+
+// cyclic row-block tiling (multi-GPU): block b of `tile_rows` rows -> rank b % world
+__host__ __device__ inline uint32_t tile_global_row(uint32_t local_row, uint32_t tile_rows, uint32_t rank, uint32_t world)
+{
+    uint32_t lb = local_row / tile_rows;
+    return (lb * world + rank) * tile_rows + (local_row % tile_rows);
+}
+
+inline uint32_t tile_row_count(uint32_t height, uint32_t tile_rows, uint32_t rank, uint32_t world)
+{
+    if (tile_rows == 0 || world == 0 || rank >= world) return 0;
+    uint32_t nblocks = (height + tile_rows - 1) / tile_rows;        // last block may be short
+    uint32_t rows = 0;
+    for (uint32_t b = rank; b < nblocks; b += world) {
+        uint32_t start = b * tile_rows;
+        uint32_t n = (start + tile_rows <= height) ? tile_rows : (height - start);
+        rows += n;
+    }
+    return rows;
+}
+
+}  // namespace rptdev
+
+namespace rptlaunch {
+
+uint32_t max_spp_per_launch();      // samples one launch of the regenerating kernel can hold in its LDS tables
+
+// One launch of the megakernel on `nblocks` 16x16 tiles: picks the instantiation (small / SDF / large,
+// regenerating or nested) from the scene.
+hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st);
+hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
+                  uint32_t rows_padded, hipStream_t st);
+hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st);
+hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t st);
+hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st);
+
+}  // namespace rptlaunch
