@@ -412,3 +412,61 @@ def test_full_size_config3_rank_tile_matches_oracle(rpt, torch_cuda, tracer, ora
         g = rows[lr]
         want = _oracle_rows(oracle, oracle.scene_analytical(), w, h, spp, (g,))[g]
         assert_bit_identical(got[lr], want, "c3 rank %d local row %d (global %d)" % (rank, lr, g))
+
+
+def _random_small_scene(rpt, rng):
+    A = rpt._abi
+    s = rpt.Scene()
+    s.camera = rpt.Pinhole(tuple(rng.uniform(-1, 1, 3) + (0, 0.5, 4)), tuple(rng.uniform(-0.5, 0.5, 3)), float(rng.uniform(30, 100)))
+    if rng.random() < 0.5:
+        s.background = dict(kind=A.RPT_BG_GRADIENT_Y, colour_a=tuple(rng.uniform(0.5, 1, 3)), colour_b=tuple(rng.uniform(0.2, 1, 3)),
+                            gamma=float(rng.choice([2.2, 1.0, 0.4545])), scale=float(rng.uniform(0.2, 1)))
+    else:
+        s.background = dict(kind=A.RPT_BG_CONSTANT, colour_a=tuple(rng.uniform(0, 0.5, 3)), colour_b=(0, 0, 0), gamma=2.2, scale=1.0)
+    fields = {"rgb": lambda: tuple(rng.uniform(0, 1, 3)), "emission": lambda: tuple(rng.uniform(0, 0.5, 3) * (rng.random() < 0.3)),
+              "anisotropic": lambda: float(rng.uniform(0, 1)), "metallic": lambda: float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])),
+              "roughness": lambda: float(rng.choice([0.0, 0.001, rng.uniform(0.02, 1)])), "subsurface": lambda: float(rng.uniform(0, 1)),
+              "specular_tint": lambda: float(rng.uniform(0, 1)), "sheen": lambda: float(rng.uniform(0, 1)), "sheen_tint": lambda: float(rng.uniform(0, 1)),
+              "clearcoat": lambda: float(rng.choice([0.0, 1.0])), "clearcoat_gloss": lambda: float(rng.uniform(0, 1)),
+              "spec_trans": lambda: float(rng.choice([0.0, 0.0, 1.0, rng.uniform(0, 1)])), "ior": lambda: float(rng.uniform(1.05, 2.2))}
+    n_mat = int(rng.integers(1, 9))
+    s.materials = []
+    for _ in range(n_mat):
+        names = [k for k in fields if rng.random() < 0.4]
+        kw = {k: fields[k]() for k in names}
+        checker = (0.5, 100.0, float(rng.uniform(0.1, 0.9)), float(rng.uniform(0.0, 0.3))) if rng.random() < 0.2 else None
+        s.materials.append(rpt.Material(checker_dir=checker, **kw))
+    s.spheres = [(tuple(rng.uniform(-2, 2, 3) * (1, 0.6, 1)), float(rng.uniform(0.3, 1.1)), int(rng.integers(0, n_mat)))
+                 for _ in range(int(rng.integers(0, 9)))]
+    s.planes = []
+    for _ in range(int(rng.integers(0, 5))):
+        n = rng.normal(size=3); n /= np.linalg.norm(n)
+        if rng.random() < 0.6:
+            n = np.array([0.0, 1.0, 0.0])
+        s.planes.append((tuple(n), tuple(-n * rng.uniform(1.0, 3.0)), 1e-4, int(rng.integers(0, n_mat)), float(rng.choice([0.0, 0.0, 25.0]))))
+    s.lights = [rpt.AnalyticalLight.spherical(tuple(rng.uniform(-4, 4, 3) + (0, 3, 0)), float(rng.uniform(0.2, 1.2)), tuple(rng.uniform(1, 8, 3)))
+                for _ in range(int(rng.integers(0, 5)))]
+    if s.lights and rng.random() < 0.2:                      # the declared-but-unsampled light types are no-ops (tracer.rs:217)
+        s.lights[0].light_type = int(rng.choice([A.RPT_LIGHT_RECTANGULAR, A.RPT_LIGHT_DISTANT]))
+    s.max_depth = int(rng.integers(1, 7))
+    s.eps = float(rng.choice([0.005, 0.001, 0.02]))
+    s.any_hit_uses_max_dist = bool(rng.random() < 0.5)
+    return s
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_small_scenes_match_oracle(rpt, oracle, seed):
+    """Fuzz: random primitive counts (including none), partial material patches (so the layering of
+    analytical.rs:56-58/82-85 matters), emissive / transmissive / anisotropic materials, both backgrounds,
+    depth 1-6, both any_hit modes, finite planes, unsampled light types, odd image sizes."""
+    rng = np.random.default_rng(1000 + seed)
+    s = _random_small_scene(rpt, rng)
+    w, h, spp = int(rng.integers(1, 70)), int(rng.integers(1, 50)), int(rng.integers(1, 4))
+    t = rpt.Tracer(s, device=0, seed=seed)
+    t.flags = rpt._abi.RPT_RENDER_NESTED_LOOPS if seed % 3 == 0 else 0
+    buf = rpt.ColorBuffer(w, h)
+    t.render_n(buf, spp)
+    want = oracle.render(s.describe(), w, h, spp, seed=seed)
+    assert_bit_identical(buf.image(), want, "fuzz seed %d (%dx%d x%d, %d spheres %d planes %d lights depth %d)" %
+                         (seed, w, h, spp, len(s.spheres), len(s.planes), len(s.lights), s.max_depth))
+    t.close()
