@@ -174,8 +174,13 @@ def main():
             cpu, ops = cpu_baseline(width, height)
             out["cpu_baseline"] = cpu
             tfl = ops["flops_per_sample"] * local_pixels * SPP / avg_kernel_s / 1e12
+            # the same work with every correctly rounded divide / sqrt counted at the 12 / 15 VALU instructions
+            # (~2 flops each where they are fmas) gfx950 needs for it: what the VALU actually has to issue
+            expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (2 * 12 - 1) + ops["sqrts_per_sample"] * (2 * 15 - 1)
             out["roofline_valu"] = {"bound": "fp32_valu", "achieved": round(tfl, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(tfl / FP32_PEAK_TFLOPS, 5), **ops,
+                                    "ieee_expanded_flops_per_sample": round(expanded, 1),
+                                    "ieee_expanded_frac": round(expanded * local_pixels * SPP / avg_kernel_s / 1e12 / FP32_PEAK_TFLOPS, 5),
                                     "note": "algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); "
                                             "a correctly rounded f32 divide or sqrt costs 12-15 VALU instructions on gfx950"}
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
