@@ -100,7 +100,11 @@ RPT_DEV float sdf_eval(const DevSdf& sd, v3 p)
 // Sphere marching.  Lanes leave the loop at different step counts; the loop runs until
 // the wave's last lane is done (no cross-lane compaction inside a bounce: the parked-lane
 // vote of the kernel works at bounce granularity).
-RPT_DEV bool sdf_march(const DevSdf& sd, const RayD& ray, float& t_out)
+// `t_useful`: a hit at or beyond this t would be rejected by the caller (it is not nearer than the
+// primitive already found, or not within the shadow ray's max_dist), and t only grows along the
+// march, so the march may stop there — the reference-order march would go on and find a hit the caller
+// then discards.  Pass +inf when every hit counts.
+RPT_DEV bool sdf_march(const DevSdf& sd, const RayD& ray, float t_useful, float& t_out)
 {
     float t = 0.0f;
     for (uint32_t step = 0; step < sd.max_steps; ++step) {
@@ -108,6 +112,7 @@ RPT_DEV bool sdf_march(const DevSdf& sd, const RayD& ray, float& t_out)
         if (dist < sd.hit_eps * t) { t_out = t; return true; }
         t = t + dist;
         if (t > sd.max_t) break;
+        if (t > t_useful) break;
     }
     return false;
 }
@@ -181,8 +186,9 @@ RPT_DEV bool closest_hit_small(const SceneSmall& sc, const DevSdf* sdf, const Ra
     bool win_sdf = false;
     if (SDF) {                                                      // the SDF object, tested last
         float t;
-        bool h = sdf_march(*sdf, ray, t);
-        bool acc = h && ((sc.n_spheres == 0 && sc.n_planes == 0) || t < dist);
+        const bool first = (sc.n_spheres == 0 && sc.n_planes == 0);
+        bool h = sdf_march(*sdf, ray, first ? __builtin_inff() : dist, t);
+        bool acc = h && (first || t < dist);
         if (acc) {
             dist = t;
             win_sdf = true;
@@ -263,7 +269,7 @@ RPT_DEV bool any_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& 
     }
     if (SDF) {
         float t;
-        bool h = sdf_march(*sdf, ray, t);
+        bool h = sdf_march(*sdf, ray, use_max ? max_dist : __builtin_inff(), t);
         occluded = occluded || (h && (!use_max || t < max_dist));
     }
     return occluded;

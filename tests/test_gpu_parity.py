@@ -311,16 +311,18 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
     """BASELINE.json configs[3]: sphere-marched smooth-union blob (divergent march lengths), analytical
     sphere, checker plane, spherical light — bit-identical to the oracle in both kernel forms."""
     from rust_pathtracer_amd import scenes
-    s = scenes.sdf_scene()
     w, h, spp = 128, 72, 4
-    t = rpt.Tracer(s, device=0, seed=9)
-    want = oracle.render(s.describe(), w, h, spp, seed=9)
-    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS):
-        t.flags = flags
-        buf = rpt.ColorBuffer(w, h)
-        t.render_n(buf, spp)
-        assert_bit_identical(buf.image(), want, "sdf scene flags=%d" % flags)
-    t.close()
+    for use_max in (False, True):                  # shadow marches may stop at max_dist only when any_hit honours it
+        s = scenes.sdf_scene()
+        s.any_hit_uses_max_dist = use_max
+        t = rpt.Tracer(s, device=0, seed=9)
+        want = oracle.render(s.describe(), w, h, spp, seed=9)
+        for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+            t.flags = flags
+            buf = rpt.ColorBuffer(w, h)
+            t.render_n(buf, spp)
+            assert_bit_identical(buf.image(), want, "sdf scene use_max=%s flags=%d" % (use_max, flags))
+        t.close()
 
 
 @pytest.mark.parametrize("n_spheres", [64, 3000])
