@@ -65,13 +65,13 @@ def cpu_baseline(width, height, budget_s=12.0):
     best_rate, threads = 0.0, quota
     for cand in sorted({quota, min(2 * quota, max(quota, o.max_threads()))}):
         t0 = time.perf_counter()
-        o.render(desc, width, height, 2, seed=1, frames_done=1, pixels=px, threads=cand)
-        rate = width * height * 2 / (time.perf_counter() - t0)
+        o.render(desc, width, height, 8, seed=1, frames_done=1, pixels=px, threads=cand)
+        rate = width * height * 8 / (time.perf_counter() - t0)
         if rate > best_rate:
             best_rate, threads = rate, cand
     spp = max(1, min(1024, int(budget_s * best_rate / (width * height))))
     t0 = time.perf_counter()
-    o.render(desc, width, height, spp, seed=1, frames_done=3, pixels=px, threads=threads)
+    o.render(desc, width, height, spp, seed=1, frames_done=9, pixels=px, threads=threads)
     t1 = time.perf_counter()
     msps = width * height * spp / (t1 - t0) / 1e6
     # algorithmic flops per sample, measured by the op-counting build of the oracle
