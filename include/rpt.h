@@ -155,7 +155,7 @@ typedef struct rpt_sdf_prim {
 
 typedef struct rpt_sdf {
     uint32_t n_prims;                 /* 0 = no SDF object; at most 8 */
-    uint32_t max_steps;
+    uint32_t max_steps;               /* at most 65536 */
     uint32_t material;
     float    smooth_k;
     float    hit_eps;
@@ -176,7 +176,7 @@ typedef struct rpt_scene_desc {
     rpt_camera     camera;
     rpt_background background;
     float    eps;                     /* Tracer.eps = 0.005 (tracer.rs:16) */
-    uint32_t max_depth;               /* Scene::recursion_depth() = 4 (scene.rs:28-30) */
+    uint32_t max_depth;               /* Scene::recursion_depth() = 4 (scene.rs:28-30); at most 4096 */
     uint32_t n_spheres;   const rpt_sphere*   spheres;    /* tested first, in order */
     uint32_t n_planes;    const rpt_plane*    planes;     /* then planes, in order  */
     uint32_t n_lights;    const rpt_light*    lights;     /* then Scene::sample_lights */

@@ -200,6 +200,9 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         set_err(ctx, "rpt_upload_scene: a table pointer is NULL");
         return RPT_ERR_INVALID_ARG;
     }
+    // bounded loop counts: a wave must always reach the end of its kernel
+    if (s->max_depth > 4096u) { set_err(ctx, "rpt_upload_scene: max_depth %u exceeds the supported 4096", s->max_depth); return RPT_ERR_INVALID_ARG; }
+    if (s->sdf.n_prims && s->sdf.max_steps > 65536u) { set_err(ctx, "rpt_upload_scene: sdf.max_steps %u exceeds the supported 65536", s->sdf.max_steps); return RPT_ERR_INVALID_ARG; }
     const bool large = s->n_spheres > (uint32_t)kMaxSpheres || s->n_lights > (uint32_t)kMaxLights || s->n_materials > (uint32_t)kMaxMaterials;
     if (s->n_planes > (uint32_t)kMaxPlanes) {
         set_err(ctx, "rpt_upload_scene: at most %d planes are supported", kMaxPlanes);

@@ -245,6 +245,10 @@ def test_error_paths(rpt):
     px = np.zeros(16, dtype=np.float32)
     assert lib.rpt_render(h, px.ctypes.data, 2, 2, 0, 1, 1, 0) == rpt._abi.RPT_ERR_NO_SCENE
     assert b"no scene" in lib.rpt_last_error(h)
+    runaway = rpt.AnalyticalScene()
+    runaway.max_depth = 1 << 20
+    d = runaway.describe()
+    assert lib.rpt_upload_scene(h, C.byref(d)) == rpt._abi.RPT_ERR_INVALID_ARG
     too_many_planes = rpt.Scene()
     too_many_planes.materials = [rpt.Material(rgb=(1, 1, 1))]
     too_many_planes.planes = [((0.0, 1.0, 0.0), (0.0, -float(i), 0.0), 1e-4, 0) for i in range(5)]
@@ -472,3 +476,72 @@ def test_random_small_scenes_match_oracle(rpt, oracle, seed):
     assert_bit_identical(buf.image(), want, "fuzz seed %d (%dx%d x%d, %d spheres %d planes %d lights depth %d)" %
                          (seed, w, h, spp, len(s.spheres), len(s.planes), len(s.lights), s.max_depth))
     t.close()
+
+
+def test_full_size_config4_sdf_rows_match_oracle(rpt, torch_cuda, oracle):
+    """BASELINE.json configs[3] at FULL size: the SDF sphere-march scene 1920x1080 x 64 spp; rows through
+    the sky, the blob and the floor recomputed by the oracle, bit-identical."""
+    from rust_pathtracer_amd import scenes
+    s = scenes.sdf_scene()
+    w, h, spp = 1920, 1080, 64
+    t = rpt.Tracer(s, device=0, seed=1)
+    buf = rpt.DeviceColorBuffer(w, h)
+    t.render_n(buf, spp)
+    torch_cuda.cuda.synchronize()
+    img = buf.pixels.cpu().numpy()
+    assert not np.isnan(img).any()
+    for r, want in _oracle_rows(oracle, s.describe(), w, h, spp, (150, 620, 1000)).items():
+        assert_bit_identical(img[r], want, "c4 row %d" % r)
+    t.close()
+
+
+def test_full_size_config5_frame(rpt, torch_cuda, oracle):
+    """BASELINE.json configs[4] at FULL resolution (10 000 spheres + 16 lights, 4096x4096; 2 of its 512 spp,
+    the oracle's brute force being what it is): two complete rows bit-identical to the oracle, and the
+    WHOLE frame identical between the grid traversal and the brute-force loops on the GPU."""
+    import os
+    from rust_pathtracer_amd import scenes
+    torch = torch_cuda
+    s = scenes.random_spheres_scene(10000, 16)
+    w, h, spp = 4096, 4096, 2
+    t = rpt.Tracer(s, device=0, seed=1)
+    grid = rpt.DeviceColorBuffer(w, h)
+    t.render_n(grid, spp)
+    torch.cuda.synchronize()
+    img = grid.pixels.cpu().numpy()
+    for r, want in _oracle_rows(oracle, s.describe(), w, h, spp, (1800, 3000)).items():
+        assert_bit_identical(img[r], want, "c5 row %d" % r)
+    os.environ["RPT_NO_GRID"] = "1"
+    try:
+        t.upload_scene()                                   # re-upload without the grid
+        brute = rpt.DeviceColorBuffer(w, h)
+        t.render_n(brute, spp)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["RPT_NO_GRID"]
+    assert torch.equal(brute.pixels.view(torch.int32), grid.pixels.view(torch.int32))
+    t.close()
+
+
+def test_two_contexts_on_two_threads(rpt, oracle):
+    """A context is used by one thread at a time, but different contexts may run concurrently
+    (the reference's Tracer is Send; include/rpt.h conventions)."""
+    import threading
+    results = {}
+
+    def work(name, seed):
+        t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=seed)
+        buf = rpt.ColorBuffer(120, 90)
+        for _ in range(4):
+            t.render_n(buf, 2)
+        results[name] = buf.image().copy()
+        t.close()
+
+    threads = [threading.Thread(target=work, args=("a", 21)), threading.Thread(target=work, args=("b", 22))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    d = oracle.scene_analytical()
+    assert_bit_identical(results["a"], oracle.render(d, 120, 90, 8, seed=21), "thread a")
+    assert_bit_identical(results["b"], oracle.render(d, 120, 90, 8, seed=22), "thread b")
