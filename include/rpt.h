@@ -219,6 +219,18 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* scene);
 int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height,
                uint64_t frames_done, uint32_t spp, uint64_t seed, uint32_t flags);
 
+/* ---- resident ColorBuffer (the reference's interactive loop without the PCIe round trip) --------------
+ * renderer/src/main.rs:113-124 does, per redraw: pt.render(&mut buffer); buffer.convert_to_u8(frame).  With
+ * rpt_render that moves 2 x 16 B per pixel over PCIe per frame.  Here the context owns a device ColorBuffer
+ * (pixels + frames, buffer.rs:6-14): render accumulates into it, and the host fetches either the f32 pixels or
+ * directly the gamma-encoded u8 frame (4 B per pixel).  Changing width/height or calling rpt_resident_reset
+ * starts a new buffer (ColorBuffer::new, buffer.rs:18-26). */
+int rpt_resident_render(rpt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint32_t flags);
+int rpt_resident_frames(const rpt_ctx* ctx, uint64_t* frames);          /* ColorBuffer.frames */
+int rpt_resident_download(rpt_ctx* ctx, float* pixels);                 /* width*height*4 f32 */
+int rpt_resident_download_u8(rpt_ctx* ctx, uint8_t* frame);             /* convert_to_u8 on the device, width*height*4 bytes */
+int rpt_resident_reset(rpt_ctx* ctx);
+
 /* Same on a DEVICE-resident buffer, asynchronously on `stream` (a hipStream_t; NULL is
  * HIP's null stream).  With world > 1 the image is row-tiled: rows are
  * dealt in blocks of `tile_rows` rows, block b to rank b % world, and `pixels` is

@@ -150,6 +150,16 @@ public:
         check(rpt_convert_to_u8(ctx_, buffer.pixels.data(), frame, (uint32_t)buffer.width, (uint32_t)buffer.height), ctx_);
     }
 
+    /// The interactive loop of renderer/src/main.rs:113-124 with the ColorBuffer kept in HBM: render `spp` more
+    /// frames into the context's resident buffer, then fetch the gamma-encoded u8 frame (4 B per pixel).
+    void render_resident(size_t width, size_t height, uint32_t spp = 1) { check(rpt_resident_render(ctx_, (uint32_t)width, (uint32_t)height, spp, seed_, 0), ctx_); }
+    void resident_to_u8(uint8_t* frame) { check(rpt_resident_download_u8(ctx_, frame), ctx_); }
+    void resident_to(ColorBuffer& buffer) {
+        check(rpt_resident_download(ctx_, buffer.pixels.data()), ctx_);
+        uint64_t f = 0; rpt_resident_frames(ctx_, &f); buffer.frames = (size_t)f;
+    }
+    void resident_reset() { check(rpt_resident_reset(ctx_), ctx_); }
+
     /// Return the scene (tracer.rs:629); call sync_scene() after mutating it.
     Scene* scene() { return scene_; }
     void sync_scene() { rpt_scene_desc d = scene_->describe(); check(rpt_upload_scene(ctx_, &d), ctx_); }

@@ -114,6 +114,11 @@ SYMBOLS = {
     "rpt_abi_version": (C.c_uint32, []),
     "rpt_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(rpt_scene_desc)]),
     "rpt_render": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]),
+    "rpt_resident_render": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]),
+    "rpt_resident_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "rpt_resident_download": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_resident_download_u8": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_resident_reset": (C.c_int, [C.c_void_p]),
     "rpt_render_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64,
                                     C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rpt_tile_row_count": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -292,6 +292,29 @@ class Tracer:
                                           self.seed, self.flags, buffer.height, 0, 1, C.c_void_p(stream)), self._h)
         buffer.frames += spp                                       # tracer.rs:121
 
+    # --- resident ColorBuffer: the interactive loop of renderer/src/main.rs:113-124 without the PCIe round trip
+    def render_resident(self, width, height, spp=1):
+        check(lib().rpt_resident_render(self._h, width, height, spp, self.seed, self.flags), self._h)
+
+    def resident_frames(self):
+        f = C.c_uint64(0)
+        check(lib().rpt_resident_frames(self._h, C.byref(f)), self._h)
+        return f.value
+
+    def resident_to_host(self, width, height):
+        b = ColorBuffer(width, height)
+        check(lib().rpt_resident_download(self._h, b.pixels.ctypes.data), self._h)
+        b.frames = self.resident_frames()
+        return b
+
+    def resident_to_u8(self, width, height):
+        out = np.zeros(width * height * 4, dtype=np.uint8)
+        check(lib().rpt_resident_download_u8(self._h, out.ctypes.data), self._h)
+        return out
+
+    def resident_reset(self):
+        check(lib().rpt_resident_reset(self._h), self._h)
+
     def render_tile(self, tile_pixels, width, height, frames_done, spp, tile_rows, rank, world):
         """Render this rank's rows of a row-tiled image into its compact tile tensor."""
         import torch

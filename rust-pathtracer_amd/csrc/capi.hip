@@ -33,6 +33,9 @@ struct rpt_ctx {
     rpt_camera camera;
     float* fb = nullptr;              // device framebuffer for the host-pointer API
     size_t fb_bytes = 0;
+    float* res = nullptr;             // resident ColorBuffer: pixels (f32 RGBA) followed by the u8 frame
+    uint32_t res_w = 0, res_h = 0;
+    uint64_t res_frames = 0;
     std::string err;
 };
 
@@ -187,6 +190,7 @@ void rpt_destroy(rpt_ctx* ctx)
     if (!ctx) return;
     DeviceGuard guard(ctx->device);
     if (ctx->fb) (void)hipFree(ctx->fb);
+    if (ctx->res) (void)hipFree(ctx->res);
     if (ctx->tables) (void)hipFree(ctx->tables);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -425,6 +429,68 @@ int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height, uin
     int rc = rpt_render_device(ctx, ctx->fb, width, height, frames_done, spp, seed, flags, height, 0, 1, ctx->stream);
     if (rc != RPT_OK) return rc;
     RPT_HIP_CHECK(ctx, hipMemcpyAsync(pixels, ctx->fb, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RPT_OK;
+}
+
+int rpt_resident_reset(rpt_ctx* ctx)
+{
+    if (!ctx) { set_err(nullptr, "rpt_resident_reset: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    RPT_ON_DEVICE(ctx);
+    if (ctx->res) { RPT_HIP_CHECK(ctx, hipFree(ctx->res)); ctx->res = nullptr; }
+    ctx->res_w = ctx->res_h = 0;
+    ctx->res_frames = 0;
+    return RPT_OK;
+}
+
+int rpt_resident_render(rpt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint32_t flags)
+{
+    if (!ctx) { set_err(nullptr, "rpt_resident_render: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (width == 0 || height == 0) { set_err(ctx, "rpt_resident_render: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    if (!ctx->has_scene) { set_err(ctx, "rpt_resident_render: no scene uploaded"); return RPT_ERR_NO_SCENE; }
+    RPT_ON_DEVICE(ctx);
+    if (!ctx->res || ctx->res_w != width || ctx->res_h != height) {             // ColorBuffer::new(width, height)
+        int rc = rpt_resident_reset(ctx);
+        if (rc != RPT_OK) return rc;
+        const size_t n = (size_t)width * height;
+        RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->res, n * 16 + n * 4));
+        RPT_HIP_CHECK(ctx, hipMemsetAsync(ctx->res, 0, n * 16, ctx->stream));
+        ctx->res_w = width; ctx->res_h = height;
+    }
+    int rc = rpt_render_device(ctx, ctx->res, width, height, ctx->res_frames, spp, seed, flags, height, 0, 1, ctx->stream);
+    if (rc != RPT_OK) return rc;
+    ctx->res_frames += spp;                                                      // tracer.rs:121
+    return RPT_OK;
+}
+
+int rpt_resident_frames(const rpt_ctx* ctx, uint64_t* frames)
+{
+    if (!ctx || !frames) return RPT_ERR_INVALID_ARG;
+    *frames = ctx->res_frames;
+    return RPT_OK;
+}
+
+int rpt_resident_download(rpt_ctx* ctx, float* pixels)
+{
+    if (!ctx) { set_err(nullptr, "rpt_resident_download: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!pixels || !ctx->res) { set_err(ctx, "rpt_resident_download: no resident buffer or NULL destination"); return RPT_ERR_INVALID_ARG; }
+    RPT_ON_DEVICE(ctx);
+    const size_t n = (size_t)ctx->res_w * ctx->res_h;
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(pixels, ctx->res, n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    RPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return RPT_OK;
+}
+
+int rpt_resident_download_u8(rpt_ctx* ctx, uint8_t* frame)
+{
+    if (!ctx) { set_err(nullptr, "rpt_resident_download_u8: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!frame || !ctx->res) { set_err(ctx, "rpt_resident_download_u8: no resident buffer or NULL destination"); return RPT_ERR_INVALID_ARG; }
+    RPT_ON_DEVICE(ctx);
+    const size_t n = (size_t)ctx->res_w * ctx->res_h;
+    uint8_t* out_dev = reinterpret_cast<uint8_t*>(ctx->res) + n * 16;
+    int rc = rpt_convert_to_u8_device(ctx, ctx->res, out_dev, ctx->res_w, ctx->res_h, ctx->stream);
+    if (rc != RPT_OK) return rc;
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(frame, out_dev, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     RPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return RPT_OK;
 }

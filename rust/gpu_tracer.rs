@@ -43,6 +43,11 @@ extern "C" {
     fn rpt_scene_analytical(out: *mut RptSceneDesc) -> c_int;
     fn rpt_render(ctx: *mut RptCtx, pixels: *mut f32, width: u32, height: u32,
                   frames_done: u64, spp: u32, seed: u64, flags: u32) -> c_int;
+    fn rpt_resident_render(ctx: *mut RptCtx, width: u32, height: u32, spp: u32, seed: u64, flags: u32) -> c_int;
+    fn rpt_resident_download(ctx: *mut RptCtx, pixels: *mut f32) -> c_int;
+    fn rpt_resident_download_u8(ctx: *mut RptCtx, frame: *mut u8) -> c_int;
+    fn rpt_resident_frames(ctx: *const RptCtx, frames: *mut u64) -> c_int;
+    fn rpt_resident_reset(ctx: *mut RptCtx) -> c_int;
     #[allow(dead_code)]
     fn rpt_render_device(ctx: *mut RptCtx, pixels_dev: *mut f32, width: u32, height: u32, frames_done: u64, spp: u32,
                          seed: u64, flags: u32, tile_rows: u32, rank: u32, world: u32, stream: *mut c_void) -> c_int;
@@ -97,6 +102,28 @@ impl GpuTracer {
         assert!(rc == 0, "rpt_render failed: {}", Self::err(self.ctx));
         buffer.frames += spp as usize;                       // tracer.rs:121
     }
+
+    /// The redraw handler of renderer/src/main.rs:113-124 with the ColorBuffer kept in HBM: render one more
+    /// frame into the context's resident buffer and fetch the gamma-encoded u8 frame (4 bytes per pixel
+    /// cross PCIe instead of 32).  `frame.len() == width * height * 4`.
+    pub fn render_resident_to_u8(&mut self, width: usize, height: usize, frame: &mut [u8]) {
+        assert!(frame.len() == width * height * 4);
+        let rc = unsafe { rpt_resident_render(self.ctx, width as u32, height as u32, 1, self.seed, 0) };
+        assert!(rc == 0, "rpt_resident_render failed: {}", Self::err(self.ctx));
+        let rc = unsafe { rpt_resident_download_u8(self.ctx, frame.as_mut_ptr()) };
+        assert!(rc == 0, "rpt_resident_download_u8 failed: {}", Self::err(self.ctx));
+    }
+
+    /// Copy the resident buffer back into a host ColorBuffer (pixels and frames).
+    pub fn resident_to(&mut self, buffer: &mut ColorBuffer) {
+        let rc = unsafe { rpt_resident_download(self.ctx, buffer.pixels.as_mut_ptr()) };
+        assert!(rc == 0, "rpt_resident_download failed: {}", Self::err(self.ctx));
+        let mut f: u64 = 0;
+        unsafe { rpt_resident_frames(self.ctx, &mut f) };
+        buffer.frames = f as usize;
+    }
+
+    pub fn resident_reset(&mut self) { unsafe { rpt_resident_reset(self.ctx); } }
 
     /// Return a mutable reference to the scene (tracer.rs:629); call `sync_scene` after mutating it.
     pub fn scene(&mut self) -> &mut Box<dyn GpuScene> { &mut self.scene }

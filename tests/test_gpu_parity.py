@@ -545,3 +545,24 @@ def test_two_contexts_on_two_threads(rpt, oracle):
     d = oracle.scene_analytical()
     assert_bit_identical(results["a"], oracle.render(d, 120, 90, 8, seed=21), "thread a")
     assert_bit_identical(results["b"], oracle.render(d, 120, 90, 8, seed=22), "thread b")
+
+
+def test_resident_buffer_interactive_loop(rpt, tracer, oracle):
+    """renderer/src/main.rs:113-124 with the ColorBuffer kept on the device: N x {render; convert_to_u8}.
+    The f32 pixels and the u8 frame after 5 redraws equal the oracle's, and a size change starts afresh."""
+    w, h = 160, 120
+    tracer.resident_reset()
+    frame = None
+    for _ in range(5):
+        tracer.render_resident(w, h)                 # pt.render(&mut buffer)
+        frame = tracer.resident_to_u8(w, h)          # buffer.convert_to_u8(frame)
+    assert tracer.resident_frames() == 5
+    want = oracle.render(oracle.scene_analytical(), w, h, 5, seed=1)
+    buf = tracer.resident_to_host(w, h)
+    assert buf.frames == 5
+    assert_bit_identical(buf.image(), want, "resident f32")
+    assert np.array_equal(frame, oracle.convert_to_u8(want, w, h))
+    tracer.render_resident(64, 48, 2)                # new size: ColorBuffer::new
+    assert tracer.resident_frames() == 2
+    assert_bit_identical(tracer.resident_to_host(64, 48).image(), oracle.render(oracle.scene_analytical(), 64, 48, 2, seed=1), "resident resized")
+    tracer.resident_reset()
