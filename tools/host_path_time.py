@@ -27,3 +27,12 @@ for _ in range(50):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 50
 print("device ColorBuffer, 1 spp per call (one reference render()): %.3f ms/call -> %.1f Msamples/s" % (dt * 1e3, w * h / dt / 1e6))
+for (rw, rh) in ((800, 600), (1920, 1080)):
+    t.resident_reset()
+    t.render_resident(rw, rh); t.resident_to_u8(rw, rh)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        t.render_resident(rw, rh)
+        frame = t.resident_to_u8(rw, rh)
+    dt = (time.perf_counter() - t0) / 50
+    print("resident buffer, %dx%d: render 1 spp + u8 frame download: %.3f ms/redraw -> %.1f Msamples/s, %.0f redraws/s" % (rw, rh, dt * 1e3, rw * rh / dt / 1e6, 1 / dt))
