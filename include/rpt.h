@@ -259,6 +259,13 @@ int rpt_untile_device(rpt_ctx* ctx, const float* gathered_dev, float* image_dev,
 int rpt_convert_to_u8_device(rpt_ctx* ctx, const float* pixels_dev, uint8_t* out_dev,
                              uint32_t width, uint32_t height, void* stream);
 
+/* ColorBuffer::convert_to_u8_at (buffer.rs:67-89): blit the buffer into a larger u8 frame (frame_width x
+ * frame_height, exactly that many RGBA bytes) at offset (at_x, at_y): no gamma, p*255 saturating cast, only
+ * x in (at_x, at_x + width) and y in (at_y, at_y + height) with y = frame row + 1 — the reference's bounds. Pixels
+ * outside keep their previous contents.  Device buffers. */
+int rpt_convert_to_u8_at_device(rpt_ctx* ctx, const float* pixels_dev, uint32_t width, uint32_t height, uint8_t* frame_dev,
+                                uint32_t at_x, uint32_t at_y, uint32_t frame_width, uint32_t frame_height, void* stream);
+
 /* The same on HOST buffers (upload, convert, download; blocks): what ColorBuffer::convert_to_u8
  * does for a caller that owns a host ColorBuffer (buffer.rs:55-64, frame = width*height*4 bytes). */
 int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_t width, uint32_t height);

@@ -311,4 +311,26 @@ void oracle_convert_to_u8(const float* pixels, uint8_t* frame, uint32_t width, u
         }
 }
 
+// ColorBuffer::convert_to_u8_at, buffer.rs:67-89: blit the buffer (bw x bh) into a larger u8 frame
+// (at.2 x at.3) at offset (at.0, at.1) — no gamma, strict `>` lower bounds, and the row shift that comes from
+// y = height - j over reverse chunks.  `frame` must hold exactly width*height*4 bytes.
+void oracle_convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8_t* frame, uint32_t at0, uint32_t at1,
+                             uint32_t width, uint32_t height)
+{
+    for (uint32_t j = 0; j < height; ++j) {                 // par_rchunks_exact_mut: j = 0 is the LAST row of `frame`
+        uint8_t* line = frame + (size_t)(height - 1 - j) * width * 4;
+        for (uint32_t ii = 0; ii < width; ++ii) {
+            size_t i = (size_t)j * width + ii;
+            size_t x = i % width;
+            size_t y = height - (i / width);
+            if (x > at0 && x < (size_t)at0 + bw) {
+                if (y > at1 && y < (size_t)at1 + bh) {
+                    size_t o = (x - at0) * 4 + (y - at1) * bw * 4;
+                    for (int c = 0; c < 4; ++c) line[ii * 4 + c] = as_u8(pixels[o + c] * 255.0f);
+                }
+            }
+        }
+    }
+}
+
 }  // extern "C"

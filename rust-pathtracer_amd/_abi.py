@@ -126,6 +126,8 @@ SYMBOLS = {
     "rpt_untile_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                     C.c_uint32, C.c_void_p]),
     "rpt_convert_to_u8_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]),
+    "rpt_convert_to_u8_at_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_uint32, C.c_void_p]),
     "rpt_convert_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
     "rpt_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_probe_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),

@@ -228,6 +228,16 @@ class DeviceColorBuffer:
     def convert_to_u8(self):
         return _convert_to_u8_tensor(self.pixels, self.width, self.height)
 
+    def convert_to_u8_at(self, frame, at):
+        """buffer.rs:67-89: blit into `frame` (a CUDA uint8 tensor [at[3], at[2], 4]) at offset (at[0], at[1])."""
+        import torch
+        assert frame.is_cuda and frame.dtype == torch.uint8 and frame.is_contiguous() and frame.numel() == at[2] * at[3] * 4
+        ctx = _ctx_for(self.pixels.device.index or 0)
+        stream = torch.cuda.current_stream(self.pixels.device).cuda_stream
+        check(lib().rpt_convert_to_u8_at_device(ctx, self.pixels.data_ptr(), self.width, self.height, frame.data_ptr(),
+                                                at[0], at[1], at[2], at[3], C.c_void_p(stream)), ctx)
+        return frame
+
 
 _default_ctx = {}
 

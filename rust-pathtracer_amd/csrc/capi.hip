@@ -516,6 +516,19 @@ int rpt_convert_to_u8_device(rpt_ctx* ctx, const float* pixels_dev, uint8_t* out
     return RPT_OK;
 }
 
+int rpt_convert_to_u8_at_device(rpt_ctx* ctx, const float* pixels_dev, uint32_t width, uint32_t height, uint8_t* frame_dev, uint32_t at_x,
+                                uint32_t at_y, uint32_t frame_width, uint32_t frame_height, void* stream)
+{
+    if (!ctx) { set_err(nullptr, "rpt_convert_to_u8_at_device: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!pixels_dev || !frame_dev || width == 0 || height == 0 || frame_width == 0 || frame_height == 0) {
+        set_err(ctx, "rpt_convert_to_u8_at_device: invalid argument");
+        return RPT_ERR_INVALID_ARG;
+    }
+    RPT_ON_DEVICE(ctx);
+    RPT_HIP_CHECK(ctx, rptlaunch::convert_to_u8_at(pixels_dev, width, height, frame_dev, at_x, at_y, frame_width, frame_height, (hipStream_t)stream));
+    return RPT_OK;
+}
+
 int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_t width, uint32_t height)
 {
     if (!ctx) { set_err(nullptr, "rpt_convert_to_u8: ctx is NULL"); return RPT_ERR_INVALID_ARG; }

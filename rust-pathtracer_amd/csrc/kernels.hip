@@ -238,6 +238,22 @@ __global__ __launch_bounds__(256) void convert_to_u8_kernel(const float4* __rest
     out[idx] = r | (g << 8) | (b << 16) | (a << 24);
 }
 
+// ColorBuffer::convert_to_u8_at, buffer.rs:67-89 (one thread per destination pixel)
+__global__ __launch_bounds__(256) void convert_to_u8_at_kernel(const float4* __restrict__ pixels, uint32_t bw, uint32_t bh,
+                                                             uint32_t* __restrict__ frame, uint32_t at0, uint32_t at1,
+                                                             uint32_t width, uint32_t height)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (uint64_t)width * height) return;
+    const uint32_t row = (uint32_t)(idx / width);
+    const uint64_t x = idx % width;
+    const uint64_t y = (uint64_t)row + 1u;                            // y = height - j with j = height - 1 - row
+    if (x > at0 && x < (uint64_t)at0 + bw && y > at1 && y < (uint64_t)at1 + bh) {
+        const float4 p = pixels[(y - at1) * bw + (x - at0)];
+        frame[idx] = as_u8(p.x * 255.0f) | (as_u8(p.y * 255.0f) << 8) | (as_u8(p.z * 255.0f) << 16) | (as_u8(p.w * 255.0f) << 24);
+    }
+}
+
 __global__ __launch_bounds__(256) void probe_math_kernel(uint32_t fn, const float* __restrict__ a, const float* __restrict__ b,
                                                          float* __restrict__ out, uint64_t n)
 {
@@ -322,6 +338,15 @@ hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t 
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st)
 {
     hipLaunchKernelGGL(convert_to_u8_kernel, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, (uint32_t*)out, n_pixels);
+    return hipGetLastError();
+}
+
+hipError_t convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8_t* frame, uint32_t at0, uint32_t at1, uint32_t width,
+                            uint32_t height, hipStream_t st)
+{
+    const uint64_t n = (uint64_t)width * height;
+    hipLaunchKernelGGL(convert_to_u8_at_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, bw, bh,
+                       (uint32_t*)frame, at0, at1, width, height);
     return hipGetLastError();
 }
 

@@ -42,6 +42,8 @@ hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneL
 hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
                   uint32_t rows_padded, hipStream_t st);
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st);
+hipError_t convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8_t* frame, uint32_t at0, uint32_t at1, uint32_t width,
+                            uint32_t height, hipStream_t st);
 hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t st);
 hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st);
 

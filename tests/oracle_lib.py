@@ -145,6 +145,12 @@ class Oracle:
         self.lib.oracle_math(fn, a.ctypes.data, b.ctypes.data, out.ctypes.data, a.size)
         return out
 
+    def convert_to_u8_at(self, pixels, bw, bh, frame, at):
+        pixels = np.ascontiguousarray(pixels, dtype=np.float32)
+        self.lib.oracle_convert_to_u8_at.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p] + [C.c_uint32] * 4
+        self.lib.oracle_convert_to_u8_at(pixels.ctypes.data, bw, bh, frame.ctypes.data, at[0], at[1], at[2], at[3])
+        return frame
+
     def convert_to_u8(self, pixels, width, height):
         pixels = np.ascontiguousarray(pixels, dtype=np.float32)
         out = np.zeros(width * height * 4, dtype=np.uint8)

@@ -566,3 +566,21 @@ def test_resident_buffer_interactive_loop(rpt, tracer, oracle):
     assert tracer.resident_frames() == 2
     assert_bit_identical(tracer.resident_to_host(64, 48).image(), oracle.render(oracle.scene_analytical(), 64, 48, 2, seed=1), "resident resized")
     tracer.resident_reset()
+
+
+@pytest.mark.parametrize("at", [(10, 7, 200, 150), (0, 0, 96, 64), (150, 100, 200, 150), (3, 60, 64, 70)])
+def test_convert_to_u8_at(rpt, torch_cuda, tracer, oracle, at):
+    """ColorBuffer::convert_to_u8_at (buffer.rs:67-89): the blit with the reference's strict bounds, row shift
+    and missing gamma; untouched frame pixels keep their contents; clipping at the frame edges."""
+    torch = torch_cuda
+    w, h = 96, 64
+    buf = rpt.DeviceColorBuffer(w, h)
+    tracer.render_n(buf, 3)
+    buf.pixels[5, 5] = torch.tensor([-1.0, 2.0, float("nan"), 0.5], device="cuda")
+    frame = torch.full((at[3], at[2], 4), 77, dtype=torch.uint8, device="cuda")
+    buf.convert_to_u8_at(frame, at)
+    torch.cuda.synchronize()
+    want = np.full((at[3], at[2], 4), 77, dtype=np.uint8)
+    oracle.convert_to_u8_at(buf.pixels.cpu().numpy(), w, h, want, at)
+    assert np.array_equal(frame.cpu().numpy(), want)
+    assert (want != 77).any() or at[0] >= at[2]
