@@ -193,7 +193,10 @@ enum {
     RPT_RENDER_DEFAULT      = 0u,
     /* Use the nested-loop kernel (sample loop outside, bounce loop inside) instead of
      * the path-regenerating one.  Same image bit for bit; kept for A/B measurement. */
-    RPT_RENDER_NESTED_LOOPS = 1u << 0
+    RPT_RENDER_NESTED_LOOPS = 1u << 0,
+    /* Relaxed arithmetic: the same kernels built with hipcc's fast f32 divide/sqrt (~2.5 ulp) and FMA contraction.
+     * Not bit-identical to the reference arithmetic (statistically equivalent); off by default, never benchmarked. */
+    RPT_RENDER_FAST_MATH    = 1u << 1
 };
 
 /* ---- context --------------------------------------------------------------- */

@@ -269,7 +269,7 @@ class Tracer:
         self._scene = scene
         self.seed = int(seed)
         self.device = int(device)
-        self.flags = 0                 # RPT_RENDER_* bits
+        self.flags = 0                 # RPT_RENDER_* bits (0 = the strict, bit-exact regenerating kernel)
         self._h = C.c_void_p()
         check(lib().rpt_create(C.byref(self._h), self.device))
         self.upload_scene()

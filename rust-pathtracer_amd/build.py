@@ -6,7 +6,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpt_hip.so")
-SOURCES = ["kernels.hip", "capi.hip"]
+SOURCES = ["kernels.hip", "kernels_fast.hip", "capi.hip"]
+# kernels_fast.hip: the same kernels with relaxed arithmetic (RPT_RENDER_FAST_MATH); every other file is strict
+EXTRA_FLAGS = {"kernels_fast.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"]}
 HEADERS = ["dev_math.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_large.h", "dev_integrator.h", "launch.h", "host_scene.h",
            os.path.join("..", "..", "include", "rpt.h"), os.path.join("..", "..", "include", "rpt_strict_math.h")]
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
@@ -17,7 +19,7 @@ HEADERS = ["dev_math.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_large.h", "dev_
 # -fno-slp-vectorize: SLP packs scalar f32 ops into v_pk_mul/add_f32, which issue at half rate on
 #   gfx950 and need paired registers: 115 -> 95 VGPRs and +6 % throughput without it.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-         "-mllvm", "-disable-machine-licm", "-fPIC", "-shared"]
+         "-mllvm", "-disable-machine-licm", "-fPIC"]
 
 
 def _hipcc():
@@ -36,10 +38,23 @@ def build(force=False, verbose=False):
     """Compile csrc/*.hip -> librpt_hip.so.  hipcc cross-compiles gfx950 without a GPU."""
     if not force and not needs_build():
         return LIB
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in SOURCES:                                   # one object per source (each with its own flags), in parallel
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        objs.append(obj)
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print(" ".join(link))
+    subprocess.run(link, check=True, cwd=CSRC)
     return LIB
 
 

@@ -406,7 +406,9 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
         const uint32_t chunk = (spp - done > max_chunk) ? max_chunk : (spp - done);
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
-        RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, (flags & RPT_RENDER_NESTED_LOOPS) != 0, rp, (uint32_t)nblocks, (hipStream_t)stream));
+        const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
+        if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, (hipStream_t)stream));
+        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, (hipStream_t)stream));
         done += chunk;
     }
     return RPT_OK;

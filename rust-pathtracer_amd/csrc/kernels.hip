@@ -10,6 +10,13 @@
 #include "dev_scene_large.h"
 #include "launch.h"
 
+// This file is compiled twice: as is (strict arithmetic: -ffp-contract=off, correctly rounded divide/sqrt) and
+// from kernels_fast.hip with hipcc's fast divide/sqrt and FMA contraction, under suffixed kernel names.
+#ifndef RPT_K
+#define RPT_K(name) name
+#define RPT_LAUNCH_NS rptlaunch
+#endif
+
 using namespace rptdev;
 
 
@@ -88,9 +95,9 @@ RPT_DEV void render_nested_body(const S& sc, const RenderParams& rp)
     *pix = acc;
 }
 
-__global__ __launch_bounds__(256) void render_small_nested_kernel(const SceneSmall sc, const RenderParams rp) { render_nested_body(sc, rp); }
-__global__ __launch_bounds__(256) void render_large_nested_kernel(const SceneLarge sc, const RenderParams rp) { render_nested_body(sc, rp); }
-__global__ __launch_bounds__(256) void render_sdf_nested_kernel(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void RPT_K(render_small_nested_kernel)(const SceneSmall sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void RPT_K(render_large_nested_kernel)(const SceneLarge sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(sc, rp); }
 
 // The production megakernel.  Same arithmetic per sample, different schedule:
 //  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
@@ -194,14 +201,14 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
 }
 
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_small_regen_kernel(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_large_regen_kernel(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void render_sdf_regen_kernel(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
 
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
-__global__ __launch_bounds__(256) void untile_kernel(const float4* __restrict__ gathered, float4* __restrict__ image,
+__global__ __launch_bounds__(256) void RPT_K(untile_kernel)(const float4* __restrict__ gathered, float4* __restrict__ image,
                                                      uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
                                                      uint32_t rows_padded)
 {
@@ -226,7 +233,7 @@ RPT_DEV uint32_t as_u8(float x)
 }
 
 // ColorBuffer::convert_to_u8, buffer.rs:55-64
-__global__ __launch_bounds__(256) void convert_to_u8_kernel(const float4* __restrict__ pixels, uint32_t* __restrict__ out, uint64_t n)
+__global__ __launch_bounds__(256) void RPT_K(convert_to_u8_kernel)(const float4* __restrict__ pixels, uint32_t* __restrict__ out, uint64_t n)
 {
     const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256) void convert_to_u8_kernel(const float4* __rest
 }
 
 // ColorBuffer::convert_to_u8_at, buffer.rs:67-89 (one thread per destination pixel)
-__global__ __launch_bounds__(256) void convert_to_u8_at_kernel(const float4* __restrict__ pixels, uint32_t bw, uint32_t bh,
+__global__ __launch_bounds__(256) void RPT_K(convert_to_u8_at_kernel)(const float4* __restrict__ pixels, uint32_t bw, uint32_t bh,
                                                              uint32_t* __restrict__ frame, uint32_t at0, uint32_t at1,
                                                              uint32_t width, uint32_t height)
 {
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void convert_to_u8_at_kernel(const float4* __r
     }
 }
 
-__global__ __launch_bounds__(256) void probe_math_kernel(uint32_t fn, const float* __restrict__ a, const float* __restrict__ b,
+__global__ __launch_bounds__(256) void RPT_K(probe_math_kernel)(uint32_t fn, const float* __restrict__ a, const float* __restrict__ b,
                                                          float* __restrict__ out, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256) void probe_math_kernel(uint32_t fn, const floa
     out[i] = r;
 }
 
-__global__ __launch_bounds__(256) void probe_rays_kernel(const SceneLarge sc, const float* __restrict__ rays, uint32_t* __restrict__ out, uint64_t n)
+__global__ __launch_bounds__(256) void RPT_K(probe_rays_kernel)(const SceneLarge sc, const float* __restrict__ rays, uint32_t* __restrict__ out, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(256) void probe_rays_kernel(const SceneLarge sc, co
 // ---------------------------------------------------------------------------
 // launch wrappers (launch.h)
 // ---------------------------------------------------------------------------
-namespace rptlaunch {
+namespace RPT_LAUNCH_NS {
 
 uint32_t max_spp_per_launch() { return kMaxSppPerLaunch; }
 
@@ -317,12 +324,12 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 {
     const bool has_sdf = !large && scs.sdf.n_prims > 0;
     const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
-    if (large && nested) hipLaunchKernelGGL(render_large_nested_kernel, dim3(nblocks), dim3(256), 0, st, scl, rp);
-    else if (large) hipLaunchKernelGGL(render_large_regen_kernel, dim3(nblocks), dim3(256), 0, st, scl, rp);
-    else if (has_sdf && nested) hipLaunchKernelGGL(render_sdf_nested_kernel, dim3(nblocks), dim3(256), 0, st, scs, rp);
-    else if (has_sdf) hipLaunchKernelGGL(render_sdf_regen_kernel, dim3(nblocks), dim3(256), 0, st, scs, rp);
-    else if (nested) hipLaunchKernelGGL(render_small_nested_kernel, dim3(nblocks), dim3(256), 0, st, sc, rp);
-    else hipLaunchKernelGGL(render_small_regen_kernel, dim3(nblocks), dim3(256), 0, st, sc, rp);
+    if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
+    else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
+    else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
+    else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
+    else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), dim3(nblocks), dim3(256), 0, st, sc, rp);
+    else hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), dim3(nblocks), dim3(256), 0, st, sc, rp);
     return hipGetLastError();
 }
 
@@ -330,14 +337,14 @@ hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t 
                   uint32_t rows_padded, hipStream_t st)
 {
     const uint64_t total = (uint64_t)width * height;
-    hipLaunchKernelGGL(untile_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, (const float4*)gathered, (float4*)image,
+    hipLaunchKernelGGL(RPT_K(untile_kernel), dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, (const float4*)gathered, (float4*)image,
                        width, height, tile_rows, world, rows_padded);
     return hipGetLastError();
 }
 
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st)
 {
-    hipLaunchKernelGGL(convert_to_u8_kernel, dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, (uint32_t*)out, n_pixels);
+    hipLaunchKernelGGL(RPT_K(convert_to_u8_kernel), dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, (uint32_t*)out, n_pixels);
     return hipGetLastError();
 }
 
@@ -345,21 +352,21 @@ hipError_t convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8
                             uint32_t height, hipStream_t st)
 {
     const uint64_t n = (uint64_t)width * height;
-    hipLaunchKernelGGL(convert_to_u8_at_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, bw, bh,
+    hipLaunchKernelGGL(RPT_K(convert_to_u8_at_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, bw, bh,
                        (uint32_t*)frame, at0, at1, width, height);
     return hipGetLastError();
 }
 
 hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(probe_math_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, fn, a, b, out, n);
+    hipLaunchKernelGGL(RPT_K(probe_math_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, fn, a, b, out, n);
     return hipGetLastError();
 }
 
 hipError_t probe_rays(const SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st)
 {
-    hipLaunchKernelGGL(probe_rays_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, sc, rays, out, n);
+    hipLaunchKernelGGL(RPT_K(probe_rays_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, sc, rays, out, n);
     return hipGetLastError();
 }
 
-}  // namespace rptlaunch
+}  // namespace RPT_LAUNCH_NS

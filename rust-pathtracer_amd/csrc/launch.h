@@ -48,3 +48,9 @@ hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, u
 hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st);
 
 }  // namespace rptlaunch
+
+// the relaxed-arithmetic build of the same kernels (kernels_fast.hip)
+namespace rptlaunch_fast {
+hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st);
+}  // namespace rptlaunch_fast

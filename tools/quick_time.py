@@ -9,7 +9,7 @@ import torch  # noqa: E402
 rpt = conftest.load_package()
 w, h = 1920, 1080
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-variants = {"regen": 0, "nested": rpt._abi.RPT_RENDER_NESTED_LOOPS}
+variants = {"regen": 0, "nested": rpt._abi.RPT_RENDER_NESTED_LOOPS, "fast": rpt._abi.RPT_RENDER_FAST_MATH}
 if len(sys.argv) > 2:
     variants = {k: v for k, v in variants.items() if k in sys.argv[2].split(",")}
 t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
@@ -25,8 +25,7 @@ for rep in range(3):
         e0.record(); t.render_n(bufs[k], spp); e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         print("%-7s %dx%d x %d spp: %8.2f ms -> %9.1f Msamples/s" % (k, w, h, spp, ms, w * h * spp / ms / 1e3))
-keys = list(bufs)
-if len(keys) == 2:
-    a, b = bufs[keys[0]].pixels, bufs[keys[1]].pixels
+if "regen" in bufs and "nested" in bufs:
+    a, b = bufs["regen"].pixels, bufs["nested"].pixels
     same = (a.view(torch.int32) == b.view(torch.int32)).all().item()
-    print("bit-identical across kernels:", same)
+    print("regen vs nested bit-identical:", same)
