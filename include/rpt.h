@@ -140,7 +140,8 @@ typedef struct rpt_background {
 
 /* ---- procedural SDF object (BASELINE.json configs[3]; the reference has no SDF scene, Readme.md:18) ----
  * One implicit surface per scene: the polynomial smooth union of a list of primitives,
- *     d = fold(smin_k) over prims,   smin_k(a,b) = min(a,b) - h*h*k*0.25,  h = max(k - |a-b|, 0) / k
+ *     d = fold(smin_k) over prims,   smin_k(a,b) = min(a,b) - h*h*k*0.25,  h = max(k - |a-b|, 0) * (1/k)
+ * (1/k is the f32 quotient 1.0f / k, computed once)
  * found by sphere marching from t = 0:  p = o + t*d;  hit when sdf(p) < hit_eps * t;  t += sdf(p);
  * miss after max_steps steps or when t > max_t.  Normal = normalised tetrahedral gradient with step
  * normal_eps.  The object is tested AFTER the spheres and planes (accepted when nearer) and counts as

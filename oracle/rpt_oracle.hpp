@@ -397,10 +397,11 @@ struct Scene {
     F sdf_eval(const F3& p) const
     {
         F k(d.sdf.smooth_k);
+        F inv_k = F(1.0f) / k;                       // the spec multiplies by this f32 reciprocal (include/rpt.h)
         F dd = sdf_prim(sdf_prims[0], p);
         for (size_t i = 1; i < sdf_prims.size(); ++i) {
             F b = sdf_prim(sdf_prims[i], p);
-            F h = f_max(k - f_abs(dd - b), 0.0f) / k;
+            F h = f_max(k - f_abs(dd - b), 0.0f) * inv_k;
             F m = (dd < b) ? dd : b;
             dd = m - h * h * k * F(0.25f);
         }

@@ -345,6 +345,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
     }
     d.sdf.n_prims = s->sdf.n_prims; d.sdf.max_steps = s->sdf.max_steps; d.sdf.material = s->sdf.material;
     d.sdf.smooth_k = s->sdf.smooth_k; d.sdf.hit_eps = s->sdf.hit_eps; d.sdf.max_t = s->sdf.max_t; d.sdf.normal_eps = s->sdf.normal_eps;
+    d.sdf.inv_smooth_k = s->sdf.n_prims ? 1.0f / s->sdf.smooth_k : 0.0f;
     for (uint32_t i = 0; i < s->sdf.n_prims; ++i) {
         const rpt_sdf_prim& a = s->sdf.prims[i];
         d.sdf.prims[i] = DevSdfPrim{a.kind, a.center[0], a.center[1], a.center[2], a.params[0], a.params[1]};

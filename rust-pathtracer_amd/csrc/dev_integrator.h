@@ -90,7 +90,7 @@ RPT_DEV float sdf_eval(const DevSdf& sd, v3 p)
     float dd = sdf_prim(sd.prims[0], p);
     for (uint32_t i = 1; i < sd.n_prims; ++i) {
         float b = sdf_prim(sd.prims[i], p);
-        float h = rmax(k - __builtin_fabsf(dd - b), 0.0f) / k;
+        float h = rmax(k - __builtin_fabsf(dd - b), 0.0f) * sd.inv_smooth_k;
         float m = (dd < b) ? dd : b;
         dd = m - h * h * k * 0.25f;
     }

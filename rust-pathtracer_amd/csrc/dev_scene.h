@@ -77,6 +77,7 @@ struct DevSdfPrim {
 struct DevSdf {
     uint32_t n_prims, max_steps, material;
     float smooth_k, hit_eps, max_t, normal_eps;
+    float inv_smooth_k;        // 1.0f / smooth_k (f32), computed by the host
     DevSdfPrim prims[kMaxSdfPrims];
 };
 
