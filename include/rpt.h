@@ -197,7 +197,10 @@ enum {
     RPT_RENDER_NESTED_LOOPS = 1u << 0,
     /* Relaxed arithmetic: the same kernels built with hipcc's fast f32 divide/sqrt (~2.5 ulp) and FMA contraction.
      * Not bit-identical to the reference arithmetic (statistically equivalent); off by default, never benchmarked. */
-    RPT_RENDER_FAST_MATH    = 1u << 1
+    RPT_RENDER_FAST_MATH    = 1u << 1,
+    /* Scenes with an SDF object: run the sphere march inside closest_hit / any_hit (one bounce per scheduling
+     * step) instead of as a resumable scheduling state of its own.  Same image bit for bit; kept for A/B. */
+    RPT_RENDER_SDF_INLINE_MARCH = 1u << 2
 };
 
 /* ---- context --------------------------------------------------------------- */

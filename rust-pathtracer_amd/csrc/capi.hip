@@ -79,15 +79,16 @@ struct DeviceGuard {
 
 // Lanes that must be parked on a surface hit before a wave runs its shading block (1..64).
 // RPT_SHADE_THRESHOLD overrides the default for tuning runs.
-static uint32_t shade_threshold()
+static uint32_t env_lanes(const char* name, long dflt)
 {
-    static const uint32_t v = [] {
-        const char* e = getenv("RPT_SHADE_THRESHOLD");
-        long t = e ? strtol(e, nullptr, 10) : 56;
-        return (uint32_t)(t < 1 ? 1 : (t > 64 ? 64 : t));
-    }();
-    return v;
+    const char* e = getenv(name);
+    long t = e ? strtol(e, nullptr, 10) : dflt;
+    return (uint32_t)(t < 1 ? 1 : (t > 64 ? 64 : t));
 }
+// Scheduling knobs (they change when work runs, never its result): lanes that must be waiting before a wave
+// runs a block.
+static uint32_t shade_threshold() { static const uint32_t v = env_lanes("RPT_SHADE_THRESHOLD", 56); return v; }
+static uint32_t sdf_march_min_lanes() { static const uint32_t v = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8); return v; }
 
 extern "C" {
 
@@ -394,7 +395,9 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
     rp.seed = seed;
     rp.tiles_x = (width + 15u) / 16u;
+    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : 1u;
     rp.shade_threshold = shade_threshold();
+    rp.march_min_lanes = sdf_march_min_lanes();
     if (rp.rows_local == 0) return RPT_OK;
     const uint32_t tiles_y = (rp.rows_local + 15u) / 16u;
     const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;

@@ -143,51 +143,88 @@ struct HitInfo {
     v3 light_emission;
 };
 
-// AnalyticalScene::closest_hit (analytical.rs:36-127) + Scene::sample_lights
-// (scene.rs:36-86) over the tables.  Only the final normal is computed (the
-// reference also computes the normals of accepted-then-superseded primitives,
-// which nothing reads).
-template <bool SDF>
-RPT_DEV bool closest_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, PathState& ps, HitInfo& hi)
-{
-    float dist = 3.40282347e+38f;                                   // F::MAX
-    bool hit = false;
-    uint32_t accepted = 0;                                          // bit i: primitive i's material writes happened
-    v3 c = mk3(0.0f, 0.0f, 0.0f);                                   // centre of the winning sphere
-    v3 pn = mk3(0.0f, 0.0f, 0.0f);                                  // normal of the winning plane
-    bool win_plane = false;
+// Result of a sphere march done elsewhere (the resumable-march kernel runs the march as its own
+// scheduling state and hands the outcome to the unchanged closest_hit / any_hit arithmetic).
+struct SdfMarchResult {
+    bool hit;
+    float t;
+};
 
+// The spheres-then-planes part of closest_hit: nearest accepted distance and who won.
+struct AnalyticHit {
+    float dist;
+    bool hit;
+    uint32_t accepted;                                              // bit i: primitive i's material writes happened
+    v3 c;                                                           // centre of the winning sphere
+    v3 pn;                                                          // normal of the winning plane
+    bool win_plane;
+};
+
+RPT_DEV void analytic_closest(const SceneSmall& sc, const RayD& ray, AnalyticHit& a)
+{
+    a.dist = 3.40282347e+38f;                                       // F::MAX
+    a.hit = false;
+    a.accepted = 0;
+    a.c = mk3(0.0f, 0.0f, 0.0f);
+    a.pn = mk3(0.0f, 0.0f, 0.0f);
+    a.win_plane = false;
     for (uint32_t i = 0; i < sc.n_spheres; ++i) {
         const DevSphere& s = sc.spheres[i];
         float t;
         bool h = hit_sphere(ray, mk3(s.cx, s.cy, s.cz), s.radius, t);
-        bool acc = h && (i == 0 || t < dist);                       // analytical.rs:43 has no distance test for the first one
+        bool acc = h && (i == 0 || t < a.dist);                     // analytical.rs:43 has no distance test for the first one
         if (acc) {
-            dist = t;
-            c = mk3(s.cx, s.cy, s.cz);
-            win_plane = false;
-            hit = true;
-            accepted |= 1u << i;
+            a.dist = t;
+            a.c = mk3(s.cx, s.cy, s.cz);
+            a.win_plane = false;
+            a.hit = true;
+            a.accepted |= 1u << i;
         }
     }
     for (uint32_t k = 0; k < sc.n_planes; ++k) {
         const DevPlane& p = sc.planes[k];
         float t;
         bool h = hit_plane(ray, p, t);
-        bool acc = h && ((sc.n_spheres == 0 && k == 0) || t < dist);
+        bool acc = h && ((sc.n_spheres == 0 && k == 0) || t < a.dist);
         if (acc) {
-            dist = t;
-            pn = mk3(p.nx, p.ny, p.nz);
-            win_plane = true;
-            hit = true;
-            accepted |= 1u << (kMaxSpheres + k);
+            a.dist = t;
+            a.pn = mk3(p.nx, p.ny, p.nz);
+            a.win_plane = true;
+            a.hit = true;
+            a.accepted |= 1u << (kMaxSpheres + k);
         }
     }
+}
+
+// How far the SDF march of closest_hit needs to look: a hit at or beyond the analytic winner loses.
+RPT_DEV float sdf_primary_t_useful(const SceneSmall& sc, const AnalyticHit& a)
+{
+    const bool first = (sc.n_spheres == 0 && sc.n_planes == 0);
+    return first ? __builtin_inff() : a.dist;
+}
+
+// AnalyticalScene::closest_hit (analytical.rs:36-127) + Scene::sample_lights
+// (scene.rs:36-86) over the tables.  Only the final normal is computed (the
+// reference also computes the normals of accepted-then-superseded primitives,
+// which nothing reads).
+template <bool SDF>
+RPT_DEV bool closest_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, PathState& ps, HitInfo& hi,
+                               const SdfMarchResult* pre = nullptr)
+{
+    AnalyticHit a;
+    analytic_closest(sc, ray, a);
+    float dist = a.dist;
+    bool hit = a.hit;
+    uint32_t accepted = a.accepted;
+    const v3 c = a.c, pn = a.pn;
+    const bool win_plane = a.win_plane;
     bool win_sdf = false;
     if (SDF) {                                                      // the SDF object, tested last
         float t;
         const bool first = (sc.n_spheres == 0 && sc.n_planes == 0);
-        bool h = sdf_march(*sdf, ray, first ? __builtin_inff() : dist, t);
+        bool h;
+        if (pre) { h = pre->hit; t = pre->t; }
+        else h = sdf_march(*sdf, ray, sdf_primary_t_useful(sc, a), t);
         bool acc = h && (first || t < dist);
         if (acc) {
             dist = t;
@@ -251,8 +288,7 @@ RPT_DEV bool closest_hit(const SceneSmallSdf& sc, const RayD& ray, PathState& ps
 
 // AnalyticalScene::any_hit (analytical.rs:130-145); it ignores max_dist unless the
 // scene opts in.
-template <bool SDF>
-RPT_DEV bool any_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, float max_dist)
+RPT_DEV bool any_hit_analytic(const SceneSmall& sc, const RayD& ray, float max_dist)
 {
     bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
     bool occluded = false;
@@ -267,9 +303,25 @@ RPT_DEV bool any_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& 
         bool h = hit_plane(ray, sc.planes[k], t);
         occluded = occluded || (h && (!use_max || t < max_dist));
     }
+    return occluded;
+}
+
+// How far the SDF march of any_hit needs to look.
+RPT_DEV float sdf_shadow_t_useful(const SceneSmall& sc, float max_dist)
+{
+    return (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) ? max_dist : __builtin_inff();
+}
+
+template <bool SDF>
+RPT_DEV bool any_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, float max_dist, const SdfMarchResult* pre = nullptr)
+{
+    bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
+    bool occluded = any_hit_analytic(sc, ray, max_dist);
     if (SDF) {
         float t;
-        bool h = sdf_march(*sdf, ray, use_max ? max_dist : __builtin_inff(), t);
+        bool h;
+        if (pre) { h = pre->hit; t = pre->t; }
+        else h = sdf_march(*sdf, ray, sdf_shadow_t_useful(sc, max_dist), t);
         occluded = occluded || (h && (!use_max || t < max_dist));
     }
     return occluded;
@@ -343,31 +395,48 @@ RPT_DEV DevLight light_at(const SceneSmall& sc, uint32_t index)
     return L;
 }
 
-// tracer.rs:126-170
+// How the integrator asks the scene its two questions.  The default asks directly; the resumable-march
+// kernel substitutes a query that carries the outcome of a march it ran as a separate scheduling state.
+struct DirectQuery {
+    template <class S> RPT_DEV bool closest(const S& sc, const RayD& ray, PathState& ps, HitInfo& hi) const { return closest_hit(sc, ray, ps, hi); }
+    template <class S> RPT_DEV bool any(const S& sc, const RayD& ray, float max_dist) const { return any_hit(sc, ray, max_dist); }
+};
+
+// Head of direct_light (tracer.rs:130-145): pick a light, sample it.  Returns the facing test of tracer.rs:147.
 template <class S>
-RPT_DEV v3 direct_light(const S& sc, const Mat& mat, float eta, const ShadeFrame& fr, v3 fhp, v3 ffnormal, Rng& rng)
+RPT_DEV bool nee_sample(const S& sc, v3 fhp, v3 ffnormal, Rng& rng, v3& scatter_pos, float& light_area, LightSample& ls)
 {
-    v3 ld = mk3(0.0f, 0.0f, 0.0f);
-    if (sc.n_lights == 0) return ld;
-    v3 scatter_pos = fhp + sc.eps * ffnormal;
+    scatter_pos = fhp + sc.eps * ffnormal;
     float random = rng.gen();
     random = random * sc.n_lights_f;
     uint32_t index = (uint32_t)random;                              // `as usize`
     index = (index >= sc.n_lights) ? sc.n_lights - 1u : index;      // the reference would panic; unreachable for n < 2^24
 
     const DevLight L = light_at(sc, index);                         // Scene::light_at for a per-lane index
-
-    LightSample ls;
+    light_area = L.area;
     sample_light(sc, L, scatter_pos, ls, rng);
+    return dot3(ls.direction, ls.normal) < 0.0f;
+}
+
+// tracer.rs:126-170
+template <class S, class Q>
+RPT_DEV v3 direct_light(const S& sc, const Q& q, const Mat& mat, float eta, const ShadeFrame& fr, v3 fhp, v3 ffnormal, Rng& rng)
+{
+    v3 ld = mk3(0.0f, 0.0f, 0.0f);
+    if (sc.n_lights == 0) return ld;
+    v3 scatter_pos;
+    float light_area;
+    LightSample ls;
+    const bool facing = nee_sample(sc, fhp, ffnormal, rng, scatter_pos, light_area, ls);
     v3 li = ls.emission;
-    if (dot3(ls.direction, ls.normal) < 0.0f) {
+    if (facing) {
         RayD shadow{scatter_pos, ls.direction};
-        bool in_shadow = any_hit(sc, shadow, ls.dist - sc.eps);
+        bool in_shadow = q.any(sc, shadow, ls.dist - sc.eps);
         if (!in_shadow) {
             float bsdf_pdf;
             v3 f = disney_eval(mat, eta, fr, ffnormal, ls.direction, bsdf_pdf);
             float mis_weight = 1.0f;
-            if (L.area > 0.0f) mis_weight = power_heuristic(ls.pdf, bsdf_pdf);
+            if (light_area > 0.0f) mis_weight = power_heuristic(ls.pdf, bsdf_pdf);
             if (bsdf_pdf > 0.0f) ld = ld + (mis_weight * li) * divs3(f, ls.pdf);
         }
     }
@@ -435,15 +504,15 @@ struct SurfaceHitCold {
 // First half of one iteration of the loop at tracer.rs:61-103: closest_hit, the miss
 // and emitter exits (tracer.rs:64-87).  Returns true when a surface was hit and `sh` is
 // filled (shading still to do); false when the path is over and p.radiance is final.
-template <class S>
-RPT_DEV bool path_trace(const S& sc, PathRegs& p, SurfaceHit& sh, SurfaceHitCold& shc)
+template <class S, class Q>
+RPT_DEV bool path_trace(const S& sc, const Q& q, PathRegs& p, SurfaceHit& sh, SurfaceHitCold& shc)
 {
     HitInfo hi;
     hi.is_emitter = false;
     hi.normal = mk3(0.0f, 0.0f, 0.0f);
     hi.light_pdf = 0.0f;
     hi.light_emission = mk3(0.0f, 0.0f, 0.0f);
-    bool hit = closest_hit(sc, p.ray, p.ps, hi);
+    bool hit = q.closest(sc, p.ray, p.ps, hi);
     if (!hit) {
         p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
         return false;
@@ -472,14 +541,14 @@ RPT_DEV bool path_trace(const S& sc, PathRegs& p, SurfaceHit& sh, SurfaceHitCold
 // `cold` points at the lane's parked {fhp.xyz, eta} (LDS in the production kernel).  The
 // hit point is read twice on purpose — for the shadow-ray origin and, much later, for the
 // next ray's origin — so that it does not occupy registers across the BSDF code.
-template <class S>
-RPT_DEV bool path_shade(const S& sc, PathRegs& p, const SurfaceHit& sh, const volatile float4* cold)
+template <class S, class Q>
+RPT_DEV bool path_shade(const S& sc, const Q& q, PathRegs& p, const SurfaceHit& sh, const volatile float4* cold)
 {
     SurfaceHitCold shc;
     shc.eta = cold->w;
     shc.fhp = mk3(cold->x, cold->y, cold->z);
     const ShadeFrame fr = make_frame(sh.mat, shc.eta, -p.ray.d, sh.ffnormal);
-    p.radiance = p.radiance + direct_light(sc, sh.mat, shc.eta, fr, shc.fhp, sh.ffnormal, p.rng) * p.throughput;
+    p.radiance = p.radiance + direct_light(sc, q, sh.mat, shc.eta, fr, shc.fhp, sh.ffnormal, p.rng) * p.throughput;
 
     float pdf;
     v3 scatter_l = (p.bounce > 0) ? p.ray.d : mk3(0.0f, 0.0f, 0.0f);   // the stale `l` of tracer.rs:531
@@ -492,6 +561,11 @@ RPT_DEV bool path_shade(const S& sc, PathRegs& p, const SurfaceHit& sh, const vo
     p.bounce += 1;
     return p.bounce >= sc.max_depth;
 }
+
+template <class S>
+RPT_DEV bool path_trace(const S& sc, PathRegs& p, SurfaceHit& sh, SurfaceHitCold& shc) { return path_trace(sc, DirectQuery{}, p, sh, shc); }
+template <class S>
+RPT_DEV bool path_shade(const S& sc, PathRegs& p, const SurfaceHit& sh, const volatile float4* cold) { return path_shade(sc, DirectQuery{}, p, sh, cold); }
 
 // One whole iteration of tracer.rs:61-103; true when the path is over.
 template <class S>

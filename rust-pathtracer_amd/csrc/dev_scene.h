@@ -111,6 +111,8 @@ struct RenderParams {
     uint64_t seed;
     uint32_t tiles_x;          // ceil(width / 16)
     uint32_t shade_threshold;  // lanes that must be waiting before a wave runs the shading block
+    uint32_t march_min_lanes;      // SDF scenes: a wave keeps marching while at least this many lanes are marching
+    uint32_t sdf_resumable_march;  // SDF scenes: march as a scheduling state (dev_sdf_path.h) instead of inside closest_hit / any_hit
 };
 
 }  // namespace rptdev

@@ -228,32 +228,23 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
         if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; hit = true; }
     }
     GridWalk g = grid_begin(sc, ray);
-    // One flat loop: each iteration a lane either tests the next sphere of its current cell or, when the
-    // cell's list is exhausted, steps to the next cell — lanes with short lists do not idle through other
-    // lanes' long ones.  `budget` bounds the loop (a DDA crosses at most nx+ny+nz cells and every list entry
-    // is visited at most once per cell), so every wave leaves it.
-    uint32_t k = 0, k1 = 0;
-    if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
-    uint32_t cells_left = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u;
-    while (g.alive) {
-        if (k < k1) {
+    // a DDA crosses at most nx+ny+nz cells; the bound guarantees every wave leaves the loop
+    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
+        const uint32_t c = grid_cell_index(sc, g);
+        const uint32_t k0 = sc.cell_start[c], k1 = sc.cell_start[c + 1];
+        for (uint32_t k = k0; k < k1; ++k) {
             const uint32_t i = sc.cell_items[k];
-            ++k;
-            if (i != 0u) {
-                const float4 s = sc.spheres[i];
-                float t;
-                if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) {
-                    if (t < dist || (t == dist && i < best)) { dist = t; best = i; hit = true; }
-                }
+            if (i == 0u) continue;
+            const float4 s = sc.spheres[i];
+            float t;
+            if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) {
+                if (t < dist || (t == dist && i < best)) { dist = t; best = i; hit = true; }
             }
-        } else {
-            const float t_exit = grid_cell_exit(g);
-            if (hit && dist <= t_exit) break;                       // nothing beyond this cell can be nearer
-            if (t_exit > g.t_end) break;
-            if (--cells_left == 0u) break;
-            grid_step(sc, g);
-            if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
         }
+        const float t_exit = grid_cell_exit(g);
+        if (hit && dist <= t_exit) break;                           // nothing beyond this cell can be nearer
+        if (t_exit > g.t_end) break;
+        grid_step(sc, g);
     }
 }
 
@@ -261,26 +252,23 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
 {
     if (!grid_usable(sc, ray)) return brute_any_sphere(sc, ray, use_max, max_dist);
     GridWalk g = grid_begin(sc, ray);
-    uint32_t k = 0, k1 = 0;
-    if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
-    uint32_t cells_left = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u;
-    bool occluded = false;
-    while (g.alive) {                                               // flat loop, as in grid_closest_sphere
-        if (k < k1) {
+    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
+        const uint32_t c = grid_cell_index(sc, g);
+        const uint32_t k0 = sc.cell_start[c], k1 = sc.cell_start[c + 1];
+        for (uint32_t k = k0; k < k1; ++k) {
             const float4 s = sc.spheres[sc.cell_items[k]];
-            ++k;
             float t;
-            if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (!use_max || t < max_dist)) { occluded = true; break; }
-        } else {
-            const float t_exit = grid_cell_exit(g);
-            if (t_exit > g.t_end) break;
-            if (use_max && t_exit > max_dist) break;                // a sphere entirely beyond max_dist cannot occlude
-            if (--cells_left == 0u) break;
-            grid_step(sc, g);
-            if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
+            if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (!use_max || t < max_dist)) return true;
         }
+        const float t_exit = grid_cell_exit(g);
+        if (t_exit > g.t_end) break;
+        if (use_max && t_exit > max_dist) {
+            // a sphere entirely beyond max_dist cannot occlude; one straddling this cell was tested
+            break;
+        }
+        grid_step(sc, g);
     }
-    return occluded;
+    return false;
 }
 
 // AnalyticalScene::closest_hit + Scene::sample_lights, as in dev_integrator.h, for N spheres.

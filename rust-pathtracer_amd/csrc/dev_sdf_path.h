@@ -1,0 +1,90 @@
+// Resumable sphere march for scenes with the SDF object (include/rpt.h rpt_sdf).
+//
+// In dev_integrator.h the march runs inside closest_hit / any_hit: a wave leaves it only when its
+// slowest lane has (measured on BASELINE.json configs[3]: 34 % lane utilisation, march lengths range
+// from 2 to `max_steps`).  Here the march is a scheduling state of the lane, like TRACE and SHADE in
+// the regeneration kernel: a lane marches in chunks, and when its march ends it waits for enough
+// lanes with the same next stage, while the lanes still marching are joined by lanes that started a
+// new march (the next bounce, the next sample of the pixel, a shadow ray).
+//
+// Nothing about the arithmetic changes: the march below is sdf_march() one iteration at a time, and
+// its outcome is handed to the same closest_hit_small / any_hit_small code through SdfMarchResult,
+// so images are bit-identical to the bounce-granular kernels (tests/test_gpu_parity.py, SDF cases).
+#pragma once
+#include "dev_integrator.h"
+
+namespace rptdev {
+
+// One lane's march in flight.  The ray origin is p.ray.o for both kinds: after RESOLVE the path's own
+// origin is dead (the next origin is rebuilt from the parked hit point), so a shadow march borrows it.
+struct MarchRegs {
+    v3 d;                      // direction being marched (the path's for a closest_hit march, the light's for a shadow march)
+    float t, t_useful;
+    uint32_t steps;
+    bool hit;
+};
+
+RPT_DEV void march_begin(MarchRegs& m, v3 dir, float t_useful)
+{
+    m.d = dir;
+    m.t = 0.0f;
+    m.t_useful = t_useful;
+    m.steps = 0;
+    m.hit = false;
+}
+
+// One iteration of sdf_march()'s loop; true when the march is over (m.hit / m.t hold its result).
+RPT_DEV bool march_step(const DevSdf& sd, v3 origin, MarchRegs& m)
+{
+    if (m.steps >= sd.max_steps) return true;
+    float dist = sdf_eval(sd, origin + m.t * m.d);
+    if (dist < sd.hit_eps * m.t) { m.hit = true; return true; }
+    m.t = m.t + dist;
+    m.steps += 1;
+    return (m.t > sd.max_t) || (m.t > m.t_useful);
+}
+
+// Scene queries answered from a finished march.
+struct SdfInjectedQuery {
+    SdfMarchResult r;
+    RPT_DEV bool closest(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, HitInfo& hi) const
+    {
+        return closest_hit_small<true>(sc, &sc.sdf, ray, ps, hi, &r);
+    }
+    RPT_DEV bool any(const SceneSmallSdf& sc, const RayD& ray, float max_dist) const
+    {
+        return any_hit_small<true>(sc, &sc.sdf, ray, max_dist, &r);
+    }
+};
+
+// Start the closest_hit march of the path's current ray.
+RPT_DEV void march_begin_primary(const SceneSmallSdf& sc, const PathRegs& p, MarchRegs& m)
+{
+    AnalyticHit a;
+    analytic_closest(sc, p.ray, a);
+    march_begin(m, p.ray.d, sdf_primary_t_useful(sc, a));
+}
+
+// After a surface hit: find out whether next-event estimation will march a shadow ray, without
+// consuming the path's random numbers (SHADE replays the same draws from p.rng).  Returns true when a
+// march was started (origin in p.ray.o); false when any_hit's answer does not depend on the SDF object,
+// in which case m.hit is set to what the march would be allowed to report (nothing).
+RPT_DEV bool march_begin_shadow(const SceneSmallSdf& sc, PathRegs& p, v3 fhp, v3 ffnormal, MarchRegs& m)
+{
+    m.hit = false;
+    m.t = 0.0f;
+    if (sc.n_lights == 0) return false;
+    Rng rng = p.rng;
+    v3 scatter_pos;
+    float light_area;
+    LightSample ls;
+    if (!nee_sample(sc, fhp, ffnormal, rng, scatter_pos, light_area, ls)) return false;
+    const float max_dist = ls.dist - sc.eps;
+    const RayD shadow{scatter_pos, ls.direction};
+    if (any_hit_analytic(sc, shadow, max_dist)) return false;      // occluded whatever the march says
+    p.ray.o = scatter_pos;
+    march_begin(m, ls.direction, sdf_shadow_t_useful(sc, max_dist));
+    return true;
+}
+
+}  // namespace rptdev

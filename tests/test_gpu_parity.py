@@ -313,7 +313,8 @@ def test_large_scene_needs_full_sphere_materials(rpt):
 
 def test_sdf_scene_matches_oracle(rpt, oracle):
     """BASELINE.json configs[3]: sphere-marched smooth-union blob (divergent march lengths), analytical
-    sphere, checker plane, spherical light — bit-identical to the oracle in both kernel forms."""
+    sphere, checker plane, spherical light — bit-identical to the oracle in all three kernel forms (resumable
+    march, march inside the bounce, nested loops)."""
     from rust_pathtracer_amd import scenes
     w, h, spp = 128, 72, 4
     for use_max in (False, True):                  # shadow marches may stop at max_dist only when any_hit honours it
@@ -321,7 +322,7 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
         s.any_hit_uses_max_dist = use_max
         t = rpt.Tracer(s, device=0, seed=9)
         want = oracle.render(s.describe(), w, h, spp, seed=9)
-        for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+        for flags in (0, rpt._abi.RPT_RENDER_SDF_INLINE_MARCH, rpt._abi.RPT_RENDER_NESTED_LOOPS):
             t.flags = flags
             buf = rpt.ColorBuffer(w, h)
             t.render_n(buf, spp)
@@ -475,6 +476,40 @@ def test_random_small_scenes_match_oracle(rpt, oracle, seed):
     want = oracle.render(s.describe(), w, h, spp, seed=seed)
     assert_bit_identical(buf.image(), want, "fuzz seed %d (%dx%d x%d, %d spheres %d planes %d lights depth %d)" %
                          (seed, w, h, spp, len(s.spheres), len(s.planes), len(s.lights), s.max_depth))
+    t.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sdf_scenes_match_oracle(rpt, oracle, seed):
+    """Fuzz the SDF object: 1-8 random spheres/tori, any smoothing radius, short and long step budgets, on top of
+    random analytical scenes (including none at all, where the SDF hit is accepted unconditionally, and no
+    lights, where no shadow ray is marched) — in all three kernel forms."""
+    A = rpt._abi
+    rng = np.random.default_rng(7000 + seed)
+    s = _random_small_scene(rpt, rng)
+    if seed % 4 == 1:
+        s.spheres, s.planes = [], []
+    if seed % 4 == 2:
+        s.lights = []
+    prims = []
+    for _ in range(int(rng.integers(1, 9))):
+        c = tuple(rng.uniform(-1.5, 1.5, 3) * (1, 0.5, 1))
+        if rng.random() < 0.4:
+            prims.append((A.RPT_SDF_TORUS_Y, c, (float(rng.uniform(0.4, 1.3)), float(rng.uniform(0.08, 0.3)))))
+        else:
+            prims.append((A.RPT_SDF_SPHERE, c, (float(rng.uniform(0.2, 0.9)), 0.0)))
+    s.sdf = dict(prims=prims, material=int(rng.integers(0, len(s.materials))), smooth_k=float(rng.choice([0.05, 0.35, 1.0])),
+                 max_steps=int(rng.choice([1, 7, 48, 200])), hit_eps=float(rng.choice([1e-3, 1e-2])), max_t=float(rng.choice([8.0, 60.0])),
+                 normal_eps=float(rng.choice([1e-3, 1e-2])))
+    w, h, spp = int(rng.integers(8, 90)), int(rng.integers(8, 60)), int(rng.integers(1, 4))
+    want = oracle.render(s.describe(), w, h, spp, seed=seed)
+    t = rpt.Tracer(s, device=0, seed=seed)
+    for flags in (0, A.RPT_RENDER_SDF_INLINE_MARCH, A.RPT_RENDER_NESTED_LOOPS):
+        t.flags = flags
+        buf = rpt.ColorBuffer(w, h)
+        t.render_n(buf, spp)
+        assert_bit_identical(buf.image(), want, "sdf fuzz seed %d flags %d (%dx%d x%d, %d sdf prims, %d spheres %d planes %d lights depth %d)" %
+                             (seed, flags, w, h, spp, len(prims), len(s.spheres), len(s.planes), len(s.lights), s.max_depth))
     t.close()
 
 
