@@ -263,8 +263,9 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         if (use_grid) grid = build_grid(s->spheres, s->n_spheres);
         const size_t sz_tables = (sz_sph + sz_smat + sz_lights + sz_mats + 15) & ~(size_t)15;
         const size_t sz_cstart = (sizeof(uint32_t) * grid.cell_start.size() + 15) & ~(size_t)15;
-        const size_t sz_items = sizeof(uint32_t) * grid.items.size();
-        std::vector<unsigned char> host(sz_tables + sz_cstart + sz_items, 0);
+        const size_t sz_items = (sizeof(uint32_t) * grid.items.size() + 15) & ~(size_t)15;
+        const size_t sz_cell_sph = sizeof(float4) * grid.items.size();
+        std::vector<unsigned char> host(sz_tables + sz_cstart + sz_items + sz_cell_sph, 0);
         float4* h_sph = reinterpret_cast<float4*>(host.data());
         uint32_t* h_smat = reinterpret_cast<uint32_t*>(host.data() + sz_sph);
         DevLight* h_lights = reinterpret_cast<DevLight*>(host.data() + sz_sph + sz_smat);
@@ -277,7 +278,10 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         for (uint32_t i = 0; i < s->n_materials; ++i) h_mats[i] = dev_material(s->materials[i]);
         if (use_grid) {
             memcpy(host.data() + sz_tables, grid.cell_start.data(), sizeof(uint32_t) * grid.cell_start.size());
-            memcpy(host.data() + sz_tables + sz_cstart, grid.items.data(), sz_items);
+            memcpy(host.data() + sz_tables + sz_cstart, grid.items.data(), sizeof(uint32_t) * grid.items.size());
+            // the spheres again, in cell-list order: the walk reads a cell's spheres without going through the index
+            float4* h_cell_sph = reinterpret_cast<float4*>(host.data() + sz_tables + sz_cstart + sz_items);
+            for (size_t k = 0; k < grid.items.size(); ++k) h_cell_sph[k] = h_sph[grid.items[k]];
         }
         if (ctx->tables) { RPT_HIP_CHECK(ctx, hipFree(ctx->tables)); ctx->tables = nullptr; }
         RPT_HIP_CHECK(ctx, hipMalloc(&ctx->tables, host.size()));
@@ -303,6 +307,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
             L.safe_r2 = grid.safe_r2;
             L.cell_start = reinterpret_cast<const uint32_t*>(base + sz_tables);
             L.cell_items = reinterpret_cast<const uint32_t*>(base + sz_tables + sz_cstart);
+            L.cell_spheres = reinterpret_cast<const float4*>(base + sz_tables + sz_cstart + sz_items);
         }
         ctx->camera = s->camera;
         ctx->large = true;

@@ -44,6 +44,7 @@ struct SceneLarge {
     float safe_r2;                    // rays starting farther than sqrt(safe_r2) from gcenter use the brute-force loop
     const uint32_t* cell_start;
     const uint32_t* cell_items;
+    const float4* cell_spheres;       // spheres[cell_items[k]] stored at k: a cell's spheres are one dependent load away, not two
 };
 
 // Wave-uniform table reads: plain dwords through the constant address space, which the
@@ -228,23 +229,27 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
         if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; hit = true; }
     }
     GridWalk g = grid_begin(sc, ray);
-    // a DDA crosses at most nx+ny+nz cells; the bound guarantees every wave leaves the loop
+    // The walk is bound by the latency of its dependent loads (cell -> list bounds -> spheres), not by
+    // arithmetic, so the next cell's list bounds are requested before this cell's spheres are tested.
+    // A DDA crosses at most nx+ny+nz cells; the guard guarantees every wave leaves the loop.
+    uint32_t k0 = 0, k1 = 0;
+    if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
     for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
-        const uint32_t c = grid_cell_index(sc, g);
-        const uint32_t k0 = sc.cell_start[c], k1 = sc.cell_start[c + 1];
+        const float t_exit = grid_cell_exit(g);                     // of the cell whose list is [k0, k1)
+        grid_step(sc, g);                                           // g is the NEXT cell from here on
+        uint32_t n0 = 0, n1 = 0;
+        if (g.alive) { const uint32_t c = grid_cell_index(sc, g); n0 = sc.cell_start[c]; n1 = sc.cell_start[c + 1]; }
         for (uint32_t k = k0; k < k1; ++k) {
-            const uint32_t i = sc.cell_items[k];
-            if (i == 0u) continue;
-            const float4 s = sc.spheres[i];
+            const float4 s = sc.cell_spheres[k];
             float t;
             if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) {
-                if (t < dist || (t == dist && i < best)) { dist = t; best = i; hit = true; }
+                const uint32_t i = sc.cell_items[k];
+                if (i != 0u && (t < dist || (t == dist && i < best))) { dist = t; best = i; hit = true; }
             }
         }
-        const float t_exit = grid_cell_exit(g);
         if (hit && dist <= t_exit) break;                           // nothing beyond this cell can be nearer
         if (t_exit > g.t_end) break;
-        grid_step(sc, g);
+        k0 = n0; k1 = n1;
     }
 }
 
@@ -252,21 +257,24 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
 {
     if (!grid_usable(sc, ray)) return brute_any_sphere(sc, ray, use_max, max_dist);
     GridWalk g = grid_begin(sc, ray);
+    uint32_t k0 = 0, k1 = 0;
+    if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
     for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
-        const uint32_t c = grid_cell_index(sc, g);
-        const uint32_t k0 = sc.cell_start[c], k1 = sc.cell_start[c + 1];
+        const float t_exit = grid_cell_exit(g);
+        grid_step(sc, g);                                           // as in grid_closest_sphere
+        uint32_t n0 = 0, n1 = 0;
+        if (g.alive) { const uint32_t c = grid_cell_index(sc, g); n0 = sc.cell_start[c]; n1 = sc.cell_start[c + 1]; }
         for (uint32_t k = k0; k < k1; ++k) {
-            const float4 s = sc.spheres[sc.cell_items[k]];
+            const float4 s = sc.cell_spheres[k];
             float t;
             if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (!use_max || t < max_dist)) return true;
         }
-        const float t_exit = grid_cell_exit(g);
         if (t_exit > g.t_end) break;
         if (use_max && t_exit > max_dist) {
             // a sphere entirely beyond max_dist cannot occlude; one straddling this cell was tested
             break;
         }
-        grid_step(sc, g);
+        k0 = n0; k1 = n1;
     }
     return false;
 }
