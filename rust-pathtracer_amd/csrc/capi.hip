@@ -260,7 +260,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         const size_t sz_mats = sizeof(DevMaterial) * (s->n_materials ? s->n_materials : 1);
         const bool use_grid = s->n_spheres >= 64 && !getenv("RPT_NO_GRID");
         HostGrid grid;
-        if (use_grid) grid = build_grid(s->spheres, s->n_spheres);
+        if (use_grid) { const char* e = getenv("RPT_GRID_SPHERES_PER_CELL"); grid = build_grid(s->spheres, s->n_spheres, e ? atof(e) : 1.0); }
         const size_t sz_tables = (sz_sph + sz_smat + sz_lights + sz_mats + 15) & ~(size_t)15;
         const size_t sz_cstart = (sizeof(uint32_t) * grid.cell_start.size() + 15) & ~(size_t)15;
         const size_t sz_items = (sizeof(uint32_t) * grid.items.size() + 15) & ~(size_t)15;

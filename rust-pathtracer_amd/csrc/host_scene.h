@@ -63,7 +63,7 @@ struct HostGrid {
     std::vector<uint32_t> cell_start, items;
 };
 
-inline HostGrid build_grid(const rpt_sphere* sph, uint32_t count)
+inline HostGrid build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per_cell = 1.0)
 {
     HostGrid g;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
@@ -79,7 +79,7 @@ inline HostGrid build_grid(const rpt_sphere* sph, uint32_t count)
         ext[a] = hi[a] - lo[a];
         vol *= ext[a];
     }
-    const double target = std::cbrt(vol / (count / 2.0 + 1.0));       // cell edge for ~2 spheres per cell
+    const double target = std::cbrt(vol / (count / spheres_per_cell + 1.0));   // cell edge for ~spheres_per_cell spheres per cell
     for (int a = 0; a < 3; ++a) {
         double n = std::ceil(ext[a] / target);
         n = n < 1 ? 1 : (n > 128 ? 128 : n);
