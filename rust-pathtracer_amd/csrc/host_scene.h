@@ -51,7 +51,7 @@ inline DevCamera make_camera(const rpt_camera& c, float width, float height)
     return d;
 }
 
-// Uniform grid over the spheres of a large scene (dev_scene_large.h).  Cell size targets ~2 spheres
+// Uniform grid over the spheres of a large scene (dev_scene_large.h).  Cell size targets ~1 sphere
 // per cell.  Every sphere is listed in each cell its PADDED bounding box overlaps; the padding is the
 // distance outside the sphere at which the reference's f32 ray/sphere test (d2 = l.l - tca^2 <= r^2,
 // absolute error ~4e-7 |l|^2) can still report a hit, for ray origins within `safe_r` of the grid
