@@ -151,6 +151,25 @@ int oracle_sample_rays(const rpt_scene_desc* desc, uint32_t col, uint32_t row, u
     return (int)n;
 }
 
+// Path events (g_event_log) of the samples [frame0, frame0 + spp) of the pixels of the rectangle [col0, col0 + cw) x
+// [row0, row0 + ch), pixel-major then sample-major, '.'-terminated per sample.  Returns the number of bytes (or
+// -needed when `cap` is too small).  tools/sched_sim.py replays them through candidate wave schedules.
+int oracle_sample_events(const rpt_scene_desc* desc, uint32_t col0, uint32_t row0, uint32_t cw, uint32_t ch, uint64_t frame0, uint32_t spp,
+                         uint32_t width, uint32_t height, uint64_t seed, uint8_t* out, uint64_t cap)
+{
+    Scene scene(*desc);
+    Tracer tracer(scene);
+    std::vector<uint8_t> log;
+    g_event_log = &log;
+    for (uint32_t r = row0; r < row0 + ch; ++r)
+        for (uint32_t c = col0; c < col0 + cw; ++c)
+            for (uint32_t s = 0; s < spp; ++s) tracer.sample_pixel(c, r, width, height, frame_key(seed, frame0 + s));
+    g_event_log = nullptr;
+    if (log.size() > cap) return -(int)log.size();
+    std::memcpy(out, log.data(), log.size());
+    return (int)log.size();
+}
+
 // Count floating-point operations over a render (RPT_OPCOUNT build; zeros otherwise).
 // counts = {add, mul, div, sqrt, transcendental, compare}
 int oracle_opcount(const rpt_scene_desc* desc, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t* counts)

@@ -314,6 +314,12 @@ struct Pinhole {                                                                
 // Debug aid for tests: when set, every closest_hit / any_hit query appends {o, d, max_dist} (max_dist = -1
 // for closest_hit) so a test can replay the exact rays of a pixel-sample through the device probes.
 inline thread_local std::vector<float>* g_ray_log = nullptr;
+// Debug aid for tools/sched_sim.py: when set, sample_pixel appends one byte per path event: per bounce
+// 'M' miss (path over) | 'E' emitter (over) | 'H' surface hit, then 'n' light sample not facing / 's' shadowed /
+// 'v' unshadowed (disney_eval runs) / 'z' no lights, then the sampled lobe 'D' 'C' 'S', then 'x' if pdf <= 0 (over);
+// '.' closes the sample.
+inline thread_local std::vector<uint8_t>* g_event_log = nullptr;
+inline void log_event(char c) { if (g_event_log) g_event_log->push_back((uint8_t)c); }
 
 struct Scene {
     rpt_scene_desc d;
@@ -767,12 +773,14 @@ struct Tracer {
         cdf[3] = cdf[2] + spec_refract_wt;
 
         if (r1 < cdf[0]) {                                                         // diffuse reflection lobe
+            log_event('D');
             r1 /= cdf[0];
             l = cosine_sample_hemisphere(r1, r2);
             F3 h = normalize(l + v);
             f = eval_diffuse(state.material, sheen_col, v, l, h, pdf);
             pdf *= diffuse_wt;
         } else if (r1 < cdf[1]) {                                                  // clearcoat lobe
+            log_event('C');
             r1 = (r1 - cdf[0]) / (cdf[1] - cdf[0]);
             F3 h = sample_gtr1(state.material.clearcoat_roughness, r1, r2);
             if (h.z < F(0.0f)) h = -h;
@@ -780,6 +788,7 @@ struct Tracer {
             f = eval_clearcoat(state.material, v, l, h, pdf);
             pdf *= clearcoat_wt;
         } else {                                                                   // specular reflection / refraction lobes
+            log_event('S');
             r1 = (r1 - cdf[1]) / (F(1.0f) - cdf[1]);
             F3 h = sample_ggxvndf(v, state.material.ax, state.material.ay, r1, r2);
             if (h.z < F(0.0f)) h = -h;
@@ -887,9 +896,12 @@ struct Tracer {
             LightSampleRec light_sample;
             sample_light(light, scatter_pos, light_sample, rng);
             F3 li = light_sample.emission;
-            if (dot(light_sample.direction, light_sample.normal) < F(0.0f)) {
+            const bool facing = dot(light_sample.direction, light_sample.normal) < F(0.0f);
+            if (!facing) log_event('n');
+            if (facing) {
                 Ray shadow_ray(scatter_pos, light_sample.direction);
                 bool in_shadow = scene.any_hit(shadow_ray, light_sample.dist - eps);
+                log_event(in_shadow ? 's' : 'v');
                 if (!in_shadow) {
                     scatter_sample.f = disney_eval(state, -ray.direction, state.ffnormal, light_sample.direction, scatter_sample.pdf);
                     F mis_weight(1.0f);
@@ -897,6 +909,8 @@ struct Tracer {
                     if (scatter_sample.pdf > F(0.0f)) ld += mis_weight * li * (scatter_sample.f / F3::new_x(light_sample.pdf));
                 }
             }
+        } else {
+            log_event('z');
         }
         return ld;
     }
@@ -931,9 +945,11 @@ struct Tracer {
             state.material = Material();
             bool hit = scene.closest_hit(ray, state, light_sample);
             if (!hit) {
+                log_event('M');
                 radiance += scene.background(ray) * throughput;
                 break;
             }
+            log_event(state.is_emitter ? 'E' : 'H');
             state.finalize(ray);
             radiance += state.material.emission * throughput;
             if (state.is_emitter) {
@@ -945,10 +961,11 @@ struct Tracer {
             radiance += direct_light(ray, state, rng) * throughput;
             scatter_sample.f = disney_sample(state, -ray.direction, state.ffnormal, scatter_sample.l, scatter_sample.pdf, rng);
             if (scatter_sample.pdf > F(0.0f)) throughput = throughput * (scatter_sample.f / F3::new_x(scatter_sample.pdf));
-            else break;
+            else { log_event('x'); break; }
             ray.direction = scatter_sample.l;
             ray.origin = state.fhp + eps * ray.direction;
         }
+        log_event('.');
         return radiance;
     }
 

@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "librpt_hip.so")
 SOURCES = ["kernels.hip", "kernels_fast.hip", "capi.hip"]
 # kernels_fast.hip: the same kernels with relaxed arithmetic (RPT_RENDER_FAST_MATH); every other file is strict
 EXTRA_FLAGS = {"kernels_fast.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"]}
-HEADERS = ["dev_math.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_large.h", "dev_integrator.h", "launch.h", "host_scene.h",
+HEADERS = ["dev_math.h", "dev_prof.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_large.h", "dev_integrator.h", "launch.h", "host_scene.h",
            os.path.join("..", "..", "include", "rpt.h"), os.path.join("..", "..", "include", "rpt_strict_math.h")]
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
 # fused operations are the explicit fma calls of rpt_strict_math.h.
@@ -34,16 +34,17 @@ def needs_build():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile csrc/*.hip -> librpt_hip.so.  hipcc cross-compiles gfx950 without a GPU."""
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="build"):
+    """Compile csrc/*.hip -> librpt_hip.so.  hipcc cross-compiles gfx950 without a GPU.
+    `extra_flags` / `lib` / `objdir_name`: experiment builds next to the product library (tools/)."""
     if not force and not needs_build():
-        return LIB
-    objdir = os.path.join(HERE, "build")
+        return lib
+    objdir = os.path.join(HERE, objdir_name)
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
     for src in SOURCES:                                   # one object per source (each with its own flags), in parallel
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
@@ -51,11 +52,11 @@ def build(force=False, verbose=False):
     for cmd, p in procs:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
-    link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", LIB]
+    link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", lib]
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True, cwd=CSRC)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -593,3 +593,12 @@ int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b
 }
 
 }  // extern "C"
+
+#ifdef RPT_PROFILE_BLOCKS
+// Development build only (dev_prof.h, tools/block_profile.py): not part of include/rpt.h.
+namespace rptlaunch { hipError_t prof_read(unsigned long long* out); }
+extern "C" int rpt_prof_read(unsigned long long* out)
+{
+    return rptlaunch::prof_read(out) == hipSuccess ? RPT_OK : RPT_ERR_HIP;
+}
+#endif

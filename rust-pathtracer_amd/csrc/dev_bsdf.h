@@ -292,12 +292,14 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
 
     v3 l;
     if (r1 < cdf0) {
+        RPT_PROF(PB_LOBE_DIFFUSE);
         r1 /= cdf0;
         l = cosine_sample_hemisphere(r1, r2);
         v3 h = norm3(l + v);
         f = eval_diffuse(m, sheen_col, v, l, h, pdf);
         pdf *= w.diffuse;
     } else if (r1 < cdf1) {
+        RPT_PROF(PB_LOBE_CLEARCOAT);
         r1 = (r1 - cdf0) / (cdf1 - cdf0);
         v3 h = sample_gtr1(m.clearcoat_roughness, r1);
         if (h.z < 0.0f) h = -h;
@@ -305,6 +307,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
         f = eval_clearcoat(m, v, l, h, pdf);
         pdf *= w.clearcoat;
     } else {
+        RPT_PROF(PB_LOBE_SPEC);
         r1 = (r1 - cdf1) / (1.0f - cdf1);
         v3 h = sample_ggxvndf(v, m.ax, m.ay, r1, r2);
         if (h.z < 0.0f) h = -h;

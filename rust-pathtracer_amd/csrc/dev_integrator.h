@@ -427,12 +427,15 @@ RPT_DEV v3 direct_light(const S& sc, const Q& q, const Mat& mat, float eta, cons
     v3 scatter_pos;
     float light_area;
     LightSample ls;
-    const bool facing = nee_sample(sc, fhp, ffnormal, rng, scatter_pos, light_area, ls);
+    bool facing;
+    { RPT_PROF(PB_NEE_SAMPLE); facing = nee_sample(sc, fhp, ffnormal, rng, scatter_pos, light_area, ls); }
     v3 li = ls.emission;
     if (facing) {
         RayD shadow{scatter_pos, ls.direction};
-        bool in_shadow = q.any(sc, shadow, ls.dist - sc.eps);
+        bool in_shadow;
+        { RPT_PROF(PB_ANYHIT); in_shadow = q.any(sc, shadow, ls.dist - sc.eps); }
         if (!in_shadow) {
+            RPT_PROF(PB_EVAL);
             float bsdf_pdf;
             v3 f = disney_eval(mat, eta, fr, ffnormal, ls.direction, bsdf_pdf);
             float mis_weight = 1.0f;
@@ -512,11 +515,14 @@ RPT_DEV bool path_trace(const S& sc, const Q& q, PathRegs& p, SurfaceHit& sh, Su
     hi.normal = mk3(0.0f, 0.0f, 0.0f);
     hi.light_pdf = 0.0f;
     hi.light_emission = mk3(0.0f, 0.0f, 0.0f);
-    bool hit = q.closest(sc, p.ray, p.ps, hi);
+    bool hit;
+    { RPT_PROF(PB_CLOSEST); hit = q.closest(sc, p.ray, p.ps, hi); }
     if (!hit) {
+        RPT_PROF(PB_BACKGROUND);
         p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
         return false;
     }
+    RPT_PROF(PB_FINALIZE);
     // State::finalize, globals.rs:50-62
     shc.fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
     float ndd = dot3(hi.normal, p.ray.d);
@@ -547,14 +553,17 @@ RPT_DEV bool path_shade(const S& sc, const Q& q, PathRegs& p, const SurfaceHit& 
     SurfaceHitCold shc;
     shc.eta = cold->w;
     shc.fhp = mk3(cold->x, cold->y, cold->z);
-    const ShadeFrame fr = make_frame(sh.mat, shc.eta, -p.ray.d, sh.ffnormal);
+    ShadeFrame fr;
+    { RPT_PROF(PB_FRAME); fr = make_frame(sh.mat, shc.eta, -p.ray.d, sh.ffnormal); }
     p.radiance = p.radiance + direct_light(sc, q, sh.mat, shc.eta, fr, shc.fhp, sh.ffnormal, p.rng) * p.throughput;
 
     float pdf;
     v3 scatter_l = (p.bounce > 0) ? p.ray.d : mk3(0.0f, 0.0f, 0.0f);   // the stale `l` of tracer.rs:531
-    v3 f = disney_sample(sh.mat, shc.eta, fr, sh.ffnormal, scatter_l, pdf, p.rng);
+    v3 f;
+    { RPT_PROF(PB_SAMPLE_HEAD); f = disney_sample(sh.mat, shc.eta, fr, sh.ffnormal, scatter_l, pdf, p.rng); }
     p.ps.scatter_pdf = pdf;
     if (!(pdf > 0.0f)) return true;
+    RPT_PROF(PB_SAMPLE_TAIL);
     p.throughput = p.throughput * divs3(f, pdf);
     p.ray.d = scatter_l;
     p.ray.o = mk3(cold->x, cold->y, cold->z) + sc.eps * p.ray.d;

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/rpt_strict_math.h"
+#include "dev_prof.h"
 
 #define RPT_DEV __device__ __forceinline__
 

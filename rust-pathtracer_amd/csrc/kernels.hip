@@ -128,6 +128,7 @@ enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u };
 template <class S>
 RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
 {
+    RPT_PROF_INIT();
     __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
     for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
@@ -169,6 +170,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
 
     // blend the finished sample into the running mean and start the next one (or retire)
     auto finish_sample = [&]() {
+        RPT_PROF(PB_FINISH);
         float4 acc = s_acc[tid];
         blend(acc, p.radiance, s_weight[s]);
         s_acc[tid] = acc;
@@ -183,7 +185,9 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     };
 
     for (;;) {
+        RPT_PROF(PB_PASS);
         if (state == ST_TRACE) {
+            RPT_PROF(PB_TRACE);
             SurfaceHitCold shc;
             if (path_trace(sc, p, sh, shc)) {
                 s_hit[tid] = make_float4(shc.fhp.x, shc.fhp.y, shc.fhp.z, shc.eta);
@@ -197,11 +201,13 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
         if ((m_shade | m_trace) == 0ull) break;
         if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_trace == 0ull) {
             if (state == ST_SHADE) {
+                RPT_PROF(PB_SHADE);
                 state = ST_TRACE;
                 if (path_shade(sc, p, sh, &s_hit[tid])) finish_sample();
             }
         }
     }
+    RPT_PROF_FLUSH();
     *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
 }
 
@@ -480,6 +486,17 @@ hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, u
     hipLaunchKernelGGL(RPT_K(probe_math_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, fn, a, b, out, n);
     return hipGetLastError();
 }
+
+#ifdef RPT_PROFILE_BLOCKS
+// development only (dev_prof.h): copy out and clear the block counters
+hipError_t prof_read(unsigned long long* out)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * PB_COUNT * 3);
+    if (e != hipSuccess) return e;
+    static const unsigned long long zeros[PB_COUNT * 3] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zeros, sizeof(zeros));
+}
+#endif
 
 hipError_t probe_rays(const SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st)
 {
