@@ -244,6 +244,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         if (large) { set_err(ctx, "rpt_upload_scene: the SDF object is only supported in small scenes"); return RPT_ERR_UNSUPPORTED; }
     }
     if (large) {
+        if (s->n_spheres >= kNoSphere) { set_err(ctx, "rpt_upload_scene: at most 2^28 - 2 spheres"); return RPT_ERR_UNSUPPORTED; }
         // Layered patches need a bit per primitive; large scenes must use full sphere materials.
         for (uint32_t i = 0; i < s->n_spheres; ++i) {
             const rpt_material& m = s->materials[s->spheres[i].material];

@@ -203,58 +203,25 @@ RPT_DEV float sdf_primary_t_useful(const SceneSmall& sc, const AnalyticHit& a)
     return first ? __builtin_inff() : a.dist;
 }
 
-// AnalyticalScene::closest_hit (analytical.rs:36-127) + Scene::sample_lights
-// (scene.rs:36-86) over the tables.  Only the final normal is computed (the
-// reference also computes the normals of accepted-then-superseded primitives,
-// which nothing reads).
-template <bool SDF>
-RPT_DEV bool closest_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, PathState& ps, HitInfo& hi,
-                               const SdfMarchResult* pre = nullptr)
+// What closest_hit's geometry pass leaves behind for the passes that only a surface hit needs (normal,
+// material): one dword.  Small scenes: the mask of accepted primitives (bit i: sphere i, bit kMaxSpheres + k:
+// plane k, bit kMaxSpheres + kMaxPlanes: the SDF object); the winner is the last accepted one, since the
+// reference tests spheres, then planes, then (project extension) the SDF object, each against the running
+// distance.  Large scenes: see dev_scene_large.h.
+struct GeomHit {
+    uint32_t code;
+};
+
+// What Scene::sample_lights reports when the ray reaches a light first (scene.rs:71-80).
+struct EmitterHit {
+    bool is_emitter;
+    float light_pdf;
+    v3 light_emission;
+};
+
+// Scene::sample_lights, scene.rs:36-86, over the kernarg light table
+RPT_DEV bool sample_lights_small(const SceneSmall& sc, const RayD& ray, PathState& ps, EmitterHit& e, bool hit)
 {
-    AnalyticHit a;
-    analytic_closest(sc, ray, a);
-    float dist = a.dist;
-    bool hit = a.hit;
-    uint32_t accepted = a.accepted;
-    const v3 c = a.c, pn = a.pn;
-    const bool win_plane = a.win_plane;
-    bool win_sdf = false;
-    if (SDF) {                                                      // the SDF object, tested last
-        float t;
-        const bool first = (sc.n_spheres == 0 && sc.n_planes == 0);
-        bool h;
-        if (pre) { h = pre->hit; t = pre->t; }
-        else h = sdf_march(*sdf, ray, sdf_primary_t_useful(sc, a), t);
-        bool acc = h && (first || t < dist);
-        if (acc) {
-            dist = t;
-            win_sdf = true;
-            hit = true;
-            accepted |= 1u << (kMaxSpheres + kMaxPlanes);
-        }
-    }
-    if (hit) {
-        ps.hit_dist = dist;                                         // analytical.rs:48,79,104
-        v3 hp = ray.o + dist * ray.d;                               // ray.at(d)
-        v3 sn;
-        if (SDF && win_sdf) sn = sdf_normal(*sdf, hp);
-        else sn = norm3(hp - c);
-        const bool use_pn = win_plane && !win_sdf;
-        hi.normal.x = use_pn ? pn.x : sn.x;                         // (per component: a struct select goes through scratch)
-        hi.normal.y = use_pn ? pn.y : sn.y;
-        hi.normal.z = use_pn ? pn.z : sn.z;
-    }
-
-    // material = Material::new() then the accepted primitives' writes, in order
-    mat_defaults(hi.mat);
-    for (uint32_t i = 0; i < sc.n_spheres; ++i)
-        apply_patch(hi.mat, sc.materials[sc.spheres[i].material], (accepted >> i) & 1u, ray.d);
-    for (uint32_t k = 0; k < sc.n_planes; ++k)
-        apply_patch(hi.mat, sc.materials[sc.planes[k].material], (accepted >> (kMaxSpheres + k)) & 1u, ray.d);
-    if (SDF)
-        apply_patch(hi.mat, sc.materials[sdf->material], (accepted >> (kMaxSpheres + kMaxPlanes)) & 1u, ray.d);
-
-    // Scene::sample_lights, scene.rs:65-85
     float ldist = ps.hit_dist;
     for (uint32_t i = 0; i < sc.n_lights; ++i) {
         const DevLight& L = sc.lights[i];
@@ -266,13 +233,123 @@ RPT_DEV bool closest_hit_small(const SceneSmall& sc, const DevSdf* sdf, const Ra
                 ldist = t;
                 v3 hit_point = ray.o + t * ray.d;
                 float cos_theta = dot3(-ray.d, norm3(hit_point - pos));
-                hi.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
-                hi.light_emission = mk3(L.ex, L.ey, L.ez);
-                hi.is_emitter = true;
+                e.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
+                e.light_emission = mk3(L.ex, L.ey, L.ez);
+                e.is_emitter = true;
                 ps.hit_dist = t;
                 hit = true;
             }
         }
+    }
+    return hit;
+}
+
+// Geometry pass of AnalyticalScene::closest_hit (analytical.rs:36-127) + Scene::sample_lights
+// (scene.rs:36-86) over the tables: who was hit and how far; no normal, no material.
+template <bool SDF>
+RPT_DEV bool closest_geom_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e,
+                                const SdfMarchResult* pre = nullptr)
+{
+    AnalyticHit a;
+    analytic_closest(sc, ray, a);
+    float dist = a.dist;
+    bool hit = a.hit;
+    uint32_t accepted = a.accepted;
+    if (SDF) {                                                      // the SDF object, tested last
+        float t;
+        const bool first = (sc.n_spheres == 0 && sc.n_planes == 0);
+        bool h;
+        if (pre) { h = pre->hit; t = pre->t; }
+        else h = sdf_march(*sdf, ray, sdf_primary_t_useful(sc, a), t);
+        bool acc = h && (first || t < dist);
+        if (acc) {
+            dist = t;
+            hit = true;
+            accepted |= 1u << (kMaxSpheres + kMaxPlanes);
+        }
+    }
+    if (hit) ps.hit_dist = dist;                                    // analytical.rs:48,79,104
+    g.code = accepted;
+    return sample_lights_small(sc, ray, ps, e, hit);
+}
+
+// material = Material::new() then the accepted primitives' writes, in order (analytical.rs:56-58, 82-85, 115-116)
+template <bool SDF>
+RPT_DEV void material_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, uint32_t accepted, Mat& mat)
+{
+    mat_defaults(mat);
+    for (uint32_t i = 0; i < sc.n_spheres; ++i)
+        apply_patch(mat, sc.materials[sc.spheres[i].material], (accepted >> i) & 1u, ray.d);
+    for (uint32_t k = 0; k < sc.n_planes; ++k)
+        apply_patch(mat, sc.materials[sc.planes[k].material], (accepted >> (kMaxSpheres + k)) & 1u, ray.d);
+    if (SDF)
+        apply_patch(mat, sc.materials[sdf->material], (accepted >> (kMaxSpheres + kMaxPlanes)) & 1u, ray.d);
+}
+
+// Only Material.emission of the same layering (what an emitter exit needs, tracer.rs:74).
+RPT_DEV void apply_patch_emission(v3& em, const DevMaterial& p, bool on)
+{
+    if (p.mask & RPT_MAT_EMISSION) { em.x = on ? p.emission[0] : em.x; em.y = on ? p.emission[1] : em.y; em.z = on ? p.emission[2] : em.z; }
+}
+template <bool SDF>
+RPT_DEV v3 emission_small(const SceneSmall& sc, const DevSdf* sdf, uint32_t accepted)
+{
+    v3 em = mk3(0.0f, 0.0f, 0.0f);
+    for (uint32_t i = 0; i < sc.n_spheres; ++i)
+        apply_patch_emission(em, sc.materials[sc.spheres[i].material], (accepted >> i) & 1u);
+    for (uint32_t k = 0; k < sc.n_planes; ++k)
+        apply_patch_emission(em, sc.materials[sc.planes[k].material], (accepted >> (kMaxSpheres + k)) & 1u);
+    if (SDF)
+        apply_patch_emission(em, sc.materials[sdf->material], (accepted >> (kMaxSpheres + kMaxPlanes)) & 1u);
+    return em;
+}
+
+// Surface pass: normal (only the final one: the reference also computes the normals of
+// accepted-then-superseded primitives, which nothing reads) and material of a surface hit at ps.hit_dist.
+template <bool SDF>
+RPT_DEV void resolve_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, float dist, uint32_t accepted, HitInfo& hi)
+{
+    v3 c = mk3(0.0f, 0.0f, 0.0f), pn = mk3(0.0f, 0.0f, 0.0f);
+    for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+        const DevSphere& s = sc.spheres[i];
+        const bool acc = (accepted >> i) & 1u;
+        c.x = acc ? s.cx : c.x; c.y = acc ? s.cy : c.y; c.z = acc ? s.cz : c.z;
+    }
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        const DevPlane& p = sc.planes[k];
+        const bool acc = (accepted >> (kMaxSpheres + k)) & 1u;
+        pn.x = acc ? p.nx : pn.x; pn.y = acc ? p.ny : pn.y; pn.z = acc ? p.nz : pn.z;
+    }
+    const bool win_sdf = SDF && ((accepted >> (kMaxSpheres + kMaxPlanes)) & 1u);
+    const bool win_plane = ((accepted >> kMaxSpheres) & ((1u << kMaxPlanes) - 1u)) != 0u;
+    v3 hp = ray.o + dist * ray.d;                                   // ray.at(d)
+    v3 sn;
+    if (SDF && win_sdf) sn = sdf_normal(*sdf, hp);
+    else sn = norm3(hp - c);
+    const bool use_pn = win_plane && !win_sdf;
+    hi.normal.x = use_pn ? pn.x : sn.x;                             // (per component: a struct select goes through scratch)
+    hi.normal.y = use_pn ? pn.y : sn.y;
+    hi.normal.z = use_pn ? pn.z : sn.z;
+    material_small<SDF>(sc, sdf, ray, accepted, hi.mat);
+}
+
+// AnalyticalScene::closest_hit + Scene::sample_lights in one call (the nested-loop kernels and the SDF
+// march kernel, which keep the finished hit record between their blocks).
+template <bool SDF>
+RPT_DEV bool closest_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, PathState& ps, HitInfo& hi,
+                               const SdfMarchResult* pre = nullptr)
+{
+    GeomHit g;
+    EmitterHit e{hi.is_emitter, hi.light_pdf, hi.light_emission};
+    const float stale = ps.hit_dist;
+    const bool hit = closest_geom_small<SDF>(sc, sdf, ray, ps, g, e, pre);
+    hi.is_emitter = e.is_emitter; hi.light_pdf = e.light_pdf; hi.light_emission = e.light_emission;
+    if (g.code != 0u) {
+        // the geometric distance: ps.hit_dist unless a nearer light overwrote it, in which case the path ends and
+        // nothing reads the normal — any finite stand-in does
+        resolve_small<SDF>(sc, sdf, ray, e.is_emitter ? stale : ps.hit_dist, g.code, hi);
+    } else {
+        material_small<SDF>(sc, sdf, ray, 0u, hi.mat);
     }
     return hit;
 }
@@ -285,6 +362,13 @@ RPT_DEV bool closest_hit(const SceneSmallSdf& sc, const RayD& ray, PathState& ps
 {
     return closest_hit_small<true>(sc, &sc.sdf, ray, ps, hi);
 }
+// the same in two passes (the regenerating kernels: the surface pass runs in the shading block)
+RPT_DEV bool closest_geom(const SceneSmall& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) { return closest_geom_small<false>(sc, nullptr, ray, ps, g, e); }
+RPT_DEV bool closest_geom(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) { return closest_geom_small<true>(sc, &sc.sdf, ray, ps, g, e); }
+RPT_DEV v3 hit_emission(const SceneSmall& sc, const GeomHit& g) { return emission_small<false>(sc, nullptr, g.code); }
+RPT_DEV v3 hit_emission(const SceneSmallSdf& sc, const GeomHit& g) { return emission_small<true>(sc, &sc.sdf, g.code); }
+RPT_DEV void resolve_hit(const SceneSmall& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi) { resolve_small<false>(sc, nullptr, ray, dist, g.code, hi); }
+RPT_DEV void resolve_hit(const SceneSmallSdf& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi) { resolve_small<true>(sc, &sc.sdf, ray, dist, g.code, hi); }
 
 // AnalyticalScene::any_hit (analytical.rs:130-145); it ignores max_dist unless the
 // scene opts in.
@@ -400,6 +484,7 @@ RPT_DEV DevLight light_at(const SceneSmall& sc, uint32_t index)
 struct DirectQuery {
     template <class S> RPT_DEV bool closest(const S& sc, const RayD& ray, PathState& ps, HitInfo& hi) const { return closest_hit(sc, ray, ps, hi); }
     template <class S> RPT_DEV bool any(const S& sc, const RayD& ray, float max_dist) const { return any_hit(sc, ray, max_dist); }
+    template <class S> RPT_DEV bool geom(const S& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) const { return closest_geom(sc, ray, ps, g, e); }
 };
 
 // Head of direct_light (tracer.rs:130-145): pick a light, sample it.  Returns the facing test of tracer.rs:147.
@@ -567,6 +652,78 @@ RPT_DEV bool path_shade(const S& sc, const Q& q, PathRegs& p, const SurfaceHit& 
     p.throughput = p.throughput * divs3(f, pdf);
     p.ray.d = scatter_l;
     p.ray.o = mk3(cold->x, cold->y, cold->z) + sc.eps * p.ray.d;
+    p.bounce += 1;
+    return p.bounce >= sc.max_depth;
+}
+
+// ---- the same bounce with everything only a surface hit needs moved into the shading half ----
+// TRACE (path_trace_geom): the geometry pass of closest_hit, the miss and emitter exits.  What a surface hit
+// parks is one dword (GeomHit) next to the path's own registers.  SHADE (path_shade_full): normal, material
+// layering, State::finalize, then next-event estimation and BSDF sampling as in path_shade.  The normal, the
+// material writes and finalize cost about as much as the three sphere tests; in TRACE they ran for the 62 % of its
+// lanes that hit a surface (42 % of the wave), in SHADE they run with the shading block's 84 %.  Per lane the
+// operations and their order are unchanged, so images stay bit-identical.
+template <class S, class Q>
+RPT_DEV bool path_trace_geom(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
+{
+    EmitterHit e;
+    e.is_emitter = false;
+    e.light_pdf = 0.0f;
+    e.light_emission = mk3(0.0f, 0.0f, 0.0f);
+    bool hit;
+    { RPT_PROF(PB_CLOSEST); hit = q.geom(sc, p.ray, p.ps, g, e); }
+    if (!hit) {
+        RPT_PROF(PB_BACKGROUND);
+        p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
+        return false;
+    }
+    if (e.is_emitter) {
+        RPT_PROF(PB_FINALIZE);
+        p.radiance = p.radiance + hit_emission(sc, g) * p.throughput;                      // tracer.rs:74
+        // state.depth > 0 always holds (tracer.rs:57,80): the MIS weight is always applied
+        float mis_weight = power_heuristic(p.ps.scatter_pdf, e.light_pdf);
+        p.radiance = p.radiance + (mis_weight * e.light_emission) * p.throughput;
+        return false;
+    }
+    return true;
+}
+
+// Returns true when the path is over (pdf <= 0 or depth exhausted).
+template <class S, class Q>
+RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit& g)
+{
+    Mat mat;
+    v3 ffnormal;
+    float eta;
+    {
+        RPT_PROF(PB_FINALIZE);
+        HitInfo hi;
+        resolve_hit(sc, p.ray, p.ps.hit_dist, g, hi);
+        // State::finalize, globals.rs:50-62
+        float ndd = dot3(hi.normal, p.ray.d);
+        const bool front = (ndd <= 0.0f);
+        ffnormal = mk3(front ? hi.normal.x : -hi.normal.x, front ? hi.normal.y : -hi.normal.y, front ? hi.normal.z : -hi.normal.z);
+        mat_finalize(hi.mat);
+        eta = (ndd < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
+        mat = hi.mat;
+        p.radiance = p.radiance + mat.emission * p.throughput;                              // tracer.rs:74
+    }
+    const v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
+    ShadeFrame fr;
+    { RPT_PROF(PB_FRAME); fr = make_frame(mat, eta, -p.ray.d, ffnormal); }
+    p.radiance = p.radiance + direct_light(sc, q, mat, eta, fr, fhp, ffnormal, p.rng) * p.throughput;
+
+    float pdf;
+    v3 scatter_l = (p.bounce > 0) ? p.ray.d : mk3(0.0f, 0.0f, 0.0f);   // the stale `l` of tracer.rs:531
+    v3 f;
+    { RPT_PROF(PB_SAMPLE_HEAD); f = disney_sample(mat, eta, fr, ffnormal, scatter_l, pdf, p.rng); }
+    p.ps.scatter_pdf = pdf;
+    if (!(pdf > 0.0f)) return true;
+    RPT_PROF(PB_SAMPLE_TAIL);
+    p.throughput = p.throughput * divs3(f, pdf);
+    // the hit point again (not kept across the BSDF code), from the old ray, before the direction changes
+    p.ray.o = (p.ray.o + p.ps.hit_dist * p.ray.d) + sc.eps * scatter_l;
+    p.ray.d = scatter_l;
     p.bounce += 1;
     return p.bounce >= sc.max_depth;
 }

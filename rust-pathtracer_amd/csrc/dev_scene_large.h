@@ -279,15 +279,17 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
     return false;
 }
 
-// AnalyticalScene::closest_hit + Scene::sample_lights, as in dev_integrator.h, for N spheres.
-RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, HitInfo& hi)
+// GeomHit.code of a large scene: the nearest sphere's index in the low 28 bits (kNoSphere: none), the mask of
+// accepted planes above.  (rpt_upload_scene refuses tables with 2^28 spheres or more.)
+constexpr uint32_t kNoSphere = 0x0FFFFFFFu;
+
+// Geometry pass of AnalyticalScene::closest_hit + Scene::sample_lights, as in dev_integrator.h, for N spheres.
+RPT_DEV bool closest_geom(const SceneLarge& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e)
 {
     float dist = 3.40282347e+38f;
     bool hit = false;
     uint32_t best = 0xFFFFFFFFu;                                    // nearest sphere so far
     uint32_t accepted_planes = 0;
-    v3 pn = mk3(0.0f, 0.0f, 0.0f);
-    bool win_plane = false;
 
     if (sc.use_grid) grid_closest_sphere(sc, ray, dist, best, hit);
     else brute_closest_sphere(sc, ray, dist, best, hit);
@@ -298,41 +300,12 @@ RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, H
         bool acc = h && ((sc.n_spheres == 0 && k == 0) || t < dist);
         if (acc) {
             dist = t;
-            pn = mk3(p.nx, p.ny, p.nz);
-            win_plane = true;
             hit = true;
             accepted_planes |= 1u << k;
         }
     }
-
-    mat_defaults(hi.mat);
-    if (best != 0xFFFFFFFFu) {                                      // the nearest sphere's full patch
-        const DevMaterial m = sc.materials[sc.sphere_material[best]];
-        hi.mat.rgb = mk3(m.rgb[0], m.rgb[1], m.rgb[2]);
-        hi.mat.emission = mk3(m.emission[0], m.emission[1], m.emission[2]);
-        hi.mat.anisotropic = m.anisotropic; hi.mat.metallic = m.metallic; hi.mat.roughness = m.roughness;
-        hi.mat.subsurface = m.subsurface; hi.mat.specular_tint = m.specular_tint; hi.mat.sheen = m.sheen;
-        hi.mat.sheen_tint = m.sheen_tint; hi.mat.clearcoat = m.clearcoat; hi.mat.clearcoat_gloss = m.clearcoat_gloss;
-        hi.mat.spec_trans = m.spec_trans; hi.mat.ior = m.ior;
-    }
-    for (uint32_t k = 0; k < sc.n_planes; ++k) {
-        const DevMaterial pm = material_uniform(sc, sc.planes[k].material);   // wave-uniform patch
-        apply_patch(hi.mat, pm, (accepted_planes >> k) & 1u, ray.d);
-    }
-
-    if (hit) {
-        ps.hit_dist = dist;
-        v3 c = mk3(0.0f, 0.0f, 0.0f);
-        if (!win_plane) {
-            const float4 s = sc.spheres[best];                      // per-lane gather
-            c = mk3(s.x, s.y, s.z);
-        }
-        v3 hp = ray.o + dist * ray.d;
-        v3 sn = norm3(hp - c);
-        hi.normal.x = win_plane ? pn.x : sn.x;
-        hi.normal.y = win_plane ? pn.y : sn.y;
-        hi.normal.z = win_plane ? pn.z : sn.z;
-    }
+    if (hit) ps.hit_dist = dist;
+    g.code = (best == 0xFFFFFFFFu ? kNoSphere : best) | (accepted_planes << 28);
 
     // Scene::sample_lights, scene.rs:65-85
     float ldist = ps.hit_dist;
@@ -346,14 +319,90 @@ RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, H
                 ldist = t;
                 v3 hit_point = ray.o + t * ray.d;
                 float cos_theta = dot3(-ray.d, norm3(hit_point - pos));
-                hi.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
-                hi.light_emission = mk3(L.ex, L.ey, L.ez);
-                hi.is_emitter = true;
+                e.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
+                e.light_emission = mk3(L.ex, L.ey, L.ez);
+                e.is_emitter = true;
                 ps.hit_dist = t;
                 hit = true;
             }
         }
     }
+    return hit;
+}
+
+// material = Material::new(), the nearest sphere's full patch, then the accepted planes' patches in order
+RPT_DEV void material_large(const SceneLarge& sc, const RayD& ray, uint32_t code, Mat& mat)
+{
+    const uint32_t best = code & kNoSphere;
+    const uint32_t accepted_planes = code >> 28;
+    mat_defaults(mat);
+    if (best != kNoSphere) {                                        // the nearest sphere's full patch
+        const DevMaterial m = sc.materials[sc.sphere_material[best]];
+        mat.rgb = mk3(m.rgb[0], m.rgb[1], m.rgb[2]);
+        mat.emission = mk3(m.emission[0], m.emission[1], m.emission[2]);
+        mat.anisotropic = m.anisotropic; mat.metallic = m.metallic; mat.roughness = m.roughness;
+        mat.subsurface = m.subsurface; mat.specular_tint = m.specular_tint; mat.sheen = m.sheen;
+        mat.sheen_tint = m.sheen_tint; mat.clearcoat = m.clearcoat; mat.clearcoat_gloss = m.clearcoat_gloss;
+        mat.spec_trans = m.spec_trans; mat.ior = m.ior;
+    }
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        const DevMaterial pm = material_uniform(sc, sc.planes[k].material);   // wave-uniform patch
+        apply_patch(mat, pm, (accepted_planes >> k) & 1u, ray.d);
+    }
+}
+
+RPT_DEV v3 hit_emission(const SceneLarge& sc, const GeomHit& g)
+{
+    const uint32_t best = g.code & kNoSphere;
+    const uint32_t accepted_planes = g.code >> 28;
+    v3 em = mk3(0.0f, 0.0f, 0.0f);
+    if (best != kNoSphere) {
+        const DevMaterial& m = sc.materials[sc.sphere_material[best]];
+        em = mk3(m.emission[0], m.emission[1], m.emission[2]);
+    }
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        const DevMaterial pm = material_uniform(sc, sc.planes[k].material);
+        apply_patch_emission(em, pm, (accepted_planes >> k) & 1u);
+    }
+    return em;
+}
+
+// Surface pass: normal and material of a surface hit at `dist`.
+RPT_DEV void resolve_hit(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi)
+{
+    const uint32_t best = g.code & kNoSphere;
+    const uint32_t accepted_planes = g.code >> 28;
+    v3 pn = mk3(0.0f, 0.0f, 0.0f);
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        const DevPlane& p = sc.planes[k];
+        const bool acc = (accepted_planes >> k) & 1u;
+        pn.x = acc ? p.nx : pn.x; pn.y = acc ? p.ny : pn.y; pn.z = acc ? p.nz : pn.z;
+    }
+    const bool win_plane = accepted_planes != 0u;
+    v3 c = mk3(0.0f, 0.0f, 0.0f);
+    if (!win_plane && best != kNoSphere) {
+        const float4 s = sc.spheres[best];                          // per-lane gather
+        c = mk3(s.x, s.y, s.z);
+    }
+    v3 hp = ray.o + dist * ray.d;
+    v3 sn = norm3(hp - c);
+    hi.normal.x = win_plane ? pn.x : sn.x;
+    hi.normal.y = win_plane ? pn.y : sn.y;
+    hi.normal.z = win_plane ? pn.z : sn.z;
+    material_large(sc, ray, g.code, hi.mat);
+}
+
+// AnalyticalScene::closest_hit + Scene::sample_lights in one call (the nested-loop kernel).
+RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, HitInfo& hi)
+{
+    GeomHit g;
+    EmitterHit e{hi.is_emitter, hi.light_pdf, hi.light_emission};
+    const float stale = ps.hit_dist;
+    const bool hit = closest_geom(sc, ray, ps, g, e);
+    hi.is_emitter = e.is_emitter; hi.light_pdf = e.light_pdf; hi.light_emission = e.light_emission;
+    const bool geom_hit = ((g.code & kNoSphere) != kNoSphere) || (g.code >> 28) != 0u;
+    if (geom_hit) resolve_hit(sc, ray, e.is_emitter ? stale : ps.hit_dist, g, hi);
+    else material_large(sc, ray, g.code, hi.mat);
     return hit;
 }
 

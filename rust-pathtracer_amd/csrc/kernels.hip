@@ -123,7 +123,7 @@ constexpr uint32_t kMaxSppPerLaunch = 512;
 #define RPT_SDF_WAVES_PER_SIMD 5
 #endif
 
-enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u };
+enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u };
 
 template <class S>
 RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
@@ -143,7 +143,6 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     // registers they would pin are what separates 4 from 5 resident waves per SIMD.
     __shared__ float4 s_acc[256];                                   // running mean, tracer.rs:105-117
     __shared__ float4 s_pix[256];                                   // {coord.x, coord.y, bits(pixel_index), -}
-    __shared__ float4 s_hit[256];                                   // parked SurfaceHitCold {fhp, eta}
     const uint32_t tid = threadIdx.x;
     {
         const PixelSetup ps = pixel_setup(rp);
@@ -162,48 +161,42 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     uint32_t s = 0;
     uint32_t state = ST_TRACE;
     PathRegs p;
-    SurfaceHit sh;
+    GeomHit g;                                                      // what a lane waiting for SHADE parks: one dword
+    g.code = 0u;
     {
         const float4 c = s_pix[tid];
         path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
     }
 
-    // blend the finished sample into the running mean and start the next one (or retire)
-    auto finish_sample = [&]() {
-        RPT_PROF(PB_FINISH);
-        float4 acc = s_acc[tid];
-        blend(acc, p.radiance, s_weight[s]);
-        s_acc[tid] = acc;
-        s += 1;
-        if (s >= rp.spp) {
-            state = ST_DONE;
-        } else {
-            const float4 c = s_pix[tid];
-            path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
-            state = ST_TRACE;
-        }
-    };
-
     for (;;) {
         RPT_PROF(PB_PASS);
-        if (state == ST_TRACE) {
-            RPT_PROF(PB_TRACE);
-            SurfaceHitCold shc;
-            if (path_trace(sc, p, sh, shc)) {
-                s_hit[tid] = make_float4(shc.fhp.x, shc.fhp.y, shc.fhp.z, shc.eta);
-                state = ST_SHADE;
+        if (state == ST_FINISH) {
+            // blend the finished sample into the running mean and start the next one (or retire); one site for
+            // the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
+            RPT_PROF(PB_FINISH);
+            float4 acc = s_acc[tid];
+            blend(acc, p.radiance, s_weight[s]);
+            s_acc[tid] = acc;
+            s += 1;
+            if (s >= rp.spp) {
+                state = ST_DONE;
             } else {
-                finish_sample();
+                const float4 c = s_pix[tid];
+                path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                state = ST_TRACE;
             }
         }
+        if (state == ST_TRACE) {
+            RPT_PROF(PB_TRACE);
+            state = path_trace_geom(sc, DirectQuery{}, p, g) ? ST_SHADE : ST_FINISH;
+        }
         const uint64_t m_shade = __ballot(state == ST_SHADE);
-        const uint64_t m_trace = __ballot(state == ST_TRACE);
-        if ((m_shade | m_trace) == 0ull) break;
-        if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_trace == 0ull) {
+        const uint64_t m_go = __ballot(state == ST_TRACE || state == ST_FINISH);
+        if ((m_shade | m_go) == 0ull) break;
+        if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_go == 0ull) {
             if (state == ST_SHADE) {
                 RPT_PROF(PB_SHADE);
-                state = ST_TRACE;
-                if (path_shade(sc, p, sh, &s_hit[tid])) finish_sample();
+                state = path_shade_full(sc, DirectQuery{}, p, g) ? ST_FINISH : ST_TRACE;
             }
         }
     }
