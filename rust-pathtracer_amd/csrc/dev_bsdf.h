@@ -276,10 +276,23 @@ RPT_DEV ShadeFrame make_frame(const Mat& m, float eta, v3 v_world, v3 n)
 // tracer.rs:441-553.  l_io: in = the previous bounce's world-space direction (zeros
 // on the first bounce) which the specular branch reads before overwriting it
 // (tracer.rs:531); out = the sampled world-space direction.
+//
+// The reference is an if / else-if / else over the three lobes.  On a 64-wide wave the three arms run one
+// after the other, each with the lanes that chose it (measured on BASELINE configs[1]: 33 % / 13 % / 48 % of the
+// wave), so every operation the arms have in common is hoisted out of them and runs once with all lanes:
+//   * the renormalisation of r1 — (r1 - lo) / (hi - lo) with (lo, hi) = (0, cdf0), (cdf0, cdf1), (cdf1, 1); for the
+//     diffuse arm r1 - 0 and cdf0 - 0 are exact, so this is the reference's r1 / cdf0;
+//   * sin/cos of 2*pi*r2 (clearcoat: of 2*pi*r1, tracer.rs:247) and sqrt(r1) (diffuse and specular);
+//   * the normalize every arm ends its sampling with — h = normalize(l + v) in the diffuse arm, l =
+//     normalize(reflect(-v, h)) in the other two;
+//   * for the clearcoat and the specular-reflection arm, which are both F*D*G / (4 l.z v.z) microfacet terms: the
+//     dielectric Fresnel term, the two Smith terms' common tail 2n / (n + sqrt(E)), the pdf's division and the
+//     first division of the value.
+// Every lane still executes exactly the reference's operations on its own values, in the reference's order.
 RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3& l_io, float& pdf, Rng& rng)
 {
     pdf = 0.0f;
-    v3 f;
+    v3 f = mk3(0.0f, 0.0f, 0.0f);
     float r1 = rng.gen();
     float r2 = rng.gen();
 
@@ -290,40 +303,126 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
     float cdf0 = w.diffuse;
     float cdf1 = cdf0 + w.clearcoat;
 
-    v3 l;
-    if (r1 < cdf0) {
+    const bool is_d = r1 < cdf0;                                    // tracer.rs:501
+    const bool is_c = !is_d && (r1 < cdf1);                         // tracer.rs:510
+    const bool is_s = !is_d && !is_c;                               // tracer.rs:520
+
+    const float lo = is_d ? 0.0f : (is_c ? cdf0 : cdf1);
+    const float hi = is_d ? cdf0 : (is_c ? cdf1 : 1.0f);
+    r1 = (r1 - lo) / (hi - lo);                                     // tracer.rs:502, 511, 521
+    const float phi = kTwoPi * (is_c ? r1 : r2);                    // tracer.rs:329, 247, 267
+    float sn, cs;
+    rpt_sincosf(phi, &sn, &cs);
+    const float rs = __builtin_sqrtf(r1);                           // tracer.rs:327, 266
+
+    v3 pre;                    // what the arm normalises: l + v (diffuse), reflect / refract(-v, h) (the others)
+    v3 other;                  // the arm's other vector: l (diffuse), h (the others)
+    bool reflected = true;
+    float ff = 1.0f;
+    if (is_d) {
         RPT_PROF(PB_LOBE_DIFFUSE);
-        r1 /= cdf0;
-        l = cosine_sample_hemisphere(r1, r2);
-        v3 h = norm3(l + v);
-        f = eval_diffuse(m, sheen_col, v, l, h, pdf);
-        pdf *= w.diffuse;
-    } else if (r1 < cdf1) {
+        v3 l;                                                       // cosine_sample_hemisphere, tracer.rs:324
+        l.x = rs * cs;
+        l.y = rs * sn;
+        l.z = __builtin_sqrtf(rmax(0.0f, 1.0f - l.x * l.x - l.y * l.y));
+        pre = l + v;
+        other = l;
+    } else if (is_c) {
         RPT_PROF(PB_LOBE_CLEARCOAT);
-        r1 = (r1 - cdf0) / (cdf1 - cdf0);
-        v3 h = sample_gtr1(m.clearcoat_roughness, r1);
+        float a = rmax(0.001f, m.clearcoat_roughness);              // sample_gtr1, tracer.rs:242 (r2 is unused there)
+        float a2 = a * a;
+        float cos_theta = __builtin_sqrtf((1.0f - rpt_powf(a2, 1.0f - r1)) / (1.0f - a2));
+        float sin_theta = clamp01(__builtin_sqrtf(1.0f - (cos_theta * cos_theta)));
+        v3 h = mk3(sin_theta * cs, sin_theta * sn, cos_theta);
         if (h.z < 0.0f) h = -h;
-        l = norm3(reflect3(-v, h));
-        f = eval_clearcoat(m, v, l, h, pdf);
-        pdf *= w.clearcoat;
+        pre = reflect3(-v, h);
+        other = h;
     } else {
         RPT_PROF(PB_LOBE_SPEC);
-        r1 = (r1 - cdf1) / (1.0f - cdf1);
-        v3 h = sample_ggxvndf(v, m.ax, m.ay, r1, r2);
+        v3 vh = norm3(mk3(m.ax * v.x, m.ay * v.y, v.z));            // sample_ggxvndf, tracer.rs:256
+        float lensq = vh.x * vh.x + vh.y * vh.y;
+        v3 t_1 = mk3(1.0f, 0.0f, 0.0f);
+        if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), 1.0f / __builtin_sqrtf(lensq));
+        v3 t_2 = cross3(vh, t_1);
+        float t1 = rs * cs;
+        float t2 = rs * sn;
+        float s = 0.5f * (1.0f + vh.z);
+        t2 = (1.0f - s) * __builtin_sqrtf(1.0f - t1 * t1) + s * t2;
+        v3 nh = t1 * t_1 + t2 * t_2 + __builtin_sqrtf(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
+        v3 h = norm3(mk3(m.ax * nh.x, m.ay * nh.y, rmax(0.0f, nh.z)));
         if (h.z < 0.0f) h = -h;
         float fresnel = disney_fresnel(m, eta, dot3(l_io, h), dot3(v, h));
-        float ff = 1.0f - ((1.0f - fresnel) * m.spec_trans * (1.0f - m.metallic));
+        ff = 1.0f - ((1.0f - fresnel) * m.spec_trans * (1.0f - m.metallic));
         float rnd = rng.gen();
-        if (rnd < ff) {
-            l = norm3(reflect3(-v, h));
-            f = eval_spec_reflection(m, eta, spec_col, v, l, h, pdf);
-            pdf *= ff;
-        } else {
-            l = norm3(refract3(-v, h, eta));
-            f = eval_spec_refraction(m, eta, v, l, h, pdf);
-            pdf *= 1.0f - ff;
-        }
+        reflected = rnd < ff;
+        if (reflected) pre = reflect3(-v, h);
+        else pre = refract3(-v, h, eta);
+        other = h;
+    }
+    const v3 nrm = norm3(pre);                                      // tracer.rs:504, 515, 537 / 542
+    const v3 l = mk3(is_d ? other.x : nrm.x, is_d ? other.y : nrm.y, is_d ? other.z : nrm.z);
+    const v3 h = mk3(is_d ? nrm.x : other.x, is_d ? nrm.y : other.y, is_d ? nrm.z : other.z);
+
+    if (is_d) {
+        RPT_PROF(PB_LOBE_DIFFUSE);
+        f = eval_diffuse(m, sheen_col, v, l, h, pdf);
+        pdf *= w.diffuse;
+    } else if (!reflected) {
+        f = eval_spec_refraction(m, eta, v, l, h, pdf);
+        pdf *= 1.0f - ff;
         pdf *= w.spec_reflect + w.spec_refract;
+    } else {
+        // eval_clearcoat (tracer.rs:404-419) and eval_spec_reflection (tracer.rs:368-382) side by side
+        RPT_PROF(PB_LOBE_SPEC);
+        if (!(l.z <= 0.0f)) {                                       // tracer.rs:370, 406
+            const float vdh = dot3(v, h);
+            const float dfr = dielectric_fresnel(is_c ? vdh : __builtin_fabsf(vdh), is_c ? (1.0f / 1.5f) : eta);
+            float d;                                                // the normal-distribution term
+            float e_v, e_l;                                         // what each Smith term takes the root of
+            v3 fcol;
+            if (is_c) {
+                d = gtr1(h.z, m.clearcoat_roughness);
+                const float a = 0.25f * 0.25f;                      // smithg, tracer.rs:276
+                const float bv = v.z * v.z, bl = l.z * l.z;
+                e_v = a + bv - a * bv;
+                e_l = a + bl - a * bl;
+                const float fc = mixf(0.04f, 1.0f, dfr);
+                fcol = mk3(fc, fc, fc);
+            } else {
+                d = gtr2aniso(h.z, h.x, h.y, m.ax, m.ay);
+                const float av = v.x * m.ax, bv = v.y * m.ay, cv = __builtin_fabsf(v.z);   // smithganiso, tracer.rs:301
+                const float al = l.x * m.ax, bl = l.y * m.ay, cl = __builtin_fabsf(l.z);
+                e_v = av * av + bv * bv + cv * cv;
+                e_l = al * al + bl * bl + cl * cl;
+                const float fm = mixf(dfr, schlick_fresnel(dot3(l, h)), m.metallic);       // disney_fresnel, tracer.rs:435
+                fcol = mix3(spec_col, mk3(1.0f, 1.0f, 1.0f), fm);
+            }
+            const float n_v = is_c ? v.z : __builtin_fabsf(v.z);
+            const float n_l = is_c ? l.z : __builtin_fabsf(l.z);
+            const float g_v = (2.0f * n_v) / (n_v + __builtin_sqrtf(e_v));
+            const float g_l = (2.0f * n_l) / (n_l + __builtin_sqrtf(e_l));
+            const float g = g_v * g_l;                              // clearcoat: smithg(l) * smithg(v); specular: g1 * smithganiso(l)
+            // pdf: clearcoat d * h.z * (1 / (4 vdh)); specular (g1 * d) / (4 v.z)
+            const float q = (is_c ? 1.0f : g_v * d) / (4.0f * (is_c ? vdh : v.z));
+            pdf = is_c ? (d * h.z * q) : q;
+            const float den = 4.0f * l.z * v.z;
+            // value: clearcoat (clearcoat * F * d * g / den) * 0.25; specular ((d * g) * F) / den per channel
+            const float dg = d * g;
+            const float numx = is_c ? (m.clearcoat * fcol.x * d * g) : (dg * fcol.x);
+            const float qx = numx / den;
+            if (is_c) {
+                const float c = qx * 0.25f;
+                f = mk3(c, c, c);
+            } else {
+                f = mk3(qx, (dg * fcol.y) / den, (dg * fcol.z) / den);
+            }
+        }
+        if (is_c) {
+            pdf *= w.clearcoat;
+        } else {
+            pdf *= ff;
+            pdf *= w.spec_reflect + w.spec_refract;
+        }
     }
     l_io = to_world(t, b, n, l);
     return __builtin_fabsf(dot3(n, l_io)) * f;
