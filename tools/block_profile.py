@@ -1,7 +1,7 @@
 """Per-block lane utilisation and time shares of the megakernel (csrc/dev_prof.h).
 
   python tools/block_profile.py build      # here: cross-compile librpt_hip_prof.so (-DRPT_PROFILE_BLOCKS)
-  python tools/block_profile.py [spp]      # on the GPU box: render c2 with it and print the table
+  python tools/block_profile.py [spp] [c2|c4|c5]   # on the GPU box: render that config with it and print the table
 """
 import ctypes as C
 import importlib.util
@@ -27,9 +27,15 @@ import conftest  # noqa: E402
 import torch  # noqa: E402
 
 rpt = conftest.load_package()
+from rust_pathtracer_amd import scenes  # noqa: E402
+
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-w, h = 1920, 1080
-t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
+which = sys.argv[2] if len(sys.argv) > 2 else "c2"
+w, h = (2048, 2048) if which == "c5" else (1920, 1080)
+scene = {"c2": rpt.AnalyticalScene, "c4": scenes.sdf_scene, "c5": lambda: scenes.random_spheres_scene(10000, 16)}[which]()
+t = rpt.Tracer(scene, device=0, seed=1)
+if which == "c4":
+    t.flags = rpt._abi.RPT_RENDER_SDF_INLINE_MARCH         # the counters are in the bounce-granular kernels
 buf = rpt.DeviceColorBuffer(w, h)
 lib = rpt.lib()
 lib.rpt_prof_read.restype = C.c_int
@@ -41,7 +47,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); t.render_n(buf, spp); e1.record(); torch.cuda.synchronize()
 assert lib.rpt_prof_read(out) == 0
 n_samples = w * h * spp
-print("profiled build: %dx%d x %d spp in %.2f ms (%.0f Msamples/s with the counters on)" % (w, h, spp, e0.elapsed_time(e1), n_samples / e0.elapsed_time(e1) / 1e3))
+print("profiled build, %s: %dx%d x %d spp in %.2f ms (%.0f Msamples/s with the counters on)" % (which, w, h, spp, e0.elapsed_time(e1), n_samples / e0.elapsed_time(e1) / 1e3))
 pass_cycles = out[(len(BLOCKS) - 1) * 3 + 2]
 print("%-20s %12s %9s %8s %10s %12s" % ("block", "wave execs", "lanes/64", "share", "execs/smp", "lane-exec/smp"))
 for i, name in enumerate(BLOCKS):
