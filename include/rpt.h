@@ -200,7 +200,11 @@ enum {
     RPT_RENDER_FAST_MATH    = 1u << 1,
     /* Scenes with an SDF object: run the sphere march inside closest_hit / any_hit (one bounce per scheduling
      * step) instead of as a resumable scheduling state of its own.  Same image bit for bit; kept for A/B. */
-    RPT_RENDER_SDF_INLINE_MARCH = 1u << 2
+    RPT_RENDER_SDF_INLINE_MARCH = 1u << 2,
+    /* Large scenes with the uniform grid: run the grid walk as a resumable scheduling state of its own (like the SDF
+     * march) instead of inside closest_hit / any_hit.  Same image bit for bit; measured SLOWER (the walk is bound by
+     * the latency of its dependent loads, not by lane utilisation: DESIGN.md 4b), kept for A/B only. */
+    RPT_RENDER_GRID_RESUMABLE_WALK = 1u << 3
 };
 
 /* ---- context --------------------------------------------------------------- */

@@ -89,6 +89,7 @@ static uint32_t env_lanes(const char* name, long dflt)
 // runs a block.
 static uint32_t shade_threshold() { static const uint32_t v = env_lanes("RPT_SHADE_THRESHOLD", 56); return v; }
 static uint32_t sdf_march_min_lanes() { static const uint32_t v = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8); return v; }
+static uint32_t grid_walk_min_lanes() { static const uint32_t v = env_lanes("RPT_GRID_WALK_MIN_LANES", 8); return v; }
 
 extern "C" {
 
@@ -404,6 +405,8 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : 1u;
     rp.shade_threshold = shade_threshold();
     rp.march_min_lanes = sdf_march_min_lanes();
+    rp.walk_min_lanes = grid_walk_min_lanes();
+    rp.grid_resumable_walk = (flags & RPT_RENDER_GRID_RESUMABLE_WALK) ? 1u : 0u;
     if (rp.rows_local == 0) return RPT_OK;
     const uint32_t tiles_y = (rp.rows_local + 15u) / 16u;
     const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;

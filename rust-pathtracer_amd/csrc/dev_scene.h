@@ -113,6 +113,8 @@ struct RenderParams {
     uint32_t shade_threshold;  // lanes that must be waiting before a wave runs the shading block
     uint32_t march_min_lanes;      // SDF scenes: a wave keeps marching while at least this many lanes are marching
     uint32_t sdf_resumable_march;  // SDF scenes: march as a scheduling state (dev_sdf_path.h) instead of inside closest_hit / any_hit
+    uint32_t walk_min_lanes;       // grid scenes: a wave keeps walking while at least this many lanes are walking
+    uint32_t grid_resumable_walk;  // grid scenes: the DDA walk as a scheduling state (dev_grid_path.h) instead of inside closest_hit / any_hit
 };
 
 }  // namespace rptdev

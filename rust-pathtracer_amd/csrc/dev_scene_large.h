@@ -283,16 +283,11 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
 // accepted planes above.  (rpt_upload_scene refuses tables with 2^28 spheres or more.)
 constexpr uint32_t kNoSphere = 0x0FFFFFFFu;
 
-// Geometry pass of AnalyticalScene::closest_hit + Scene::sample_lights, as in dev_integrator.h, for N spheres.
-RPT_DEV bool closest_geom(const SceneLarge& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e)
+// Geometry pass of AnalyticalScene::closest_hit + Scene::sample_lights, as in dev_integrator.h, for N spheres:
+// the part after the sphere loop (dist / best / hit are the loop's result, however it was run).
+RPT_DEV bool closest_geom_finish(const SceneLarge& sc, const RayD& ray, PathState& ps, float dist, uint32_t best, bool hit, GeomHit& g, EmitterHit& e)
 {
-    float dist = 3.40282347e+38f;
-    bool hit = false;
-    uint32_t best = 0xFFFFFFFFu;                                    // nearest sphere so far
     uint32_t accepted_planes = 0;
-
-    if (sc.use_grid) grid_closest_sphere(sc, ray, dist, best, hit);
-    else brute_closest_sphere(sc, ray, dist, best, hit);
     for (uint32_t k = 0; k < sc.n_planes; ++k) {
         const DevPlane& p = sc.planes[k];
         float t;
@@ -328,6 +323,16 @@ RPT_DEV bool closest_geom(const SceneLarge& sc, const RayD& ray, PathState& ps, 
         }
     }
     return hit;
+}
+
+RPT_DEV bool closest_geom(const SceneLarge& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e)
+{
+    float dist = 3.40282347e+38f;
+    bool hit = false;
+    uint32_t best = 0xFFFFFFFFu;                                    // nearest sphere so far
+    if (sc.use_grid) grid_closest_sphere(sc, ray, dist, best, hit);
+    else brute_closest_sphere(sc, ray, dist, best, hit);
+    return closest_geom_finish(sc, ray, ps, dist, best, hit, g, e);
 }
 
 // material = Material::new(), the nearest sphere's full patch, then the accepted planes' patches in order
@@ -367,8 +372,8 @@ RPT_DEV v3 hit_emission(const SceneLarge& sc, const GeomHit& g)
     return em;
 }
 
-// Surface pass: normal and material of a surface hit at `dist`.
-RPT_DEV void resolve_hit(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi)
+// Normal of a surface hit at `dist`.
+RPT_DEV v3 normal_large(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g)
 {
     const uint32_t best = g.code & kNoSphere;
     const uint32_t accepted_planes = g.code >> 28;
@@ -386,9 +391,13 @@ RPT_DEV void resolve_hit(const SceneLarge& sc, const RayD& ray, float dist, cons
     }
     v3 hp = ray.o + dist * ray.d;
     v3 sn = norm3(hp - c);
-    hi.normal.x = win_plane ? pn.x : sn.x;
-    hi.normal.y = win_plane ? pn.y : sn.y;
-    hi.normal.z = win_plane ? pn.z : sn.z;
+    return mk3(win_plane ? pn.x : sn.x, win_plane ? pn.y : sn.y, win_plane ? pn.z : sn.z);
+}
+
+// Surface pass: normal and material of a surface hit at `dist`.
+RPT_DEV void resolve_hit(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi)
+{
+    hi.normal = normal_large(sc, ray, dist, g);
     material_large(sc, ray, g.code, hi.mat);
 }
 
@@ -404,6 +413,18 @@ RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, H
     if (geom_hit) resolve_hit(sc, ray, e.is_emitter ? stale : ps.hit_dist, g, hi);
     else material_large(sc, ray, g.code, hi.mat);
     return hit;
+}
+
+// any_hit after the sphere part (`occluded` = its answer, however it was obtained)
+RPT_DEV bool any_hit_finish(const SceneLarge& sc, const RayD& ray, float max_dist, bool occluded)
+{
+    bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        float t;
+        bool h = hit_plane(ray, sc.planes[k], t);
+        occluded = occluded || (h && (!use_max || t < max_dist));
+    }
+    return occluded;
 }
 
 RPT_DEV bool any_hit(const SceneLarge& sc, const RayD& ray, float max_dist)

@@ -9,6 +9,7 @@
 #include "dev_integrator.h"
 #include "dev_sdf_path.h"
 #include "dev_scene_large.h"
+#include "dev_grid_path.h"
 #include "launch.h"
 
 // This file is compiled twice: as is (strict arithmetic: -ffp-contract=off, correctly rounded divide/sqrt) and
@@ -323,6 +324,106 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
 
+// Large scenes with the uniform grid, resumable walk (dev_grid_path.h).  Per lane:
+//   WALK_P --(walk over)--> RESOLVE --(miss / emitter)--> FINISH: next sample, WALK_P
+//                                   --(surface)--> WALK_S --(walk over)--> SHADE --> WALK_P / FINISH
+//                                   --(no shadow walk needed)-----------> SHADE
+// Per wave, each pass runs ONE block for the lanes waiting at it: walk steps (one cell per lane per step, primary and
+// shadow walks together) while at least `walk_min_lanes` lanes are walking or nobody waits elsewhere; otherwise the
+// fuller of RESOLVE / SHADE, whose lanes then start new walks next to the stragglers.
+enum : uint32_t { GW_WALK_P = 0u, GW_WALK_S = 1u, GW_RESOLVE = 2u, GW_SHADE = 3u, GW_FINISH = 4u, GW_DONE = 5u };
+
+RPT_DEV void render_large_walk_body(const SceneLarge& sc, const RenderParams& rp)
+{
+    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
+    __shared__ float s_weight[kMaxSppPerLaunch];
+    for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
+        const uint64_t frames = rp.frames_done + i;
+        s_fkey[i] = frame_key_hd(rp.seed, frames);
+        s_weight[i] = 1.0f / (float)(frames + 1);                   // tracer.rs:115
+    }
+    __syncthreads();
+
+    __shared__ float4 s_acc[256];                                   // running mean, tracer.rs:105-117
+    __shared__ float4 s_pix[256];                                   // {coord.x, coord.y, bits(pixel_index), -}
+    const uint32_t tid = threadIdx.x;
+    {
+        const PixelSetup ps = pixel_setup(rp);
+        if (!ps.valid) return;
+        s_acc[tid] = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
+        s_pix[tid] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
+    }
+
+    if (sc.max_depth == 0) {                                        // no bounce loop at all: radiance is zero
+        float4 acc = s_acc[tid];
+        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), s_weight[s]);
+        *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = acc;
+        return;
+    }
+
+    uint32_t s = 0;
+    uint32_t state;
+    PathRegs p;
+    GeomHit g;
+    g.code = 0u;
+    WalkRegs w;
+    {
+        const float4 c = s_pix[tid];
+        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        state = walk_begin_closest(sc, p.ray, w) ? GW_RESOLVE : GW_WALK_P;
+    }
+
+    for (;;) {
+        if (state == GW_FINISH) {                                   // blend, next sample of the pixel (or retire)
+            float4 acc = s_acc[tid];
+            blend(acc, p.radiance, s_weight[s]);
+            s_acc[tid] = acc;
+            s += 1;
+            if (s >= rp.spp) {
+                state = GW_DONE;
+            } else {
+                const float4 c = s_pix[tid];
+                path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                state = walk_begin_closest(sc, p.ray, w) ? GW_RESOLVE : GW_WALK_P;
+            }
+        }
+        const uint32_t n_walk = (uint32_t)__popcll(__ballot(state <= GW_WALK_S));
+        const uint32_t n_resolve = (uint32_t)__popcll(__ballot(state == GW_RESOLVE));
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == GW_SHADE));
+        if (n_walk == 0u && n_resolve == 0u && n_shade == 0u) break;
+
+        const bool waiting = (n_resolve | n_shade) != 0u;
+        if (n_walk >= rp.walk_min_lanes || !waiting) {
+            // walk until too few lanes are left walking (and somebody waits) or nobody walks
+            for (;;) {
+                if (state <= GW_WALK_S) {
+                    if (walk_step(sc, w, state == GW_WALK_S)) state = (state == GW_WALK_P) ? GW_RESOLVE : GW_SHADE;
+                }
+                const uint32_t left = (uint32_t)__popcll(__ballot(state <= GW_WALK_S));
+                if (left == 0u || left < rp.walk_min_lanes) break;
+            }
+        } else if (n_shade >= n_resolve) {
+            if (state == GW_SHADE) {
+                const GridInjectedQuery q{0.0f, 0u, false, w.hit};
+                if (path_shade_full(sc, q, p, g)) state = GW_FINISH;
+                else state = walk_begin_closest(sc, p.ray, w) ? GW_RESOLVE : GW_WALK_P;
+            }
+        } else {
+            if (state == GW_RESOLVE) {
+                const GridInjectedQuery q{w.dist, w.best, w.hit, false};
+                if (path_trace_geom(sc, q, p, g)) state = walk_begin_shadow(sc, p, g, w) ? GW_WALK_S : GW_SHADE;
+                else state = GW_FINISH;
+            }
+        }
+    }
+    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
+}
+
+#ifndef RPT_WALK_WAVES_PER_SIMD
+#define RPT_WALK_WAVES_PER_SIMD 5
+#endif
+__global__ __launch_bounds__(256, RPT_WALK_WAVES_PER_SIMD) void RPT_K(render_large_walk_kernel)(const SceneLarge sc, const RenderParams rp) { render_large_walk_body(sc, rp); }
+
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
 __global__ __launch_bounds__(256) void RPT_K(untile_kernel)(const float4* __restrict__ gathered, float4* __restrict__ image,
                                                      uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
@@ -441,6 +542,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     const bool has_sdf = !large && scs.sdf.n_prims > 0;
     const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
     if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
+    else if (large && scl.use_grid && rp.grid_resumable_walk) hipLaunchKernelGGL(RPT_K(render_large_walk_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);

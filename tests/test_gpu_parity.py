@@ -290,7 +290,8 @@ def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
     s = scenes.random_spheres_scene(n_spheres=n_spheres, n_lights=n_lights, seed=0x5EED0005)
     w, h, spp = 96, 54, 3
     t = rpt.Tracer(s, device=0, seed=5)
-    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+    # default: the grid walk inside the bounce (from 64 spheres up); then the resumable walk; then nested loops
+    for flags in (0, rpt._abi.RPT_RENDER_GRID_RESUMABLE_WALK, rpt._abi.RPT_RENDER_NESTED_LOOPS):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -555,6 +556,12 @@ def test_full_size_config5_frame(rpt, torch_cuda, oracle):
     finally:
         del os.environ["RPT_NO_GRID"]
     assert torch.equal(brute.pixels.view(torch.int32), grid.pixels.view(torch.int32))
+    t.upload_scene()                                       # with the grid again: the walk as a scheduling state
+    t.flags = rpt._abi.RPT_RENDER_GRID_RESUMABLE_WALK
+    walk = rpt.DeviceColorBuffer(w, h)
+    t.render_n(walk, spp)
+    torch.cuda.synchronize()
+    assert torch.equal(walk.pixels.view(torch.int32), grid.pixels.view(torch.int32))
     t.close()
 
 
