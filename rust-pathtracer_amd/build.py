@@ -18,8 +18,11 @@ HEADERS = ["dev_math.h", "dev_prof.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_l
 #   they stay live for the whole kernel: 183 VGPRs (2 waves/SIMD) with it, 115 without.
 # -fno-slp-vectorize: SLP packs scalar f32 ops into v_pk_mul/add_f32, which issue at half rate on
 #   gfx950 and need paired registers: 115 -> 95 VGPRs and +6 % throughput without it.
+# -mllvm -amdgpu-sched-strategy=max-ilp: the machine scheduler interleaves independent chains (the three divides of a
+#   normalize, the three pow of the background) instead of minimising register pressure first: +2 % on configs[1]
+#   and [3] at the same 96 VGPRs (iterative-ilp / iterative-minreg: no gain).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-         "-mllvm", "-disable-machine-licm", "-fPIC"]
+         "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC"]
 
 
 def _hipcc():

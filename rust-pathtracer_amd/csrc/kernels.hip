@@ -1,7 +1,7 @@
 // kernels.hip — every __global__ kernel of the library (gfx950) and the host-side launch wrappers
 // declared in launch.h.  The C ABI lives in capi.hip.
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-licm
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp
 // (build.py).  There is NO CPU fallback anywhere in this library.
 #include <hip/hip_runtime.h>
 
