@@ -105,14 +105,13 @@ __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_kernel)(const Sce
 //  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
 //    PathRegs); when its path ends it blends the sample into its running mean and starts
 //    the next camera path at once (path regeneration);
-//  * a bounce is split into TRACE (closest hit + miss/emitter exits, cheap) and SHADE
-//    (next-event estimation + Disney BSDF sampling, ~3x the instructions).  A lane that
-//    hits a surface parks its SurfaceHit in registers and waits; the wave runs SHADE only
-//    when at least `shade_threshold` lanes are parked (wave ballot + popcount), or nobody
-//    is left to trace.  The expensive block therefore executes with most lanes active,
-//    while the cheap one absorbs the divergence.
-// The per-sample frame key and blend weight 1/(frames+1) are per-lane values now (lanes
-// drift apart in sample index), so the workgroup stages them once in LDS tables.
+//  * a bounce is split into TRACE (the geometry pass of closest_hit + the miss / emitter exits:
+//    what every ray needs) and SHADE (normal, material layering, State::finalize, next-event
+//    estimation, Disney BSDF sampling: what only a surface hit needs, ~5x the instructions).  A lane
+//    that hits a surface parks one dword (GeomHit) and waits; the wave runs SHADE only when at least
+//    `shade_threshold` lanes are parked (wave ballot + popcount), or nobody is left to trace.  The
+//    expensive block therefore executes with most lanes active, while the cheap one absorbs the
+//    divergence.
 constexpr uint32_t kMaxSppPerLaunch = 512;
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd argument of
@@ -124,6 +123,42 @@ constexpr uint32_t kMaxSppPerLaunch = 512;
 #define RPT_SDF_WAVES_PER_SIMD 5
 #endif
 
+// What the three state-machine kernels below share: per-launch tables and cold per-lane state in LDS.
+// The per-sample frame key and blend weight 1/(frames+1) are per-lane values there (lanes drift apart in sample
+// index), so the workgroup stages them once.  The pixel's running mean and its constants are touched only when a
+// sample ends (once per ~2 bounces); in VGPRs the seven registers they would pin are what separates 4 from 5
+// resident waves per SIMD.
+struct LaneTables {
+    uint32_t* fkey;            // [kMaxSppPerLaunch] frame_key(seed, frames_done + s)
+    float* weight;             // [kMaxSppPerLaunch] 1 / (frames_done + s + 1), tracer.rs:115
+    float4* acc;               // [256] running mean, tracer.rs:105-117
+    float4* pix;               // [256] {coord.x, coord.y, bits(pixel_index), -}
+};
+
+// Fills the tables and this lane's slots.  False: the lane has no pixel, or the scene has max_depth == 0 (no bounce
+// loop at all: every sample's radiance is zero and the lane's pixel is finished here) — the caller returns.
+RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderParams& rp)
+{
+    for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
+        const uint64_t frames = rp.frames_done + i;
+        lt.fkey[i] = frame_key_hd(rp.seed, frames);
+        lt.weight[i] = 1.0f / (float)(frames + 1);                  // tracer.rs:115
+    }
+    __syncthreads();
+    const PixelSetup ps = pixel_setup(rp);
+    if (!ps.valid) return false;
+    float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
+    if (max_depth == 0) {
+        float4 acc = *pixel;
+        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), lt.weight[s]);
+        *pixel = acc;
+        return false;
+    }
+    lt.acc[threadIdx.x] = *pixel;
+    lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
+    return true;
+}
+
 enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u };
 
 template <class S>
@@ -132,32 +167,10 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     RPT_PROF_INIT();
     __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
-    for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
-        const uint64_t frames = rp.frames_done + i;
-        s_fkey[i] = frame_key_hd(rp.seed, frames);
-        s_weight[i] = 1.0f / (float)(frames + 1);                   // tracer.rs:115
-    }
-    __syncthreads();
-
-    // Cold per-lane state lives in LDS, not in VGPRs: the pixel's running mean and its
-    // constants are touched only when a sample ends (once per ~2 bounces), and the seven
-    // registers they would pin are what separates 4 from 5 resident waves per SIMD.
-    __shared__ float4 s_acc[256];                                   // running mean, tracer.rs:105-117
-    __shared__ float4 s_pix[256];                                   // {coord.x, coord.y, bits(pixel_index), -}
+    __shared__ float4 s_acc[256];
+    __shared__ float4 s_pix[256];
     const uint32_t tid = threadIdx.x;
-    {
-        const PixelSetup ps = pixel_setup(rp);
-        if (!ps.valid) return;
-        s_acc[tid] = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
-        s_pix[tid] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
-    }
-
-    if (sc.max_depth == 0) {                                        // no bounce loop at all: radiance is zero
-        float4 acc = s_acc[tid];
-        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), s_weight[s]);
-        *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = acc;
-        return;
-    }
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = ST_TRACE;
@@ -227,30 +240,11 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
 {
     __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
-    for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
-        const uint64_t frames = rp.frames_done + i;
-        s_fkey[i] = frame_key_hd(rp.seed, frames);
-        s_weight[i] = 1.0f / (float)(frames + 1);                   // tracer.rs:115
-    }
-    __syncthreads();
-
-    __shared__ float4 s_acc[256];                                   // running mean, tracer.rs:105-117
-    __shared__ float4 s_pix[256];                                   // {coord.x, coord.y, bits(pixel_index), -}
+    __shared__ float4 s_acc[256];
+    __shared__ float4 s_pix[256];
     __shared__ float4 s_hit[256];                                   // parked SurfaceHitCold {fhp, eta}
     const uint32_t tid = threadIdx.x;
-    {
-        const PixelSetup ps = pixel_setup(rp);
-        if (!ps.valid) return;
-        s_acc[tid] = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
-        s_pix[tid] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
-    }
-
-    if (sc.max_depth == 0) {                                        // no bounce loop at all: radiance is zero
-        float4 acc = s_acc[tid];
-        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), s_weight[s]);
-        *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = acc;
-        return;
-    }
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = SM_MARCH_P;
@@ -337,29 +331,10 @@ RPT_DEV void render_large_walk_body(const SceneLarge& sc, const RenderParams& rp
 {
     __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
-    for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
-        const uint64_t frames = rp.frames_done + i;
-        s_fkey[i] = frame_key_hd(rp.seed, frames);
-        s_weight[i] = 1.0f / (float)(frames + 1);                   // tracer.rs:115
-    }
-    __syncthreads();
-
-    __shared__ float4 s_acc[256];                                   // running mean, tracer.rs:105-117
-    __shared__ float4 s_pix[256];                                   // {coord.x, coord.y, bits(pixel_index), -}
+    __shared__ float4 s_acc[256];
+    __shared__ float4 s_pix[256];
     const uint32_t tid = threadIdx.x;
-    {
-        const PixelSetup ps = pixel_setup(rp);
-        if (!ps.valid) return;
-        s_acc[tid] = *(reinterpret_cast<const float4*>(rp.pixels) + ps.pix_offset);
-        s_pix[tid] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
-    }
-
-    if (sc.max_depth == 0) {                                        // no bounce loop at all: radiance is zero
-        float4 acc = s_acc[tid];
-        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), s_weight[s]);
-        *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = acc;
-        return;
-    }
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
 
     uint32_t s = 0;
     uint32_t state;
