@@ -3,8 +3,10 @@
 
 One "step" = one pass of the hot path over one batch: `SPP` (256) consecutive
 Tracer::render() calls folded into one launch over the whole frame, on a frame that is
-already resident in HBM; for N > 1 the step ends with the RCCL all-gather of the per-rank
-row tiles (the image is row-tiled across the GPUs; ranks exchange nothing while rendering).
+already resident in HBM; for N > 1 every step's per-rank row tiles are all-gathered over RCCL
+(the image is row-tiled across the GPUs; ranks exchange nothing while rendering) and scattered into
+the full image on every rank.  The gather of step k runs on RCCL's stream while step k+1 renders
+(TiledRender.gather_begin / gather_end); all K gathers complete inside the timed region.
 
 N = 1 workload = BASELINE.json configs[1]: AnalyticalScene 1920x1080, 256 spp, f32.
 N > 1 is WEAK scaling: the same view at round(1920*sqrt(N)) x round(1080*sqrt(N)) pixels
@@ -131,6 +133,9 @@ def main():
         job.render_n(SPP)
         return job.gather() if world > 1 else None
 
+    def finish_gather(pending):
+        return job.gather_end(pending) if pending is not None else None
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -142,6 +147,7 @@ def main():
     kernel_ms = []
     evs = []
     t0 = time.perf_counter()
+    pending = None
     for _ in range(args.steps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()                         # torch's current stream == the stream the kernel is launched on
@@ -149,7 +155,9 @@ def main():
         e1.record()
         evs.append((e0, e1))
         if world > 1:
-            job.gather()
+            finish_gather(pending)          # the previous step's gather ran while this step rendered
+            pending = job.gather_begin()
+    finish_gather(pending)
     fence()
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in evs]

@@ -75,6 +75,8 @@ class TiledRender:
         self.device = device if device is not None else torch.device("cuda", tracer.device)
         self.tile = torch.zeros(self.rows_padded, width, 4, dtype=torch.float32, device=self.device)
         self.frames = 0
+        self._snapshot = None       # gather_begin: the tile as it was when the gather was requested
+        self._gathered = None       # all-gather destination, [world * rows_padded, width, 4]
 
     def render_n(self, spp):
         self.tracer.render_tile(self.tile, self.width, self.height, self.frames, spp, self.tile_rows, self.rank, self.world)
@@ -85,5 +87,22 @@ class TiledRender:
         if self.world == 1:
             return self.tile[: self.height].clone() if self.rows == self.height else untile(
                 self.tile.unsqueeze(0), self.width, self.height, self.tile_rows, 1, self.tracer)
-        out = all_gather_tiles(self.tile, self.world, self.group)
+        return self.gather_end(self.gather_begin())
+
+    def gather_begin(self):
+        """Start the all-gather of the tile as it is NOW and return a handle for gather_end().  The collective runs on
+        the process group's own stream (RCCL over xGMI), so render_n() calls issued before gather_end() overlap with it;
+        the tile is snapshotted first (one device-to-device copy) because the next render_n() updates it in place.
+        At most one gather is in flight: call gather_end() before the next gather_begin()."""
+        assert self.world > 1
+        if self._snapshot is None:
+            self._snapshot = torch.empty_like(self.tile)
+            self._gathered = torch.empty((self.world * self.rows_padded, self.width, 4), dtype=torch.float32, device=self.device)
+        self._snapshot.copy_(self.tile)
+        return self.dist.all_gather_into_tensor(self._gathered, self._snapshot, group=self.group, async_op=True)
+
+    def gather_end(self, work):
+        """Wait for gather_begin()'s collective (a stream-level wait on device tensors) and scatter the tiles into the image."""
+        work.wait()
+        out = self._gathered.view(self.world, self.rows_padded, self.width, 4)
         return untile(out, self.width, self.height, self.tile_rows, self.world, self.tracer)

@@ -25,6 +25,14 @@ def test_single_rank_rccl_gather_matches_plain_render(rpt):
         dist.barrier()
         gathered = tiling.all_gather_tiles(job.tile, 1)            # RCCL all-gather on the device tile
         img = tiling.untile(gathered, w, h, 2, 1, tracer)
+        # the pipelined form bench.py uses: begin, render the next step into the tile, end -> the image of the step it
+        # was begun for
+        job._snapshot = torch.empty_like(job.tile)
+        job._gathered = torch.empty((job.rows_padded, w, 4), dtype=torch.float32, device=job.device)
+        job._snapshot.copy_(job.tile)
+        work = dist.all_gather_into_tensor(job._gathered, job._snapshot, async_op=True)
+        job.render_n(2)                                            # overlaps with the collective, updates the tile in place
+        img_async = job.gather_end(work)
         t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         torch.cuda.synchronize()
@@ -34,6 +42,7 @@ def test_single_rank_rccl_gather_matches_plain_render(rpt):
         torch.cuda.synchronize()
         a, b = img.cpu().numpy(), buf.pixels.cpu().numpy()
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(img_async.cpu().numpy().view(np.uint32), b.view(np.uint32))
         tracer.close()
     finally:
         dist.destroy_process_group()
