@@ -1,8 +1,11 @@
 // rpt_oracle.hpp — CPU restatement of rust-pathtracer's per-pixel-sample path.
 //
 // TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
-// and bench.py's cpu_baseline leg may build, load or call anything under oracle/.
-// The shipped path (rust-pathtracer_amd/csrc/) never includes this file.
+// and bench.py's cpu_baseline leg may build, load or call anything under oracle/
+// (plus the development scripts under tools/ that generate fixtures, time the CPU
+// baseline or replay path events through schedule simulations; the package never
+// imports tools/).  The shipped path (rust-pathtracer_amd/) never includes,
+// links or loads anything from here, and has no CPU fallback.
 //
 // PARITY UNPINNED: the reference (/root/reference, crate v0.2.4) ships no tests,
 // golden vectors or fixtures, cannot be compiled here (no Rust toolchain), and its

@@ -4,6 +4,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp
 // (build.py).  There is NO CPU fallback anywhere in this library.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "../../include/rpt.h"
 #include "dev_integrator.h"
@@ -523,7 +524,12 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), dim3(nblocks), dim3(256), 0, st, sc, rp);
-    else hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), dim3(nblocks), dim3(256), 0, st, sc, rp);
+    else {
+        // RPT_DEBUG_EXTRA_LDS (bytes, experiments only): pads the workgroup's LDS so that fewer waves fit a CU — how the
+        // kernel's throughput depends on resident waves per SIMD (occupancy sensitivity)
+        static const unsigned extra_lds = getenv("RPT_DEBUG_EXTRA_LDS") ? (unsigned)atoi(getenv("RPT_DEBUG_EXTRA_LDS")) : 0u;
+        hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), dim3(nblocks), dim3(256), extra_lds, st, sc, rp);
+    }
     return hipGetLastError();
 }
 
