@@ -246,21 +246,33 @@ RPT_DEV bool sample_lights_small(const SceneSmall& sc, const RayD& ray, PathStat
 
 // Geometry pass of AnalyticalScene::closest_hit (analytical.rs:36-127) + Scene::sample_lights
 // (scene.rs:36-86) over the tables: who was hit and how far; no normal, no material.
+// The spheres-then-planes result when it was computed earlier (the march kernel needs it before the march, to know
+// how far the march has to look): nearest accepted distance and the accepted mask.
+struct AnalyticPre {
+    float dist;
+    uint32_t accepted;
+};
+
 template <bool SDF>
 RPT_DEV bool closest_geom_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e,
-                                const SdfMarchResult* pre = nullptr)
+                                const SdfMarchResult* pre = nullptr, const AnalyticPre* apre = nullptr)
 {
-    AnalyticHit a;
-    analytic_closest(sc, ray, a);
-    float dist = a.dist;
-    bool hit = a.hit;
-    uint32_t accepted = a.accepted;
+    float dist;
+    bool hit;
+    uint32_t accepted;
+    if (apre) {
+        dist = apre->dist; accepted = apre->accepted; hit = accepted != 0u;
+    } else {
+        AnalyticHit a;
+        analytic_closest(sc, ray, a);
+        dist = a.dist; hit = a.hit; accepted = a.accepted;
+    }
     if (SDF) {                                                      // the SDF object, tested last
         float t;
         const bool first = (sc.n_spheres == 0 && sc.n_planes == 0);
         bool h;
         if (pre) { h = pre->hit; t = pre->t; }
-        else h = sdf_march(*sdf, ray, sdf_primary_t_useful(sc, a), t);
+        else h = sdf_march(*sdf, ray, first ? __builtin_inff() : dist, t);   // sdf_primary_t_useful
         bool acc = h && (first || t < dist);
         if (acc) {
             dist = t;
@@ -305,9 +317,9 @@ RPT_DEV v3 emission_small(const SceneSmall& sc, const DevSdf* sdf, uint32_t acce
 }
 
 // Surface pass: normal (only the final one: the reference also computes the normals of
-// accepted-then-superseded primitives, which nothing reads) and material of a surface hit at ps.hit_dist.
+// accepted-then-superseded primitives, which nothing reads) of a surface hit at `dist`.
 template <bool SDF>
-RPT_DEV void resolve_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, float dist, uint32_t accepted, HitInfo& hi)
+RPT_DEV v3 normal_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, float dist, uint32_t accepted)
 {
     v3 c = mk3(0.0f, 0.0f, 0.0f), pn = mk3(0.0f, 0.0f, 0.0f);
     for (uint32_t i = 0; i < sc.n_spheres; ++i) {
@@ -327,9 +339,14 @@ RPT_DEV void resolve_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& 
     if (SDF && win_sdf) sn = sdf_normal(*sdf, hp);
     else sn = norm3(hp - c);
     const bool use_pn = win_plane && !win_sdf;
-    hi.normal.x = use_pn ? pn.x : sn.x;                             // (per component: a struct select goes through scratch)
-    hi.normal.y = use_pn ? pn.y : sn.y;
-    hi.normal.z = use_pn ? pn.z : sn.z;
+    return mk3(use_pn ? pn.x : sn.x, use_pn ? pn.y : sn.y, use_pn ? pn.z : sn.z);   // (per component: a struct select goes through scratch)
+}
+
+// ... and its material.
+template <bool SDF>
+RPT_DEV void resolve_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, float dist, uint32_t accepted, HitInfo& hi)
+{
+    hi.normal = normal_small<SDF>(sc, sdf, ray, dist, accepted);
     material_small<SDF>(sc, sdf, ray, accepted, hi.mat);
 }
 
@@ -367,8 +384,10 @@ RPT_DEV bool closest_geom(const SceneSmall& sc, const RayD& ray, PathState& ps, 
 RPT_DEV bool closest_geom(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) { return closest_geom_small<true>(sc, &sc.sdf, ray, ps, g, e); }
 RPT_DEV v3 hit_emission(const SceneSmall& sc, const GeomHit& g) { return emission_small<false>(sc, nullptr, g.code); }
 RPT_DEV v3 hit_emission(const SceneSmallSdf& sc, const GeomHit& g) { return emission_small<true>(sc, &sc.sdf, g.code); }
-RPT_DEV void resolve_hit(const SceneSmall& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi) { resolve_small<false>(sc, nullptr, ray, dist, g.code, hi); }
-RPT_DEV void resolve_hit(const SceneSmallSdf& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi) { resolve_small<true>(sc, &sc.sdf, ray, dist, g.code, hi); }
+RPT_DEV v3 hit_normal(const SceneSmall& sc, const RayD& ray, float dist, const GeomHit& g) { return normal_small<false>(sc, nullptr, ray, dist, g.code); }
+RPT_DEV v3 hit_normal(const SceneSmallSdf& sc, const RayD& ray, float dist, const GeomHit& g) { return normal_small<true>(sc, &sc.sdf, ray, dist, g.code); }
+RPT_DEV void hit_material(const SceneSmall& sc, const RayD& ray, const GeomHit& g, Mat& mat) { material_small<false>(sc, nullptr, ray, g.code, mat); }
+RPT_DEV void hit_material(const SceneSmallSdf& sc, const RayD& ray, const GeomHit& g, Mat& mat) { material_small<true>(sc, &sc.sdf, ray, g.code, mat); }
 
 // AnalyticalScene::any_hit (analytical.rs:130-145); it ignores max_dist unless the
 // scene opts in.
@@ -689,26 +708,28 @@ RPT_DEV bool path_trace_geom(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
 }
 
 // Returns true when the path is over (pdf <= 0 or depth exhausted).
+// `n_pre`: the normal when the caller already has it (the march kernel needs it before the shadow march); `cold`: the
+// hit point parked in LDS when p.ray.o no longer holds the path's origin (the march kernel lends it to the shadow
+// march).  Both null: everything is rebuilt from the unchanged ray and p.ps.hit_dist.
 template <class S, class Q>
-RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit& g)
+RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit& g, const v3* n_pre = nullptr, const volatile float4* cold = nullptr)
 {
     Mat mat;
     v3 ffnormal;
     float eta;
     {
         RPT_PROF(PB_FINALIZE);
-        HitInfo hi;
-        resolve_hit(sc, p.ray, p.ps.hit_dist, g, hi);
+        const v3 normal = n_pre ? *n_pre : hit_normal(sc, p.ray, p.ps.hit_dist, g);
+        hit_material(sc, p.ray, g, mat);
         // State::finalize, globals.rs:50-62
-        float ndd = dot3(hi.normal, p.ray.d);
+        float ndd = dot3(normal, p.ray.d);
         const bool front = (ndd <= 0.0f);
-        ffnormal = mk3(front ? hi.normal.x : -hi.normal.x, front ? hi.normal.y : -hi.normal.y, front ? hi.normal.z : -hi.normal.z);
-        mat_finalize(hi.mat);
-        eta = (ndd < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
-        mat = hi.mat;
+        ffnormal = mk3(front ? normal.x : -normal.x, front ? normal.y : -normal.y, front ? normal.z : -normal.z);
+        mat_finalize(mat);
+        eta = (ndd < 0.0f) ? (1.0f / mat.ior) : mat.ior;
         p.radiance = p.radiance + mat.emission * p.throughput;                              // tracer.rs:74
     }
-    const v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
+    const v3 fhp = cold ? mk3(cold->x, cold->y, cold->z) : (p.ray.o + p.ps.hit_dist * p.ray.d);
     ShadeFrame fr;
     { RPT_PROF(PB_FRAME); fr = make_frame(mat, eta, -p.ray.d, ffnormal); }
     p.radiance = p.radiance + direct_light(sc, q, mat, eta, fr, fhp, ffnormal, p.rng) * p.throughput;
@@ -721,8 +742,9 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
     if (!(pdf > 0.0f)) return true;
     RPT_PROF(PB_SAMPLE_TAIL);
     p.throughput = p.throughput * divs3(f, pdf);
-    // the hit point again (not kept across the BSDF code), from the old ray, before the direction changes
-    p.ray.o = (p.ray.o + p.ps.hit_dist * p.ray.d) + sc.eps * scatter_l;
+    // the hit point again (not kept across the BSDF code): from LDS, or from the old ray before the direction changes
+    const v3 fhp2 = cold ? mk3(cold->x, cold->y, cold->z) : (p.ray.o + p.ps.hit_dist * p.ray.d);
+    p.ray.o = fhp2 + sc.eps * scatter_l;
     p.ray.d = scatter_l;
     p.bounce += 1;
     return p.bounce >= sc.max_depth;

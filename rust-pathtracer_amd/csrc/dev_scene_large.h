@@ -394,7 +394,8 @@ RPT_DEV v3 normal_large(const SceneLarge& sc, const RayD& ray, float dist, const
     return mk3(win_plane ? pn.x : sn.x, win_plane ? pn.y : sn.y, win_plane ? pn.z : sn.z);
 }
 
-// Surface pass: normal and material of a surface hit at `dist`.
+RPT_DEV v3 hit_normal(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g) { return normal_large(sc, ray, dist, g); }
+RPT_DEV void hit_material(const SceneLarge& sc, const RayD& ray, const GeomHit& g, Mat& mat) { material_large(sc, ray, g.code, mat); }
 RPT_DEV void resolve_hit(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi)
 {
     hi.normal = normal_large(sc, ray, dist, g);

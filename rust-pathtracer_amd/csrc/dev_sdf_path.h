@@ -21,6 +21,7 @@ struct MarchRegs {
     v3 d;                      // direction being marched (the path's for a closest_hit march, the light's for a shadow march)
     float t, t_useful;
     uint32_t steps;
+    uint32_t accepted;         // closest_hit march: the analytic primitives accepted before the march (analytic_closest)
     bool hit;
 };
 
@@ -47,6 +48,11 @@ RPT_DEV bool march_step(const DevSdf& sd, v3 origin, MarchRegs& m)
 // Scene queries answered from a finished march.
 struct SdfInjectedQuery {
     SdfMarchResult r;
+    AnalyticPre a;             // closest_hit: what march_begin_primary found among the analytic primitives
+    RPT_DEV bool geom(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) const
+    {
+        return closest_geom_small<true>(sc, &sc.sdf, ray, ps, g, e, &r, &a);
+    }
     RPT_DEV bool closest(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, HitInfo& hi) const
     {
         return closest_hit_small<true>(sc, &sc.sdf, ray, ps, hi, &r);
@@ -63,7 +69,12 @@ RPT_DEV void march_begin_primary(const SceneSmallSdf& sc, const PathRegs& p, Mar
     AnalyticHit a;
     analytic_closest(sc, p.ray, a);
     march_begin(m, p.ray.d, sdf_primary_t_useful(sc, a));
+    m.accepted = a.accepted;
 }
+
+// The analytic part of closest_hit as march_begin_primary left it.  (With no analytic primitive t_useful is +inf
+// where analytic_closest says F::MAX; closest_geom_small does not read the distance in that case.)
+RPT_DEV AnalyticPre march_analytic(const MarchRegs& m) { return AnalyticPre{m.t_useful, m.accepted}; }
 
 // After a surface hit: find out whether next-event estimation will march a shadow ray, without
 // consuming the path's random numbers (SHADE replays the same draws from p.rng).  Returns true when a

@@ -235,22 +235,25 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_rege
 // Measured on configs[3] (MI355X): min lanes 1: 1.81, 2: 2.11, 4: 2.28, 8: 2.31, 16: 2.01, 32: 1.63
 // Gsamples/s; the bounce-granular kernel: 1.97.  (A policy with RESOLVE/SHADE waiting rooms that fire when
 // 24 lanes wait, as in the regeneration kernel, is slower than bounce-granular: three rooms dilute 64 lanes.)
-enum : uint32_t { SM_MARCH_P = 0u, SM_MARCH_S = 1u, SM_RESOLVE = 2u, SM_SHADE = 3u, SM_DONE = 4u };
+enum : uint32_t { SM_MARCH_P = 0u, SM_MARCH_S = 1u, SM_RESOLVE = 2u, SM_SHADE = 3u, SM_DONE = 4u, SM_FINISH = 5u };
 
 RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& rp)
 {
+    RPT_PROF_INIT();
     __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
-    __shared__ float4 s_hit[256];                                   // parked SurfaceHitCold {fhp, eta}
+    __shared__ float4 s_hit[256];                                   // parked hit point (the shadow march borrows p.ray.o)
     const uint32_t tid = threadIdx.x;
     if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = SM_MARCH_P;
     PathRegs p;
-    SurfaceHit sh;
+    GeomHit g;                                                      // what a lane parks between RESOLVE and SHADE: the accepted
+    g.code = 0u;                                                    // mask, the normal (RESOLVE needs it for the shadow ray) and,
+    v3 normal = mk3(0.0f, 0.0f, 0.0f);                              // in LDS, the hit point
     MarchRegs m;
     {
         const float4 c = s_pix[tid];
@@ -258,23 +261,23 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
         march_begin_primary(sc, p, m);
     }
 
-    // blend the finished sample into the running mean and start the next one (or retire)
-    auto finish_sample = [&]() {
-        float4 acc = s_acc[tid];
-        blend(acc, p.radiance, s_weight[s]);
-        s_acc[tid] = acc;
-        s += 1;
-        if (s >= rp.spp) {
-            state = SM_DONE;
-        } else {
-            const float4 c = s_pix[tid];
-            path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
-            march_begin_primary(sc, p, m);
-            state = SM_MARCH_P;
-        }
-    };
-
     for (;;) {
+        RPT_PROF(PB_PASS);
+        if (state == SM_FINISH) {                                   // blend, next sample of the pixel (or retire)
+            RPT_PROF(PB_FINISH);
+            float4 acc = s_acc[tid];
+            blend(acc, p.radiance, s_weight[s]);
+            s_acc[tid] = acc;
+            s += 1;
+            if (s >= rp.spp) {
+                state = SM_DONE;
+            } else {
+                const float4 c = s_pix[tid];
+                path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                march_begin_primary(sc, p, m);
+                state = SM_MARCH_P;
+            }
+        }
         const uint64_t w_march = __ballot(state <= SM_MARCH_S);
         const uint32_t n_resolve = (uint32_t)__popcll(__ballot(state == SM_RESOLVE));
         const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == SM_SHADE));
@@ -286,6 +289,7 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
             // march until too few lanes are left marching (and somebody waits) or nobody marches
             for (;;) {
                 if (state <= SM_MARCH_S) {
+                    RPT_PROF(PB_CLOSEST);                              // (block profile: one march step of the wave)
                     if (march_step(sc.sdf, p.ray.o, m)) state = (state == SM_MARCH_P) ? SM_RESOLVE : SM_SHADE;
                 }
                 const uint32_t left = (uint32_t)__popcll(__ballot(state <= SM_MARCH_S));
@@ -293,9 +297,10 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
             }
         } else if (n_shade >= n_resolve) {
             if (state == SM_SHADE) {
-                const SdfInjectedQuery q{{m.hit, m.t}};
-                if (path_shade(sc, q, p, sh, &s_hit[tid])) {
-                    finish_sample();
+                RPT_PROF(PB_SHADE);
+                const SdfInjectedQuery q{{m.hit, m.t}, {0.0f, 0u}};
+                if (path_shade_full(sc, q, p, g, &normal, &s_hit[tid])) {
+                    state = SM_FINISH;
                 } else {
                     march_begin_primary(sc, p, m);
                     state = SM_MARCH_P;
@@ -303,17 +308,22 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
             }
         } else {
             if (state == SM_RESOLVE) {
-                const SdfInjectedQuery q{{m.hit, m.t}};
-                SurfaceHitCold shc;
-                if (path_trace(sc, q, p, sh, shc)) {
-                    s_hit[tid] = make_float4(shc.fhp.x, shc.fhp.y, shc.fhp.z, shc.eta);
-                    state = march_begin_shadow(sc, p, shc.fhp, sh.ffnormal, m) ? SM_MARCH_S : SM_SHADE;
+                RPT_PROF(PB_TRACE);
+                const SdfInjectedQuery q{{m.hit, m.t}, march_analytic(m)};
+                if (path_trace_geom(sc, q, p, g)) {
+                    normal = hit_normal(sc, p.ray, p.ps.hit_dist, g);
+                    const bool front = (dot3(normal, p.ray.d) <= 0.0f);             // State::finalize, globals.rs:53-57
+                    const v3 ffnormal = mk3(front ? normal.x : -normal.x, front ? normal.y : -normal.y, front ? normal.z : -normal.z);
+                    const v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
+                    s_hit[tid] = make_float4(fhp.x, fhp.y, fhp.z, 0.0f);
+                    state = march_begin_shadow(sc, p, fhp, ffnormal, m) ? SM_MARCH_S : SM_SHADE;
                 } else {
-                    finish_sample();
+                    state = SM_FINISH;
                 }
             }
         }
     }
+    RPT_PROF_FLUSH();
     *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
 }
 
