@@ -204,7 +204,11 @@ enum {
     /* Large scenes with the uniform grid: run the grid walk as a resumable scheduling state of its own (like the SDF
      * march) instead of inside closest_hit / any_hit.  Same image bit for bit; measured SLOWER (the walk is bound by
      * the latency of its dependent loads, not by lane utilisation: DESIGN.md 4b), kept for A/B only. */
-    RPT_RENDER_GRID_RESUMABLE_WALK = 1u << 3
+    RPT_RENDER_GRID_RESUMABLE_WALK = 1u << 3,
+    /* Scenes with an SDF object: lanes submit their marches to a workgroup-wide queue in LDS that all four waves serve
+     * (dev_sdf_pool.h) instead of marching their own ray.  Same image bit for bit; measured SLOWER (1.5 vs 2.2
+     * Gsamples/s: DESIGN.md 4b), kept for A/B only. */
+    RPT_RENDER_SDF_POOL_MARCH = 1u << 4
 };
 
 /* ---- context --------------------------------------------------------------- */

@@ -42,6 +42,7 @@ RPT_RENDER_NESTED_LOOPS = 1 << 0
 RPT_RENDER_FAST_MATH = 1 << 1
 RPT_RENDER_SDF_INLINE_MARCH = 1 << 2
 RPT_RENDER_GRID_RESUMABLE_WALK = 1 << 3
+RPT_RENDER_SDF_POOL_MARCH = 1 << 4
 
 RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG = range(7)
 

@@ -89,6 +89,10 @@ static uint32_t env_lanes(const char* name, long dflt)
 // runs a block.
 static uint32_t shade_threshold() { static const uint32_t v = env_lanes("RPT_SHADE_THRESHOLD", 56); return v; }
 static uint32_t sdf_march_min_lanes() { static const uint32_t v = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8); return v; }
+static uint32_t sdf_pool_shade_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_SHADE_LANES", 48); return v; }
+static uint32_t sdf_pool_resolve_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_RESOLVE_LANES", 16); return v; }
+static uint32_t sdf_pool_min_batch() { static const uint32_t v = env_lanes("RPT_SDF_POOL_MIN_BATCH", 32); return v; }
+static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_POOL_PATIENCE") ? (uint32_t)atoi(getenv("RPT_SDF_POOL_PATIENCE")) : 8u; return v; }
 static uint32_t grid_walk_min_lanes() { static const uint32_t v = env_lanes("RPT_GRID_WALK_MIN_LANES", 8); return v; }
 
 extern "C" {
@@ -402,7 +406,11 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
     rp.seed = seed;
     rp.tiles_x = (width + 15u) / 16u;
-    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : 1u;
+    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : ((flags & RPT_RENDER_SDF_POOL_MARCH) ? 2u : 1u);
+    rp.pool_shade_lanes = sdf_pool_shade_lanes();
+    rp.pool_resolve_lanes = sdf_pool_resolve_lanes();
+    rp.pool_min_batch = sdf_pool_min_batch();
+    rp.pool_patience = sdf_pool_patience();
     rp.shade_threshold = shade_threshold();
     rp.march_min_lanes = sdf_march_min_lanes();
     rp.walk_min_lanes = grid_walk_min_lanes();

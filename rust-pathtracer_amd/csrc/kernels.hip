@@ -9,6 +9,7 @@
 #include "../../include/rpt.h"
 #include "dev_integrator.h"
 #include "dev_sdf_path.h"
+#include "dev_sdf_pool.h"
 #include "dev_scene_large.h"
 #include "dev_grid_path.h"
 #include "launch.h"
@@ -329,6 +330,144 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
 
+// SDF scenes, workgroup-wide march pool (dev_sdf_pool.h): the lane states are those of the march kernel above, but a
+// lane in MARCH_P / MARCH_S has SUBMITTED its march and only polls for the answer; the marching itself is done by
+// whichever lanes of the workgroup are serving the queue.  Per pass a wave either runs one of its own blocks — when
+// `pool_block_lanes` lanes wait at it, or when there is no march work left to do meanwhile — or serves the queue.
+RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& rp)
+{
+    RPT_PROF_INIT();
+    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
+    __shared__ float s_weight[kMaxSppPerLaunch];
+    __shared__ float4 s_acc[256];
+    __shared__ float4 s_pix[256];
+    __shared__ MarchPool pool;
+    pool_init(pool);                                                // (lane_setup has the barrier)
+    const uint32_t tid = threadIdx.x;
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+
+    uint32_t s = 0;
+    uint32_t state = SM_MARCH_P;
+    PathRegs p;
+    GeomHit g;
+    g.code = 0u;
+    v3 normal = mk3(0.0f, 0.0f, 0.0f);
+    MarchRegs m;                                                    // the lane's own march: what RESOLVE / SHADE need of it
+    MarchJob job;                                                   // the march the lane is stepping for the workgroup
+    job.owner = kPoolEmpty;
+    uint32_t patience = 0;
+    {
+        const float4 c = s_pix[tid];
+        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        pool_begin_primary(pool, sc, p, m);
+    }
+
+    // Every wait in here is bounded (pool_take's spin, this pass count): a lost request must show up as a wrong image
+    // in the parity tests, never as a wave that does not end.
+    for (uint32_t pass = 0; pass < (1u << 22); ++pass) {
+        RPT_PROF(PB_PASS);
+        if (state == SM_FINISH) {                                   // blend, next sample of the pixel (or retire)
+            RPT_PROF(PB_FINISH);
+            float4 acc = s_acc[tid];
+            blend(acc, p.radiance, s_weight[s]);
+            s_acc[tid] = acc;
+            s += 1;
+            if (s >= rp.spp) {
+                state = SM_DONE;
+            } else {
+                const float4 c = s_pix[tid];
+                path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                pool_begin_primary(pool, sc, p, m);
+                state = SM_MARCH_P;
+            }
+        }
+        if (state <= SM_MARCH_S && pool_poll(pool, tid, m)) state = (state == SM_MARCH_P) ? SM_RESOLVE : SM_SHADE;
+        const uint32_t n_march = (uint32_t)__popcll(__ballot(state <= SM_MARCH_S));
+        const uint32_t n_resolve = (uint32_t)__popcll(__ballot(state == SM_RESOLVE));
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == SM_SHADE));
+        if (n_march == 0u && n_resolve == 0u && n_shade == 0u) {    // every pixel of the wave is finished
+            pool_put_back(pool, job);
+            break;
+        }
+        // What to do this pass.  SHADE is the expensive block (~4x RESOLVE): it waits for `pool_shade_lanes` lanes, RESOLVE
+        // for `pool_resolve_lanes`; until then the wave serves the queue — but only when it can fill `pool_min_batch` lanes
+        // with jobs: a sleeping wave costs the SIMD nothing (other workgroups' waves issue), a quarter-full one does.  After
+        // `pool_patience` idle passes it takes whatever there is, so the tail of a tile always drains.
+        const uint32_t have = (uint32_t)__popcll(__ballot(job.owner != kPoolEmpty));
+        const uint32_t avail = pool_avail(pool);
+        const bool patient = patience < rp.pool_patience;
+        uint32_t action;                                            // 0 sleep, 1 serve, 2 SHADE, 3 RESOLVE
+        if (rp.pool_patience == 0u) {
+            // the wave kernel's rule: march while enough of the wave's own marches are outstanding, else the fuller block
+            const bool waiting = (n_resolve | n_shade) != 0u;
+            if (n_march >= rp.march_min_lanes || !waiting) action = (have + avail != 0u) ? 1u : 0u;
+            else action = (n_shade >= n_resolve) ? 2u : 3u;
+        } else
+        if (n_shade >= rp.pool_shade_lanes) action = 2u;
+        else if (n_resolve >= rp.pool_resolve_lanes) action = 3u;
+        else if (have + avail >= rp.pool_min_batch || (!patient && have + avail != 0u)) action = 1u;
+        else if (!patient && (n_shade | n_resolve) != 0u) action = (n_shade >= n_resolve) ? 2u : 3u;
+        else action = 0u;
+
+        if (action >= 2u) {
+            pool_put_back(pool, job);
+            patience = 0u;
+            if (action == 2u) {
+                if (state == SM_SHADE) {
+                    RPT_PROF(PB_SHADE);
+                    const SdfInjectedQuery q{{m.hit, m.t}, {0.0f, 0u}};
+                    if (path_shade_full(sc, q, p, g, &normal)) {
+                        state = SM_FINISH;
+                    } else {
+                        pool_begin_primary(pool, sc, p, m);
+                        state = SM_MARCH_P;
+                    }
+                }
+            } else {
+                if (state == SM_RESOLVE) {
+                    RPT_PROF(PB_TRACE);
+                    const SdfInjectedQuery q{{m.hit, m.t}, march_analytic(m)};
+                    if (path_trace_geom(sc, q, p, g)) {
+                        normal = hit_normal(sc, p.ray, p.ps.hit_dist, g);
+                        const bool front = (dot3(normal, p.ray.d) <= 0.0f);         // State::finalize, globals.rs:53-57
+                        const v3 ffnormal = mk3(front ? normal.x : -normal.x, front ? normal.y : -normal.y, front ? normal.z : -normal.z);
+                        const v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
+                        state = pool_begin_shadow(pool, sc, p, fhp, ffnormal, m) ? SM_MARCH_S : SM_SHADE;
+                    } else {
+                        state = SM_FINISH;
+                    }
+                }
+            }
+        } else if (action == 1u) {
+            // serve the workgroup's queue until one of the wave's own blocks has filled, or too few jobs are left
+            patience = patient ? 0u : patience;
+            for (uint32_t it = 0; it < 256u; ++it) {
+                pool_take(pool, job);
+                const uint32_t jobs = (uint32_t)__popcll(__ballot(job.owner != kPoolEmpty));
+                if (jobs == 0u) break;
+                if (rp.pool_patience != 0u && patient && 2u * jobs < rp.pool_min_batch) break;   // hand the rest back: another wave can merge them
+                pool_step(pool, sc.sdf, job);
+                if (state <= SM_MARCH_S && pool_poll(pool, tid, m)) state = (state == SM_MARCH_P) ? SM_RESOLVE : SM_SHADE;
+                const uint32_t r = (uint32_t)__popcll(__ballot(state == SM_RESOLVE)), sh = (uint32_t)__popcll(__ballot(state == SM_SHADE));
+                if (rp.pool_patience == 0u) {
+                    const uint32_t left = (uint32_t)__popcll(__ballot(state <= SM_MARCH_S));
+                    if ((r | sh) != 0u && left < rp.march_min_lanes) break;
+                    continue;
+                }
+                if (sh >= rp.pool_shade_lanes || r >= rp.pool_resolve_lanes) break;
+            }
+        } else {
+            pool_put_back(pool, job);
+            patience += 1u;
+            __builtin_amdgcn_s_sleep(4);                            // nothing worth doing yet: let other waves use the SIMD
+        }
+    }
+    RPT_PROF_FLUSH();
+    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
+}
+
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_pool_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_pool_body(sc, rp); }
+
 // Large scenes with the uniform grid, resumable walk (dev_grid_path.h).  Per lane:
 //   WALK_P --(walk over)--> RESOLVE --(miss / emitter)--> FINISH: next sample, WALK_P
 //                                   --(surface)--> WALK_S --(walk over)--> SHADE --> WALK_P / FINISH
@@ -531,6 +670,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     else if (large && scl.use_grid && rp.grid_resumable_walk) hipLaunchKernelGGL(RPT_K(render_large_walk_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
+    else if (has_sdf && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), dim3(nblocks), dim3(256), 0, st, sc, rp);

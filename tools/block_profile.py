@@ -32,8 +32,10 @@ from rust_pathtracer_amd import scenes  # noqa: E402
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 which = sys.argv[2] if len(sys.argv) > 2 else "c2"
 w, h = (2048, 2048) if which == "c5" else (1920, 1080)
-scene = {"c2": rpt.AnalyticalScene, "c4": scenes.sdf_scene, "c4i": scenes.sdf_scene, "c5": lambda: scenes.random_spheres_scene(10000, 16)}[which]()
+scene = {"c2": rpt.AnalyticalScene, "c4": scenes.sdf_scene, "c4i": scenes.sdf_scene, "c4p": scenes.sdf_scene, "c5": lambda: scenes.random_spheres_scene(10000, 16)}[which]()
 t = rpt.Tracer(scene, device=0, seed=1)
+if which == "c4p":
+    t.flags = rpt._abi.RPT_RENDER_SDF_POOL_MARCH           # the workgroup march pool
 if which == "c4i":
     t.flags = rpt._abi.RPT_RENDER_SDF_INLINE_MARCH         # c4: the march kernel (closest_hit row = one march step, TRACE = RESOLVE)
 buf = rpt.DeviceColorBuffer(w, h)
