@@ -462,7 +462,7 @@ def _random_small_scene(rpt, rng):
     return s
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_random_small_scenes_match_oracle(rpt, oracle, seed):
     """Fuzz: random primitive counts (including none), partial material patches (so the layering of
     analytical.rs:56-58/82-85 matters), emissive / transmissive / anisotropic materials, both backgrounds,
@@ -480,7 +480,7 @@ def test_random_small_scenes_match_oracle(rpt, oracle, seed):
     t.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(20))
 def test_random_sdf_scenes_match_oracle(rpt, oracle, seed):
     """Fuzz the SDF object: 1-8 random spheres/tori, any smoothing radius, short and long step budgets, on top of
     random analytical scenes (including none at all, where the SDF hit is accepted unconditionally, and no

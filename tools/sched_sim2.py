@@ -96,6 +96,56 @@ def sim_rooms(pixels, variant, thr=56, thr2=40):
     return T
 
 
+def sim_two_rooms_k(pixels, k, thr=56, swap_cost=0.6):
+    """The shipped two rooms, but every lane owns k pixels (= k paths): one path in the working registers, the others
+    parked (a parked path is its PathRegs + one dword: 18 VGPRs).  In a pass a lane takes part with any one of its paths
+    that is in the room."""
+    T = T2()
+    n = len(pixels); L = n // k
+    si = [0] * n; bi = [0] * n
+    st = ["T"] * n
+    def cur(q): return pixels[q][si[q]][bi[q]]
+    def end_sample(q):
+        si[q] += 1; bi[q] = 0
+        st[q] = "F" if si[q] < len(pixels[q]) else "X"
+    extra = 0.0
+    def pick(l, states):
+        for j in range(k):
+            if st[l * k + j] in states: return l * k + j
+        return None
+    while True:
+        # finish + trace: lanes with a path in F or T (F first: regenerate then trace in the same pass, like the kernel)
+        chosen = [pick(l, "FT") for l in range(L)]
+        tr = [q for q in chosen if q is not None]
+        if tr:
+            fin = [q for q in tr if st[q] == "F"]
+            T.run("finish", len(fin))
+            for q in fin: st[q] = "T"
+            T.run("closest", len(tr))
+            T.run("background", sum(1 for q in tr if cur(q)[0] == "M"))
+            for q in tr:
+                if cur(q)[0] == "H": st[q] = "H"
+                else: end_sample(q)
+            extra += swap_cost if k > 1 else 0.0
+        T.run("vote", 64)
+        go = sum(1 for l in range(L) if pick(l, "FT") is not None)
+        hl = [pick(l, "H") for l in range(L)]
+        h = [q for q in hl if q is not None]
+        if not go and not h: break
+        if len(h) >= thr or not go:
+            T.run("surface", len(h)); T.run("frame", len(h)); T.run("nee", len(h))
+            T.run("anyhit", sum(1 for q in h if cur(q)[1] in "sv"))
+            T.run("eval", sum(1 for q in h if cur(q)[1] == "v"))
+            T.run("rest", len(h)); T.run("common", len(h))
+            for a in "DCS": T.run(a, sum(1 for q in h if cur(q)[2] == a))
+            for q in h:
+                if cur(q)[3]: end_sample(q)
+                else:
+                    bi[q] += 1; st[q] = "T"
+            extra += swap_cost if k > 1 else 0.0
+    return T, extra
+
+
 if __name__ == "__main__":
     spp = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     ntiles = int(sys.argv[2]) if len(sys.argv) > 2 else 12
@@ -106,6 +156,7 @@ if __name__ == "__main__":
     tiles = [(int(rng.integers(0, 1920 // 32)) * 32, int(rng.integers(0, 1080 // 32)) * 32) for _ in range(ntiles)]
     variants = [("two", 56, 0), ("two", 64, 0), ("three", 0, 24), ("three", 0, 40), ("three", 0, 56), ("chain", 56, 0), ("chain", 40, 0)]
     res = {v: T2() for v in variants}
+    kres = {k_: [T2(), 0.0] for k_ in (1, 2, 4)}
     ns = 0
     for (c0, r0) in tiles:
         px = S.tile_events(oracle, desc, c0, r0, 32, 32, spp)
@@ -116,7 +167,17 @@ if __name__ == "__main__":
                 wave = [grid[wy * 8 + y][wx * 8 + x] for y in range(8) for x in range(8)]
                 for v in variants:
                     res[v].add(sim_rooms(wave, v[0], v[1], v[2]))
+        for k_ in kres:
+            for wy in range(32 // (8 * k_)):
+                for wx in range(4):
+                    wave = [grid[wy * 8 * k_ + j * 8 + y][wx * 8 + x] for y in range(8) for x in range(8) for j in range(k_)]
+                    T, extra = sim_two_rooms_k(wave, k_)
+                    kres[k_][0].add(T); kres[k_][1] += extra
     base = res[("two", 56, 0)].time()
+    for k_, (T, extra) in kres.items():
+        t = T.time() + extra
+        print("two rooms, %d paths per lane: cost/sample %.1f (%.3fx of shipped) useful %.1f%%  execs/sample: closest %.2f head %.2f" % (
+            k_, 64 * t / ns, base / t, 100 * T.useful() / t, 64 * T.e["closest"] / ns, 64 * T.e["surface"] / ns))
     for v in variants:
         T = res[v]
         print("%-18s cost/sample %.1f  (%.3fx of shipped)  useful %.1f%%   execs/sample: closest %.2f head %.2f lobes %.2f" % (
