@@ -220,7 +220,10 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
 }
 
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
+#ifndef RPT_SMALL_WAVES_PER_SIMD
+#define RPT_SMALL_WAVES_PER_SIMD RPT_WAVES_PER_SIMD
+#endif
+__global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
