@@ -318,7 +318,7 @@ struct Pinhole {                                                                
 // for closest_hit) so a test can replay the exact rays of a pixel-sample through the device probes.
 inline thread_local std::vector<float>* g_ray_log = nullptr;
 // Debug aid for tools/sched_sim.py: when set, sample_pixel appends one byte per path event: per bounce
-// 'M' miss (path over) | 'E' emitter (over) | 'H' surface hit, then 'n' light sample not facing / 's' shadowed /
+// 'M' miss (path over) | 'E' emitter (over) | 'H' surface hit ('k' follows when its material has clearcoat != 0), then 'n' light sample not facing / 's' shadowed /
 // 'v' unshadowed (disney_eval runs) / 'z' no lights, then the sampled lobe 'D' 'C' 'S', then 'x' if pdf <= 0 (over);
 // '.' closes the sample.
 inline thread_local std::vector<uint8_t>* g_event_log = nullptr;
@@ -953,6 +953,7 @@ struct Tracer {
                 break;
             }
             log_event(state.is_emitter ? 'E' : 'H');
+            if (!state.is_emitter && raw(state.material.clearcoat) != 0.0f) log_event('k');   // surface with a clearcoat lobe
             state.finalize(ray);
             radiance += state.material.emission * throughput;
             if (state.is_emitter) {

@@ -50,6 +50,9 @@ def parse(events):
             i += 1
         else:
             assert c == "H", c
+            coat = ev[i + 1] == "k"
+            if coat:
+                i += 1
             nee, lobe = ev[i + 1], ev[i + 2]
             i += 3
             ended = False
@@ -58,7 +61,7 @@ def parse(events):
                 i += 1
             if ev[i] == ".":
                 ended = True                      # depth exhausted
-            cur.append(("H", nee, lobe, ended))
+            cur.append(("H", nee, lobe, ended, coat))
     return samples
 
 

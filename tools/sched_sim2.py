@@ -10,8 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import sched_sim as S  # noqa: E402
 import ctypes as C  # noqa: E402
 
-COST = {"closest": 4.47, "background": 4.03, "finish": 1.56, "surface": 6.3, "frame": 0.76, "nee": 4.5, "anyhit": 2.6, "eval": 8.25,
-        "common": 3.0, "D": 0.39, "C": 6.15, "S": 8.4, "rest": 5.1, "vote": 0.15}
+COST = {"closest": 4.47, "background": 4.03, "finish": 1.56, "surface": 6.3, "frame": 0.76, "nee": 4.5, "anyhit": 2.6, "eval": 5.95,
+        "common": 3.0, "D": 0.39, "C": 6.15, "S": 8.4, "rest": 5.1, "vote": 0.15, "evalcc": 3.6}
 
 
 class T2:
@@ -66,7 +66,9 @@ def sim_rooms(pixels, variant, thr=56, thr2=40):
         def head(lanes, with_eval=True):
             T.run("surface", len(lanes)); T.run("frame", len(lanes)); T.run("nee", len(lanes))
             T.run("anyhit", sum(1 for l in lanes if cur(l)[1] in "sv"))
-            if with_eval: T.run("eval", sum(1 for l in lanes if cur(l)[1] == "v"))
+            if with_eval:
+                T.run("eval", sum(1 for l in lanes if cur(l)[1] == "v"))
+                T.run("evalcc", sum(1 for l in lanes if cur(l)[1] == "v" and cur(l)[4]))
             T.run("rest", len(lanes))
         def lobes(lanes):
             T.run("common", len(lanes))
@@ -85,6 +87,22 @@ def sim_rooms(pixels, variant, thr=56, thr2=40):
             elif len(h) >= thr2 or not go:
                 head(h)
                 for l in h: st[l] = "L"
+        elif variant == "coat":
+            # two SHADE rooms by material class: surfaces with a clearcoat lobe wait apart, so the plain passes skip the
+            # clearcoat code altogether; thr for the plain room, thr2 for the clearcoat room
+            hp = [l for l in h if not cur(l)[4]]
+            hc = [l for l in h if cur(l)[4]]
+            def shade(lanes, coat):
+                T.run("surface", len(lanes)); T.run("frame", len(lanes)); T.run("nee", len(lanes))
+                T.run("anyhit", sum(1 for l in lanes if cur(l)[1] in "sv"))
+                T.run("eval", sum(1 for l in lanes if cur(l)[1] == "v"))
+                if coat: T.run("evalcc", sum(1 for l in lanes if cur(l)[1] == "v"))
+                T.run("rest", len(lanes))
+                lobes(lanes)
+            if len(hc) >= thr2 or (not go and not hp and hc) or (not go and len(hc) > len(hp)):
+                shade(hc, True)
+            elif len(hp) >= thr or (not go and hp):
+                shade(hp, False)
         elif variant == "chain":
             # HEAD fires at thr; its lanes join the LOBES room, which fires at thr (or with nobody left to trace / shade)
             if len(h) >= thr or (not go and h):
@@ -154,7 +172,7 @@ if __name__ == "__main__":
     desc = oracle.scene_analytical()
     rng = np.random.default_rng(5)
     tiles = [(int(rng.integers(0, 1920 // 32)) * 32, int(rng.integers(0, 1080 // 32)) * 32) for _ in range(ntiles)]
-    variants = [("two", 56, 0), ("two", 64, 0), ("three", 0, 24), ("three", 0, 40), ("three", 0, 56), ("chain", 56, 0), ("chain", 40, 0)]
+    variants = [("two", 56, 0), ("two", 64, 0), ("coat", 56, 16), ("coat", 56, 32), ("coat", 48, 24), ("coat", 56, 48), ("three", 0, 24), ("three", 0, 40), ("three", 0, 56), ("chain", 56, 0), ("chain", 40, 0)]
     res = {v: T2() for v in variants}
     kres = {k_: [T2(), 0.0] for k_ in (1, 2, 4)}
     ns = 0
