@@ -192,11 +192,11 @@ def main():
         }
         # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (committed
         # under profiles/; bench.py cannot collect counters itself)
-        tj = os.path.join(ROOT, "profiles", "r1", "v5_surface_pass_in_shade", "traffic.json")
+        tj = os.path.join(ROOT, "profiles", "r1", "v6_max_ilp", "traffic.json")
         if world == 1 and os.path.exists(tj):
             t = json.load(open(tj))
             out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r1/v5_surface_pass_in_shade/traffic.json (%s)" % t["correction"]
+            out["roofline"]["traffic_source"] = "profiles/r1/v6_max_ilp/traffic.json (%s)" % t["correction"]
         if world == 1 and not args.no_cpu_baseline:
             cpu, ops = cpu_baseline(width, height)
             out["cpu_baseline"] = cpu
