@@ -135,13 +135,6 @@ struct PathState {
     float scatter_pdf;         // ScatterSampleRec.pdf of the previous bounce (MIS, tracer.rs:81)
 };
 
-struct HitInfo {
-    v3 normal;
-    Mat mat;
-    bool is_emitter;
-    float light_pdf;           // LightSampleRec.pdf / .emission written by Scene::sample_lights
-    v3 light_emission;
-};
 
 // Result of a sphere march done elsewhere (the resumable-march kernel runs the march as its own
 // scheduling state and hands the outcome to the unchanged closest_hit / any_hit arithmetic).
@@ -342,44 +335,7 @@ RPT_DEV v3 normal_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray
     return mk3(use_pn ? pn.x : sn.x, use_pn ? pn.y : sn.y, use_pn ? pn.z : sn.z);   // (per component: a struct select goes through scratch)
 }
 
-// ... and its material.
-template <bool SDF>
-RPT_DEV void resolve_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, float dist, uint32_t accepted, HitInfo& hi)
-{
-    hi.normal = normal_small<SDF>(sc, sdf, ray, dist, accepted);
-    material_small<SDF>(sc, sdf, ray, accepted, hi.mat);
-}
-
-// AnalyticalScene::closest_hit + Scene::sample_lights in one call (the nested-loop kernels and the SDF
-// march kernel, which keep the finished hit record between their blocks).
-template <bool SDF>
-RPT_DEV bool closest_hit_small(const SceneSmall& sc, const DevSdf* sdf, const RayD& ray, PathState& ps, HitInfo& hi,
-                               const SdfMarchResult* pre = nullptr)
-{
-    GeomHit g;
-    EmitterHit e{hi.is_emitter, hi.light_pdf, hi.light_emission};
-    const float stale = ps.hit_dist;
-    const bool hit = closest_geom_small<SDF>(sc, sdf, ray, ps, g, e, pre);
-    hi.is_emitter = e.is_emitter; hi.light_pdf = e.light_pdf; hi.light_emission = e.light_emission;
-    if (g.code != 0u) {
-        // the geometric distance: ps.hit_dist unless a nearer light overwrote it, in which case the path ends and
-        // nothing reads the normal — any finite stand-in does
-        resolve_small<SDF>(sc, sdf, ray, e.is_emitter ? stale : ps.hit_dist, g.code, hi);
-    } else {
-        material_small<SDF>(sc, sdf, ray, 0u, hi.mat);
-    }
-    return hit;
-}
-
-RPT_DEV bool closest_hit(const SceneSmall& sc, const RayD& ray, PathState& ps, HitInfo& hi)
-{
-    return closest_hit_small<false>(sc, nullptr, ray, ps, hi);
-}
-RPT_DEV bool closest_hit(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, HitInfo& hi)
-{
-    return closest_hit_small<true>(sc, &sc.sdf, ray, ps, hi);
-}
-// the same in two passes (the regenerating kernels: the surface pass runs in the shading block)
+// closest_hit in two passes: geometry (TRACE) and surface (normal, material: SHADE)
 RPT_DEV bool closest_geom(const SceneSmall& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) { return closest_geom_small<false>(sc, nullptr, ray, ps, g, e); }
 RPT_DEV bool closest_geom(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) { return closest_geom_small<true>(sc, &sc.sdf, ray, ps, g, e); }
 RPT_DEV v3 hit_emission(const SceneSmall& sc, const GeomHit& g) { return emission_small<false>(sc, nullptr, g.code); }
@@ -501,7 +457,6 @@ RPT_DEV DevLight light_at(const SceneSmall& sc, uint32_t index)
 // How the integrator asks the scene its two questions.  The default asks directly; the resumable-march
 // kernel substitutes a query that carries the outcome of a march it ran as a separate scheduling state.
 struct DirectQuery {
-    template <class S> RPT_DEV bool closest(const S& sc, const RayD& ray, PathState& ps, HitInfo& hi) const { return closest_hit(sc, ray, ps, hi); }
     template <class S> RPT_DEV bool any(const S& sc, const RayD& ray, float max_dist) const { return any_hit(sc, ray, max_dist); }
     template <class S> RPT_DEV bool geom(const S& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) const { return closest_geom(sc, ray, ps, g, e); }
 };
@@ -596,87 +551,8 @@ RPT_DEV void path_begin(const S& sc, PathRegs& p, float px, float py, uint32_t f
     p.bounce = 0;
 }
 
-// What a surface hit leaves behind for the shading half of the bounce (State after
-// State::finalize, globals.rs:50-62).
-struct SurfaceHit {
-    Mat mat;
-    v3 ffnormal;
-};
-// ... the rest of it (hit point, eta) is parked in LDS by the kernel: one float4 per lane.
-struct SurfaceHitCold {
-    v3 fhp;
-    float eta;
-};
-
-// First half of one iteration of the loop at tracer.rs:61-103: closest_hit, the miss
-// and emitter exits (tracer.rs:64-87).  Returns true when a surface was hit and `sh` is
-// filled (shading still to do); false when the path is over and p.radiance is final.
-template <class S, class Q>
-RPT_DEV bool path_trace(const S& sc, const Q& q, PathRegs& p, SurfaceHit& sh, SurfaceHitCold& shc)
-{
-    HitInfo hi;
-    hi.is_emitter = false;
-    hi.normal = mk3(0.0f, 0.0f, 0.0f);
-    hi.light_pdf = 0.0f;
-    hi.light_emission = mk3(0.0f, 0.0f, 0.0f);
-    bool hit;
-    { RPT_PROF(PB_CLOSEST); hit = q.closest(sc, p.ray, p.ps, hi); }
-    if (!hit) {
-        RPT_PROF(PB_BACKGROUND);
-        p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
-        return false;
-    }
-    RPT_PROF(PB_FINALIZE);
-    // State::finalize, globals.rs:50-62
-    shc.fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
-    float ndd = dot3(hi.normal, p.ray.d);
-    const bool front = (ndd <= 0.0f);
-    sh.ffnormal = mk3(front ? hi.normal.x : -hi.normal.x, front ? hi.normal.y : -hi.normal.y, front ? hi.normal.z : -hi.normal.z);
-    mat_finalize(hi.mat);
-    shc.eta = (ndd < 0.0f) ? (1.0f / hi.mat.ior) : hi.mat.ior;
-    sh.mat = hi.mat;
-
-    p.radiance = p.radiance + hi.mat.emission * p.throughput;
-    if (hi.is_emitter) {
-        // state.depth > 0 always holds (tracer.rs:57,80): the MIS weight is always applied
-        float mis_weight = power_heuristic(p.ps.scatter_pdf, hi.light_pdf);
-        p.radiance = p.radiance + (mis_weight * hi.light_emission) * p.throughput;
-        return false;
-    }
-    return true;
-}
-
-// Second half (tracer.rs:89-101): next-event estimation, BSDF sampling, next ray.
-// Returns true when the path is over (pdf <= 0 or depth exhausted).
-// `cold` points at the lane's parked {fhp.xyz, eta} (LDS in the production kernel).  The
-// hit point is read twice on purpose — for the shadow-ray origin and, much later, for the
-// next ray's origin — so that it does not occupy registers across the BSDF code.
-template <class S, class Q>
-RPT_DEV bool path_shade(const S& sc, const Q& q, PathRegs& p, const SurfaceHit& sh, const volatile float4* cold)
-{
-    SurfaceHitCold shc;
-    shc.eta = cold->w;
-    shc.fhp = mk3(cold->x, cold->y, cold->z);
-    ShadeFrame fr;
-    { RPT_PROF(PB_FRAME); fr = make_frame(sh.mat, shc.eta, -p.ray.d, sh.ffnormal); }
-    p.radiance = p.radiance + direct_light(sc, q, sh.mat, shc.eta, fr, shc.fhp, sh.ffnormal, p.rng) * p.throughput;
-
-    float pdf;
-    v3 scatter_l = (p.bounce > 0) ? p.ray.d : mk3(0.0f, 0.0f, 0.0f);   // the stale `l` of tracer.rs:531
-    v3 f;
-    { RPT_PROF(PB_SAMPLE_HEAD); f = disney_sample(sh.mat, shc.eta, fr, sh.ffnormal, scatter_l, pdf, p.rng); }
-    p.ps.scatter_pdf = pdf;
-    if (!(pdf > 0.0f)) return true;
-    RPT_PROF(PB_SAMPLE_TAIL);
-    p.throughput = p.throughput * divs3(f, pdf);
-    p.ray.d = scatter_l;
-    p.ray.o = mk3(cold->x, cold->y, cold->z) + sc.eps * p.ray.d;
-    p.bounce += 1;
-    return p.bounce >= sc.max_depth;
-}
-
-// ---- the same bounce with everything only a surface hit needs moved into the shading half ----
-// TRACE (path_trace_geom): the geometry pass of closest_hit, the miss and emitter exits.  What a surface hit
+// One iteration of the loop at tracer.rs:61-103 in two halves, split where the work stops being needed by every ray:
+// TRACE (path_trace_geom): the geometry pass of closest_hit, the miss and emitter exits (tracer.rs:64-87).  What a surface hit
 // parks is one dword (GeomHit) next to the path's own registers.  SHADE (path_shade_full): normal, material
 // layering, State::finalize, then next-event estimation and BSDF sampling as in path_shade.  The normal, the
 // material writes and finalize cost about as much as the three sphere tests; in TRACE they ran for the 62 % of its
@@ -750,20 +626,14 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
     return p.bounce >= sc.max_depth;
 }
 
-template <class S>
-RPT_DEV bool path_trace(const S& sc, PathRegs& p, SurfaceHit& sh, SurfaceHitCold& shc) { return path_trace(sc, DirectQuery{}, p, sh, shc); }
-template <class S>
-RPT_DEV bool path_shade(const S& sc, PathRegs& p, const SurfaceHit& sh, const volatile float4* cold) { return path_shade(sc, DirectQuery{}, p, sh, cold); }
 
 // One whole iteration of tracer.rs:61-103; true when the path is over.
 template <class S>
 RPT_DEV bool path_bounce(const S& sc, PathRegs& p)
 {
-    SurfaceHit sh;
-    SurfaceHitCold shc;
-    if (!path_trace(sc, p, sh, shc)) return true;
-    float4 cold = make_float4(shc.fhp.x, shc.fhp.y, shc.fhp.z, shc.eta);
-    return path_shade(sc, p, sh, &cold);
+    GeomHit g;
+    if (!path_trace_geom(sc, DirectQuery{}, p, g)) return true;
+    return path_shade_full(sc, DirectQuery{}, p, g);
 }
 
 // One pixel-sample start to end (the nested-loop form; kept for the A/B kernel).

@@ -396,26 +396,6 @@ RPT_DEV v3 normal_large(const SceneLarge& sc, const RayD& ray, float dist, const
 
 RPT_DEV v3 hit_normal(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g) { return normal_large(sc, ray, dist, g); }
 RPT_DEV void hit_material(const SceneLarge& sc, const RayD& ray, const GeomHit& g, Mat& mat) { material_large(sc, ray, g.code, mat); }
-RPT_DEV void resolve_hit(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g, HitInfo& hi)
-{
-    hi.normal = normal_large(sc, ray, dist, g);
-    material_large(sc, ray, g.code, hi.mat);
-}
-
-// AnalyticalScene::closest_hit + Scene::sample_lights in one call (the nested-loop kernel).
-RPT_DEV bool closest_hit(const SceneLarge& sc, const RayD& ray, PathState& ps, HitInfo& hi)
-{
-    GeomHit g;
-    EmitterHit e{hi.is_emitter, hi.light_pdf, hi.light_emission};
-    const float stale = ps.hit_dist;
-    const bool hit = closest_geom(sc, ray, ps, g, e);
-    hi.is_emitter = e.is_emitter; hi.light_pdf = e.light_pdf; hi.light_emission = e.light_emission;
-    const bool geom_hit = ((g.code & kNoSphere) != kNoSphere) || (g.code >> 28) != 0u;
-    if (geom_hit) resolve_hit(sc, ray, e.is_emitter ? stale : ps.hit_dist, g, hi);
-    else material_large(sc, ray, g.code, hi.mat);
-    return hit;
-}
-
 // any_hit after the sphere part (`occluded` = its answer, however it was obtained)
 RPT_DEV bool any_hit_finish(const SceneLarge& sc, const RayD& ray, float max_dist, bool occluded)
 {

@@ -8,7 +8,7 @@
 // new march (the next bounce, the next sample of the pixel, a shadow ray).
 //
 // Nothing about the arithmetic changes: the march below is sdf_march() one iteration at a time, and
-// its outcome is handed to the same closest_hit_small / any_hit_small code through SdfMarchResult,
+// its outcome is handed to the same closest_geom_small / any_hit_small code through SdfMarchResult,
 // so images are bit-identical to the bounce-granular kernels (tests/test_gpu_parity.py, SDF cases).
 #pragma once
 #include "dev_integrator.h"
@@ -52,10 +52,6 @@ struct SdfInjectedQuery {
     RPT_DEV bool geom(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) const
     {
         return closest_geom_small<true>(sc, &sc.sdf, ray, ps, g, e, &r, &a);
-    }
-    RPT_DEV bool closest(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, HitInfo& hi) const
-    {
-        return closest_hit_small<true>(sc, &sc.sdf, ray, ps, hi, &r);
     }
     RPT_DEV bool any(const SceneSmallSdf& sc, const RayD& ray, float max_dist) const
     {
