@@ -124,6 +124,9 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        warm = torch.zeros(1, device="cuda")
+        dist.all_reduce(warm)                   # create the communicator now, not inside the first timed gather (--warmup 0)
+        torch.cuda.synchronize()
 
     width, height = frame_size(world)
     tracer = rpt.Tracer(rpt.AnalyticalScene(), device=local_rank, seed=1)
