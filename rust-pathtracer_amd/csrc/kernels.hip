@@ -223,7 +223,20 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
 #ifndef RPT_SMALL_WAVES_PER_SIMD
 #define RPT_SMALL_WAVES_PER_SIMD RPT_WAVES_PER_SIMD
 #endif
+#ifdef RPT_SCENE_IN_LDS
+// A/B build ("why not the other shapes"): the scene tables staged in LDS and read from there (ds_read of a
+// wave-uniform address, value in a VGPR) instead of from the kernarg segment (s_load, value in an SGPR).
+__global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp)
+{
+    __shared__ SceneSmall s_scene;
+    static_assert(sizeof(SceneSmall) % 4 == 0, "dword copy");
+    for (uint32_t i = threadIdx.x; i < sizeof(SceneSmall) / 4; i += 256u) ((uint32_t*)&s_scene)[i] = ((const uint32_t*)&sc)[i];
+    __syncthreads();
+    render_regen_body(s_scene, rp);
+}
+#else
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
+#endif
 // Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
