@@ -23,6 +23,9 @@ HEADERS = ["dev_math.h", "dev_prof.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_l
 #   and [3] at the same 96 VGPRs (iterative-ilp / iterative-minreg: no gain).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
          "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC"]
+# The two -mllvm options are tuning only (they change instruction order / register use, never a result); a toolchain that
+# does not know them still builds the library without them.
+TUNING_FLAGS = ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def _hipcc():
@@ -54,7 +57,9 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="buil
         objs.append(obj)
     for cmd, p in procs:
         if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, cmd)
+            plain = [c for c in cmd if c not in TUNING_FLAGS]
+            print("build.py: retrying without the -mllvm tuning options: " + " ".join(plain))
+            subprocess.run(plain, check=True, cwd=CSRC)
     link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", lib]
     if verbose:
         print(" ".join(link))
