@@ -53,13 +53,16 @@ def _cpu_quota():
 def cpu_baseline(width, height, budget_s=12.0):
     """Time the CPU oracle (a port of the reference's rayon path: OpenMP over scanlines) on
     the host cores, on a bounded sample of the same workload: the full 1920x1080 frame at a
-    few spp (Msamples/s does not depend on spp on the CPU).  The thread count is the best of
+    few spp (Msamples/s does not depend on spp on the CPU).  The build timed is the one with the
+    PLATFORM libm (liboracle_libm.so: glibc sinf/cosf/powf/log2f, what the reference's Rust f32 methods
+    call on Linux) — 1.6x faster than the bit-reproducible strict-math build the parity tests use, so it
+    is the fairer stand-in for the reference binary.  The thread count is the best of
     {quota, 2 x quota} CPUs (cgroup-aware: oversubscribing a quota makes the baseline slower,
     which would flatter the GPU).  Also counts flops per sample."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib
-    o = oracle_lib.Oracle("liboracle.so")
+    o = oracle_lib.Oracle("liboracle_libm.so")
     desc = o.scene_analytical()
     quota = _cpu_quota()
     px = np.zeros((height, width, 4), dtype=np.float32)
@@ -84,7 +87,7 @@ def cpu_baseline(width, height, budget_s=12.0):
     flops = (c["add"] + c["mul"] + c["div"] + c["sqrt"]) / n
     return {
         "value": round(msps, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
-        "sample": "%dx%d x %d spp, same scene/seed (%.1f s of CPU work); OpenMP scanline loop, g++ -O3 -march=x86-64-v3; "
+        "sample": "%dx%d x %d spp, same scene/seed (%.1f s of CPU work); OpenMP scanline loop, g++ -O3 -march=x86-64-v3, glibc libm; "
                   "%d threads on a %d-CPU quota (%d logical CPUs visible)"
                   % (width, height, spp, t1 - t0, threads, quota, os.cpu_count() or 0),
     }, {"flops_per_sample": round(flops, 1), "transcendentals_per_sample": round(c["transc"] / n, 2),
