@@ -1,16 +1,19 @@
 #!/usr/bin/env python3
 """bench.py — Msamples/s of the render hot path on MI355X (driver contract: see the task).
 
-One "step" = one pass of the hot path over one batch: `SPP` (256) consecutive
-Tracer::render() calls folded into one launch over the whole frame, on a frame that is
-already resident in HBM; for N > 1 every step's per-rank row tiles are all-gathered over RCCL
-(the image is row-tiled across the GPUs; ranks exchange nothing while rendering) and scattered into
-the full image on every rank.  The gather of step k runs on RCCL's stream while step k+1 renders
-(TiledRender.gather_begin / gather_end); all K gathers complete inside the timed region.
+One "step" = one pass of the hot path over one batch: SPP consecutive Tracer::render() calls folded into one
+launch sequence over the whole frame, on a frame that is already resident in HBM.
 
-N = 1 workload = BASELINE.json configs[1]: AnalyticalScene 1920x1080, 256 spp, f32.
-N > 1 is WEAK scaling: the same view at round(1920*sqrt(N)) x round(1080*sqrt(N)) pixels
-(N = 4 is 3840x2160, configs[2]'s frame), i.e. a fixed number of pixels and samples per GPU.
+N = 1   BASELINE.json configs[1]: AnalyticalScene 1920x1080, 256 spp per step, f32.
+N > 1   BASELINE.json configs[2] EXACTLY: AnalyticalScene 3840x2160, 1024 spp per step, the image row-tiled over the N
+        GPUs (cyclic 2-row blocks), one process per GPU; every step ends with the RCCL gather of the tiles to rank 0
+        and the scatter into the full image on rank 0's device, inside the timed region.  STRONG scaling: the frame
+        is the same for every N; rank 0 also renders it alone after the timed region, so the line carries the
+        measured 1-GPU time of the same frame next to the N-GPU time.  Fixed work per GPU (weak scaling) is a
+        secondary key.
+The multi-GPU machinery is the library's (include/rpt.h: rpt_create_rank, rpt_resident_render,
+rpt_resident_gather_device); torch.distributed (gloo) only carries the 128-byte communicator id, the barriers and the
+max over ranks of the elapsed time.
 
 Usage: python bench.py [--gpus N] [--steps K] [--warmup W]
        (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
@@ -26,16 +29,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-SPP = 256
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
+C2 = (1920, 1080, 256)         # BASELINE.json configs[1]
+C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
+TRAFFIC_JSON = os.path.join("profiles", "r2", "c2_bench", "traffic.json")
 
 
-def frame_size(n_gpus):
+def weak_frame(n_gpus):
+    """Fixed pixels per GPU: configs[1]'s frame scaled by sqrt(N) per axis (N = 4 is configs[2]'s frame)."""
     s = math.sqrt(n_gpus)
-    w = int(round(1920 * s / 8.0)) * 8
-    h = int(round(1080 * s / 8.0)) * 8
-    return w, h
+    return int(round(1920 * s / 8.0)) * 8, int(round(1080 * s / 8.0)) * 8
 
 
 def _cpu_quota():
@@ -50,6 +54,19 @@ def _cpu_quota():
     return n
 
 
+def op_counts():
+    """Algorithmic flops per sample of the AnalyticalScene view, measured by the op-counting build of the oracle."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    oc = oracle_lib.Oracle("liboracle_opcount.so")
+    cw, ch, cs = 240, 136, 4
+    c = oc.opcount(oc.scene_analytical(), cw, ch, cs, seed=1)
+    n = cw * ch * cs
+    return {"flops_per_sample": round((c["add"] + c["mul"] + c["div"] + c["sqrt"]) / n, 1),
+            "transcendentals_per_sample": round(c["transc"] / n, 2),
+            "divides_per_sample": round(c["div"] / n, 2), "sqrts_per_sample": round(c["sqrt"] / n, 2)}
+
+
 def cpu_baseline(width, height, budget_s=12.0):
     """Time the CPU oracle (a port of the reference's rayon path: OpenMP over scanlines) on
     the host cores, on a bounded sample of the same workload: the full 1920x1080 frame at a
@@ -58,7 +75,7 @@ def cpu_baseline(width, height, budget_s=12.0):
     call on Linux) — 1.6x faster than the bit-reproducible strict-math build the parity tests use, so it
     is the fairer stand-in for the reference binary.  The thread count is the best of
     {quota, 2 x quota} CPUs (cgroup-aware: oversubscribing a quota makes the baseline slower,
-    which would flatter the GPU).  Also counts flops per sample."""
+    which would flatter the GPU)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import oracle_lib
@@ -79,19 +96,12 @@ def cpu_baseline(width, height, budget_s=12.0):
     o.render(desc, width, height, spp, seed=1, frames_done=9, pixels=px, threads=threads)
     t1 = time.perf_counter()
     msps = width * height * spp / (t1 - t0) / 1e6
-    # algorithmic flops per sample, measured by the op-counting build of the oracle
-    oc = oracle_lib.Oracle("liboracle_opcount.so")
-    cw, ch, cs = 240, 136, 4
-    c = oc.opcount(oc.scene_analytical(), cw, ch, cs, seed=1)
-    n = cw * ch * cs
-    flops = (c["add"] + c["mul"] + c["div"] + c["sqrt"]) / n
     return {
         "value": round(msps, 3), "unit": "Msamples/s", "cores": threads, "kind": "port",
         "sample": "%dx%d x %d spp, same scene/seed (%.1f s of CPU work); OpenMP scanline loop, g++ -O3 -march=x86-64-v3, glibc libm; "
                   "%d threads on a %d-CPU quota (%d logical CPUs visible)"
                   % (width, height, spp, t1 - t0, threads, quota, os.cpu_count() or 0),
-    }, {"flops_per_sample": round(flops, 1), "transcendentals_per_sample": round(c["transc"] / n, 2),
-        "divides_per_sample": round(c["div"] / n, 2), "sqrts_per_sample": round(c["sqrt"] / n, 2)}
+    }
 
 
 def main():
@@ -101,8 +111,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
     ap.add_argument("--smoke-shared-gpu", action="store_true",
-                    help="TEST ONLY: all ranks use cuda:0 and the gloo backend (RCCL rejects duplicate devices), to exercise "
-                         "the N>1 code path on a 1-GPU box; the numbers mean nothing")
+                    help="TEST ONLY: every rank drives cuda:0 and the tiles are gathered with peer copies (RCCL rejects "
+                         "duplicate devices), to exercise the N>1 control flow on a 1-GPU box; the numbers mean nothing")
+    ap.add_argument("--small", action="store_true", help="TEST ONLY: 1/8-size frames and 1/16 of the samples (control-flow rehearsals)")
     args = ap.parse_args()
 
     import torch
@@ -113,114 +124,186 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    dist = None
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if args.smoke_shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.smoke_shared_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        warm = torch.zeros(1, device="cuda")
-        dist.all_reduce(warm)                   # create the communicator now, not inside the first timed gather (--warmup 0)
-        torch.cuda.synchronize()
+        dist.init_process_group(backend="gloo")           # control plane only: the data path's RCCL lives in the library
 
-    width, height = frame_size(world)
-    tracer = rpt.Tracer(rpt.AnalyticalScene(), device=local_rank, seed=1)
-    job = tiling.TiledRender(tracer, width, height, tile_rows=2)
+    def shrink(cfg):
+        return (cfg[0] // 8, cfg[1] // 8, max(1, cfg[2] // 16)) if args.small else cfg
 
-    def step():
-        job.render_n(SPP)
-        return job.gather() if world > 1 else None
-
-    def finish_gather(pending):
-        return job.gather_end(pending) if pending is not None else None
-
-    def fence():
+    def host_fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    kernel_ms = []
-    evs = []
-    t0 = time.perf_counter()
-    pending = None
-    for _ in range(args.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()                         # torch's current stream == the stream the kernel is launched on
-        job.render_n(SPP)
-        e1.record()
-        evs.append((e0, e1))
-        if world > 1:
-            finish_gather(pending)          # the previous step's gather ran while this step rendered
-            pending = job.gather_begin()
-    finish_gather(pending)
-    fence()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in evs]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    scene = rpt.AnalyticalScene()
+    out = None
+    if world == 1:
+        # ---- one GPU: configs[1].  The frame is a torch tensor, the launches go to torch's current stream, and
+        # torch.cuda.Event pairs on that stream time each step's kernel.
+        width, height, spp = shrink(C2)
+        tracer = rpt.Tracer(scene, device=local_rank, seed=1)
+        buf = rpt.DeviceColorBuffer(width, height, device="cuda:%d" % local_rank)
+        for _ in range(args.warmup):
+            tracer.render_n(buf, spp)
+        host_fence()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                     # torch's current stream == the stream the kernel is launched on
+            tracer.render_n(buf, spp)
+            e1.record()
+            evs.append((e0, e1))
+        host_fence()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = [a.elapsed_time(b) for a, b in evs]
+        local_pixels = width * height
+        extra = {}
+    else:
+        # ---- N GPUs: configs[2], strong scaling, gather to rank 0 inside the timed region
+        width, height, spp = shrink(C3)
+        if args.smoke_shared_gpu:
+            os.environ["RPT_GATHER"] = "p2p"
+            tracer = None
+            if rank == 0:                   # one process drives all "ranks" of cuda:0; the others only keep the barriers company
+                tracer = rpt.Tracer(scene, devices=[0] * world, seed=1)
+        else:
+            tracer = tiling.rank_tracer(scene, local_rank, seed=1)
+        job = tiling.TiledRender(tracer, width, height, tile_rows=2) if tracer else None
+
+        def step():
+            if job:
+                job.render_n(spp)
+                job.gather_begin()          # enqueued behind the render on the library's streams: no host wait
+
+        def drain():
+            if job:
+                job.gather_end()
+
+        for _ in range(args.warmup):
+            step()
+        drain()
+        host_fence()
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            if tracer:
+                kernel_ms.append(tracer.resident_kernel_ms())     # HIP events around this step's launches, on their stream
+        drain()
+        host_fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        local_pixels = tiling.tile_row_count(height, 2, rank, world) * width
+        extra = {}
+        # secondary: fixed work per GPU (weak scaling), a few steps
+        ww, wh = weak_frame(world)
+        ww, wh, wspp = shrink((ww, wh, C2[2]))
+        wjob = tiling.TiledRender(tracer, ww, wh, tile_rows=2) if tracer else None
+        wsteps = max(1, min(args.steps, 5))
+        if wjob:
+            wjob.render_n(wspp)
+            wjob.gather()
+        host_fence()
+        tw = time.perf_counter()
+        for _ in range(wsteps):
+            if wjob:
+                wjob.render_n(wspp)
+                wjob.gather_begin()
+        if wjob:
+            wjob.gather_end()
+        host_fence()
+        tw = time.perf_counter() - tw
+        t = torch.tensor([tw], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        extra["weak_scaling"] = {"workload": "AnalyticalScene %dx%d x %d spp per step (fixed pixels and samples per GPU)" % (ww, wh, wspp),
+                                 "steps": wsteps, "ms_per_step": round(float(t.item()) / wsteps * 1e3, 3),
+                                 "value": round(ww * wh * wspp * wsteps / float(t.item()) / 1e6, 2), "unit": "Msamples/s"}
+        # the same configs[2] frame on ONE GPU (rank 0 alone), for the strong-scaling ratio
+        if rank == 0:
+            solo = rpt.Tracer(scene, device=local_rank, seed=1)
+            sbuf = rpt.DeviceColorBuffer(width, height, device="cuda:%d" % local_rank)
+            solo.render_n(sbuf, max(1, spp // 8))           # warm
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            solo.render_n(sbuf, spp)
+            torch.cuda.synchronize()
+            ts = time.perf_counter() - ts
+            solo.close()
+            del sbuf
+            extra["strong_scaling"] = {"t1_ms": round(ts * 1e3, 3), "tN_ms": round(elapsed / args.steps * 1e3, 3),
+                                       "speedup": round(ts / (elapsed / args.steps), 3), "n_gpus": world,
+                                       "note": "same configs[2] frame rendered by rank 0 alone after the timed region (1 step)"}
+        dist.barrier()
 
     if rank == 0:
-        samples = width * height * SPP * args.steps
+        samples = width * height * spp * args.steps
         value = samples / elapsed / 1e6
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-        local_pixels = job.rows * width
-        # HBM roofline of the megakernel: the only framebuffer traffic is one 16 B read + one
-        # 16 B write of the RGBA-f32 running mean per pixel per launch (32/S B
-        # per pixel-sample x pixels*S samples per launch).
-        algo_bytes = 32.0 * local_pixels
-        achieved = algo_bytes / avg_kernel_s / 1e9
-        out = {
-            "metric": "Msamples/s (pixels x spp) on AnalyticalScene 1920x1080 f32",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "AnalyticalScene %dx%d x %d spp per step, f32, seed 1%s" %
-                                   (width, height, SPP, "" if world == 1 else ", cyclic 2-row tiles over %d GPUs + RCCL all-gather per step" % world),
-                       "spp_per_step": SPP, "width": width, "height": height, "parallelism": "rows%d" % world},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "kernel": "render_small_regen_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3),
-                         "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "the path is FP32-VALU bound (no dense contraction, 32/S bytes per sample): see roofline_valu"},
-        }
-        # HBM bytes per launch measured with rocprofv3 PMC passes of this same command (committed
-        # under profiles/; bench.py cannot collect counters itself)
-        tj = os.path.join(ROOT, "profiles", "r1", "v6_max_ilp", "traffic.json")
-        if world == 1 and os.path.exists(tj):
+        ops = op_counts()
+        # FP32-VALU roofline of the megakernel (no dense contraction, HBM is not the limiter):
+        # algorithmic flops per launch = flops per sample (measured by the oracle's op-counting build) x this rank's
+        # pixels x spp, over the launch's measured duration.
+        launch_samples = local_pixels * spp
+        tfl = ops["flops_per_sample"] * launch_samples / avg_kernel_s / 1e12
+        # the same work with every correctly rounded divide / sqrt counted at the 12 / 15 VALU instructions
+        # (~2 flops each where they are fmas) gfx950 needs for it: what the VALU actually has to issue
+        expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (2 * 12 - 1) + ops["sqrts_per_sample"] * (2 * 15 - 1)
+        algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
+        hbm = algo_bytes / avg_kernel_s / 1e9
+        launches = -(-spp // 512)                 # the kernel's LDS tables hold 512 samples: longer batches are split
+        roofline = {"bound": "fp32_valu", "achieved": round(tfl, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tfl / FP32_PEAK_TFLOPS, 5), "traffic": None,
+                    "kernel": "render_small_regen_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3), "launches_per_step": launches,
+                    "algorithmic_flops_per_step": ops["flops_per_sample"] * launch_samples, **ops,
+                    "ieee_expanded_flops_per_sample": round(expanded, 1),
+                    "ieee_expanded_frac": round(expanded * launch_samples / avg_kernel_s / 1e12 / FP32_PEAK_TFLOPS, 5),
+                    "note": "algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
+                            "rounded f32 divide or sqrt costs 12-15 VALU instructions on gfx950; kernel_ms = HIP events on the launch stream"}
+        tj = os.path.join(ROOT, TRAFFIC_JSON)
+        if world == 1 and not args.small and os.path.exists(tj):
             t = json.load(open(tj))
-            out["roofline"]["traffic"] = t["hbm_bytes_per_launch"]
-            out["roofline"]["traffic_source"] = "profiles/r1/v6_max_ilp/traffic.json (%s)" % t["correction"]
-        if world == 1 and not args.no_cpu_baseline:
-            cpu, ops = cpu_baseline(width, height)
+            roofline["traffic"] = t["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "%s: rocprofv3 PMC passes of this command, committed (%s); bench.py cannot collect counters itself" % (
+                TRAFFIC_JSON, t["correction"])
+        out = {
+            "metric": "Msamples/s (pixels x spp) on AnalyticalScene 1920x1080 f32; 1/2/4/8-GPU scaling",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if world == 1 else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[1])" % (width, height, spp)) if world == 1 else
+                                   ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[2]): cyclic 2-row tiles over %d GPUs, "
+                                    "RCCL gather to rank 0 + scatter per step inside the timed region" % (width, height, spp, world)),
+                       "spp_per_step": spp, "width": width, "height": height, "parallelism": "rows%d" % world},
+            "roofline": roofline,
+            "roofline_hbm": {"bound": "hbm", "achieved": round(hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 6),
+                             "algorithmic_bytes_per_step": algo_bytes,
+                             "note": "32/S bytes per pixel-sample: the honest signature of an ALU-bound path, not the binding roofline"},
+        }
+        out.update(extra)
+        if world == 1 and not args.no_cpu_baseline and not args.small:
+            cpu = cpu_baseline(width, height)
             out["cpu_baseline"] = cpu
-            tfl = ops["flops_per_sample"] * local_pixels * SPP / avg_kernel_s / 1e12
-            # the same work with every correctly rounded divide / sqrt counted at the 12 / 15 VALU instructions
-            # (~2 flops each where they are fmas) gfx950 needs for it: what the VALU actually has to issue
-            expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (2 * 12 - 1) + ops["sqrts_per_sample"] * (2 * 15 - 1)
-            out["roofline_valu"] = {"bound": "fp32_valu", "achieved": round(tfl, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                    "frac": round(tfl / FP32_PEAK_TFLOPS, 5), **ops,
-                                    "ieee_expanded_flops_per_sample": round(expanded, 1),
-                                    "ieee_expanded_frac": round(expanded * local_pixels * SPP / avg_kernel_s / 1e12 / FP32_PEAK_TFLOPS, 5),
-                                    "note": "algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); "
-                                            "a correctly rounded f32 divide or sqrt costs 12-15 VALU instructions on gfx950"}
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
+        if tracer:
+            tracer.close()
         dist.destroy_process_group()
-    tracer.close()
+    else:
+        tracer.close()
 
 
 if __name__ == "__main__":

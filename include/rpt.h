@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RPT_ABI_VERSION 1u
+#define RPT_ABI_VERSION 2u
 
 typedef enum rpt_status {
     RPT_OK              =  0,
@@ -36,7 +36,8 @@ typedef enum rpt_status {
     RPT_ERR_NO_DEVICE   = -2,   /* no usable gfx950 device: the product has no CPU fallback */
     RPT_ERR_HIP         = -3,   /* a HIP runtime call failed; see rpt_last_error */
     RPT_ERR_NO_SCENE    = -4,
-    RPT_ERR_UNSUPPORTED = -5
+    RPT_ERR_UNSUPPORTED = -5,
+    RPT_ERR_RCCL        = -6    /* an RCCL call failed (or librccl.so.1 could not be loaded); see rpt_last_error */
 } rpt_status;
 
 /* ---- scene as data ---------------------------------------------------------
@@ -107,7 +108,17 @@ typedef struct rpt_plane {            /* analytical.rs:193-204 generalised: dot(
 
 enum { RPT_LIGHT_RECTANGULAR = 0, RPT_LIGHT_SPHERICAL = 1, RPT_LIGHT_DISTANT = 2 };  /* globals.rs:69-73 */
 
-typedef struct rpt_light {            /* globals.rs:76-84; only SPHERICAL is sampled (tracer.rs:175-217) */
+/* globals.rs:76-84.  The reference samples and intersects only SPHERICAL lights (tracer.rs:175-217, scene.rs:68).
+ * With RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES the other two declared types work too — project-defined, after the
+ * renderer tracer.rs is a port of (its comments "Required for quad lights with single sided emission",
+ * tracer.rs:148, and "No MIS for distant light", tracer.rs:158, are that renderer's), in the operation order
+ * written in oracle/rpt_oracle.hpp:
+ *   RECTANGULAR  the parallelogram position + a*u + b*v, a,b in [0,1]; area = |u x v| (the caller supplies it);
+ *                sampled uniformly (2 draws), pdf = dist^2 / (area * |n.dir|), n = normalize(u x v); emits from the
+ *                side n points to; a ray reaching it from that side ends the path like a spherical light does.
+ *   DISTANT      direction = normalize(position), no draws, dist = +inf, pdf = 1, area = 0 (so no MIS weight);
+ *                never intersected. */
+typedef struct rpt_light {
     uint32_t type;
     float    position[3];
     float    emission[3];
@@ -168,7 +179,11 @@ typedef struct rpt_sdf {
 enum {                                /* rpt_scene_desc.flags */
     /* Scene::any_hit honours max_dist.  OFF reproduces analytical.rs:130, which
      * ignores it (anything along the shadow ray occludes). */
-    RPT_SCENE_ANYHIT_USES_MAX_DIST = 1u << 0
+    RPT_SCENE_ANYHIT_USES_MAX_DIST = 1u << 0,
+    /* Sample and intersect RECTANGULAR and DISTANT lights (project-defined, see rpt_light).  OFF reproduces the
+     * reference, whose sample_light and Scene::sample_lights only know LightType::Spherical (tracer.rs:175-217,
+     * scene.rs:68): such lights are still picked by the light-index draw but contribute nothing. */
+    RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES = 1u << 1
 };
 
 typedef struct rpt_scene_desc {
@@ -208,7 +223,14 @@ enum {
     /* Scenes with an SDF object: lanes submit their marches to a workgroup-wide queue in LDS that all four waves serve
      * (dev_sdf_pool.h) instead of marching their own ray.  Same image bit for bit; measured SLOWER (1.5 vs 2.2
      * Gsamples/s: DESIGN.md 4b), kept for A/B only. */
-    RPT_RENDER_SDF_POOL_MARCH = 1u << 4
+    RPT_RENDER_SDF_POOL_MARCH = 1u << 4,
+    /* Russian roulette (project-defined; the reference's bounce loop is a fixed `for _ in 0..depth` with three
+     * early exits, tracer.rs:61-103).  After the throughput update and the next-ray set-up of bounce b (0-based),
+     * when b + 1 >= 2 and b + 1 < depth:  q = clamp(max(throughput.x, throughput.y, throughput.z), 0.05, 1)
+     * (f32::max, so a NaN component is ignored);  one more draw r (after the bounce's other draws);  r >= q ends
+     * the path, otherwise throughput = throughput / q.  Same expectation, different samples: OFF (the default) is
+     * the reference.  Worth it for deep paths (max_depth > 4). */
+    RPT_RENDER_RUSSIAN_ROULETTE = 1u << 5
 };
 
 /* ---- context --------------------------------------------------------------- */
@@ -220,6 +242,38 @@ int rpt_create(rpt_ctx** out, int device_id);
 void rpt_destroy(rpt_ctx* ctx);
 const char* rpt_last_error(const rpt_ctx* ctx);   /* valid until the next call on ctx; ctx may be NULL */
 uint32_t rpt_abi_version(void);
+/* sizeof(rpt_scene_desc) as this library was built: a binding in another language asserts it against its own
+ * mirror of the struct before the first rpt_upload_scene (rust/gpu_tracer.rs does). */
+uint32_t rpt_sizeof_scene_desc(void);
+
+/* ---- the GPUs of one node (what replaces rayon's fan-out, tracer.rs:29-32) -----------------------------
+ * The reference's only parallel construct is INSIDE render(): one rayon task per scanline.  Here the image is
+ * row-tiled over the GPUs: rows are dealt cyclically in blocks of `tile_rows` rows (default 2; block b -> rank
+ * b % world; sky rows are ~10x cheaper than floor rows, so contiguous slabs would not balance), each GPU keeps
+ * its rows as a compact tile in its own HBM, ranks exchange nothing while rendering, and one RCCL gather over
+ * xGMI brings the tiles to the root (rank 0), where a small kernel scatters them into the top-down image.
+ * The RNG is keyed by the global pixel, so the image does not depend on the number of GPUs.
+ *
+ * Two ways to get there, same entry points afterwards:
+ *   rpt_create_multi   ONE process drives n devices (one host thread, one stream + tile per device,
+ *                      ncclCommInitAll): rpt_render / rpt_resident_* on such a context fan out over the
+ *                      devices inside the call, exactly where the reference fans out over threads.
+ *   rpt_create_rank    one process per GPU (torch.distributed.run, MPI, ...): rank 0 calls
+ *                      rpt_comm_unique_id, the host distributes those 128 bytes over any channel it has, every
+ *                      rank calls rpt_create_rank (ncclCommInitRank: collective).  rpt_resident_render,
+ *                      rpt_resident_gather_device, rpt_resident_download[_u8] are then collective calls: every
+ *                      rank makes them in the same order; destinations are only written on rank 0.
+ * A context from rpt_create is world = 1.                                                                */
+#define RPT_UNIQUE_ID_BYTES 128
+typedef struct rpt_unique_id { char bytes[RPT_UNIQUE_ID_BYTES]; } rpt_unique_id;
+
+int rpt_create_multi(rpt_ctx** out, const int* device_ids, int n_devices);
+int rpt_comm_unique_id(rpt_unique_id* out);
+int rpt_create_rank(rpt_ctx** out, int device_id, int rank, int world, const rpt_unique_id* id);
+/* rank of this context's first device, number of ranks in all, number of devices this context drives */
+int rpt_world(const rpt_ctx* ctx, int* rank, int* world, int* n_local);
+/* Rows per cyclic block for the NEXT resident buffer / rpt_render call (0 < tile_rows). */
+int rpt_set_tile_rows(rpt_ctx* ctx, uint32_t tile_rows);
 
 /* Copy the scene into the context (Tracer owns its scene: tracer.rs:8). */
 int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* scene);
@@ -242,9 +296,22 @@ int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height,
  * starts a new buffer (ColorBuffer::new, buffer.rs:18-26). */
 int rpt_resident_render(rpt_ctx* ctx, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint32_t flags);
 int rpt_resident_frames(const rpt_ctx* ctx, uint64_t* frames);          /* ColorBuffer.frames */
+/* Device time of the last rpt_resident_render's launches (HIP events on the stream they ran on; the slowest of this
+ * context's devices).  Waits for them. */
+int rpt_resident_kernel_ms(rpt_ctx* ctx, float* ms);
 int rpt_resident_download(rpt_ctx* ctx, float* pixels);                 /* width*height*4 f32 */
 int rpt_resident_download_u8(rpt_ctx* ctx, uint8_t* frame);             /* convert_to_u8 on the device, width*height*4 bytes */
 int rpt_resident_reset(rpt_ctx* ctx);
+/* The resident image assembled ON THE ROOT DEVICE (no PCIe): RCCL gather of the tiles + scatter kernel, enqueued
+ * behind the renders on the context's streams.  image_dev: width*height*4 f32 on rank 0's device (ignored on other
+ * ranks; NULL = into the context's own staging image).  Returns without waiting; rpt_resident_sync waits.
+ * world = 1: a device-to-device copy. */
+int rpt_resident_gather_device(rpt_ctx* ctx, float* image_dev);
+/* Block until everything enqueued on this context's devices has finished. */
+int rpt_resident_sync(rpt_ctx* ctx);
+/* Start the resident buffer from a host ColorBuffer (pixels + frames): what resuming a cloned ColorBuffer is in the
+ * reference (buffer.rs:5 derives Clone).  Each rank uploads only the rows it owns. */
+int rpt_resident_upload(rpt_ctx* ctx, const float* pixels, uint32_t width, uint32_t height, uint64_t frames);
 
 /* Same on a DEVICE-resident buffer, asynchronously on `stream` (a hipStream_t; NULL is
  * HIP's null stream).  With world > 1 the image is row-tiled: rows are
@@ -260,6 +327,17 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
 uint32_t rpt_tile_row_count(uint32_t height, uint32_t tile_rows, uint32_t rank, uint32_t world);
 /* Global image row of local row `local_row` of rank `rank`. */
 uint32_t rpt_tile_global_row(uint32_t local_row, uint32_t tile_rows, uint32_t rank, uint32_t world);
+/* Rows of the largest tile: what every rank's tile buffer is padded to, so that the gather moves equal counts. */
+uint32_t rpt_tile_rows_padded(uint32_t height, uint32_t tile_rows, uint32_t world);
+/* How a rank's rows move between a top-down host image and its compact tile (what rpt_render / rpt_resident_upload
+ * do per device, each over its own PCIe link): `full_blocks` blocks of `block_rows` rows, block i at host row
+ * host_row0 + i * host_row_stride and at tile row i * block_rows (ONE strided copy), plus `ragged_rows` rows of the
+ * image's short last block from host row ragged_host_row0 to tile row ragged_tile_row0 when this rank owns it. */
+typedef struct rpt_tile_plan {
+    uint32_t full_blocks, block_rows, host_row0, host_row_stride;
+    uint32_t ragged_rows, ragged_host_row0, ragged_tile_row0;
+} rpt_tile_plan;
+int rpt_tile_copy_plan(uint32_t height, uint32_t tile_rows, uint32_t rank, uint32_t world, rpt_tile_plan* out);
 
 /* Scatter a rank-major concatenation of compact tiles (what an all-gather of the
  * per-rank tile buffers yields, each padded to `rows_padded` rows) into the full
@@ -296,6 +374,27 @@ enum {
 };
 int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b_dev,
                    float* out_dev, uint64_t n, void* stream);
+
+/* One integrator function per record, for tests that localise a frame mismatch: records are RPT_PROBE_IN_STRIDE floats
+ * in, RPT_PROBE_OUT_STRIDE floats out (u32 values as their bit patterns), device pointers.  Layouts (in -> out):
+ *   GEN_RAY        {px, py, offx, offy}; camera = the uploaded scene's, params = {width, height} (host)
+ *                  -> {origin[3], direction[3]}                                      camera/pinhole.rs:38-60
+ *   HIT_SPHERE     {o[3], d[3], centre[3], radius} -> {hit, t}                       analytical.rs:166-190
+ *   HIT_PLANE      {o[3], d[3], normal[3], point[3], min_denom, max_t} -> {hit, t}   analytical.rs:193-204
+ *   SAMPLE_LIGHT   {type, position[3], emission[3], radius, area, u[3], v[3], scatter_pos[3], n_lights, scene flags,
+ *                   fkey, pixel, counter} -> {normal[3], emission[3], direction[3], dist, pdf, draws}   tracer.rs:173-220
+ *   DISNEY_EVAL    {material: rgb[3], emission[3], anisotropic, metallic, roughness, subsurface, specular_tint, sheen,
+ *                   sheen_tint, clearcoat, clearcoat_gloss, spec_trans, ior (before finalize), eta, v[3], n[3], l[3]}
+ *                  -> {f[3], pdf}                                                    tracer.rs:555-626
+ *   DISNEY_SAMPLE  {material (17), eta, v[3], n[3], l_stale[3], fkey, pixel, counter}
+ *                  -> {f[3], l[3], pdf, draws}                                       tracer.rs:441-553            */
+enum {
+    RPT_PROBE_FN_GEN_RAY = 0, RPT_PROBE_FN_HIT_SPHERE = 1, RPT_PROBE_FN_HIT_PLANE = 2, RPT_PROBE_FN_SAMPLE_LIGHT = 3,
+    RPT_PROBE_FN_DISNEY_EVAL = 4, RPT_PROBE_FN_DISNEY_SAMPLE = 5, RPT_PROBE_FN_COUNT = 6
+};
+#define RPT_PROBE_IN_STRIDE 32
+#define RPT_PROBE_OUT_STRIDE 16
+int rpt_probe_fn(rpt_ctx* ctx, uint32_t fn, const float* in_dev, float* out_dev, uint64_t n, const float* params, void* stream);
 
 /* Ray queries against the uploaded LARGE scene's spheres, for testing the acceleration structure:
  * rays_dev = n x {origin[3], direction[3], max_dist}; out_dev = n x {t (f32 bits), nearest sphere index

@@ -64,6 +64,26 @@ struct AnalyticalLight {
         l.light.area = 4.0f * 3.14159265358979323846f * radius * radius;      // light.rs:22
         return l;
     }
+    // LightType::Rectangular / Distant (globals.rs:69-73): declared by the reference, sampled only in scenes with
+    // sample_all_light_types (project-defined, see rpt.h)
+    static AnalyticalLight rectangular(F3 position, F3 u, F3 v, F3 emission) {
+        AnalyticalLight l;
+        l.light.type = RPT_LIGHT_RECTANGULAR;
+        l.light.position[0] = position.x; l.light.position[1] = position.y; l.light.position[2] = position.z;
+        l.light.emission[0] = emission.x; l.light.emission[1] = emission.y; l.light.emission[2] = emission.z;
+        l.light.u[0] = u.x; l.light.u[1] = u.y; l.light.u[2] = u.z;
+        l.light.v[0] = v.x; l.light.v[1] = v.y; l.light.v[2] = v.z;
+        const double cx = (double)u.y * v.z - (double)u.z * v.y, cy = (double)u.z * v.x - (double)u.x * v.z, cz = (double)u.x * v.y - (double)u.y * v.x;
+        l.light.area = (float)std::sqrt(cx * cx + cy * cy + cz * cz);
+        return l;
+    }
+    static AnalyticalLight distant(F3 position, F3 emission) {
+        AnalyticalLight l;
+        l.light.type = RPT_LIGHT_DISTANT;
+        l.light.position[0] = position.x; l.light.position[1] = position.y; l.light.position[2] = position.z;
+        l.light.emission[0] = emission.x; l.light.emission[1] = emission.y; l.light.emission[2] = emission.z;
+        return l;
+    }
 };
 
 // Data-driven counterpart of trait Scene (scene.rs:5-90): the scene describes itself.
@@ -77,6 +97,7 @@ struct Scene {
     float eps = 0.005f;                        // tracer.rs:16
     uint32_t max_depth = 4;                    // scene.rs:28-30
     bool any_hit_uses_max_dist = false;
+    bool sample_all_light_types = false;       // rectangular / distant lights do something (off = the reference)
     virtual ~Scene() = default;
 
     size_t number_of_lights() const { return lights.size(); }
@@ -89,7 +110,7 @@ struct Scene {
         for (const auto& l : lights) lights_flat_.push_back(l.light);
         rpt_scene_desc d{};
         d.abi_version = RPT_ABI_VERSION;
-        d.flags = any_hit_uses_max_dist ? RPT_SCENE_ANYHIT_USES_MAX_DIST : 0u;
+        d.flags = (any_hit_uses_max_dist ? RPT_SCENE_ANYHIT_USES_MAX_DIST : 0u) | (sample_all_light_types ? RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES : 0u);
         d.camera.origin[0] = camera.origin.x; d.camera.origin[1] = camera.origin.y; d.camera.origin[2] = camera.origin.z;
         d.camera.center[0] = camera.center.x; d.camera.center[1] = camera.center.y; d.camera.center[2] = camera.center.z;
         d.camera.fov_deg = camera.fov;
@@ -132,6 +153,13 @@ public:
         check(rpt_create(&ctx_, device), nullptr);
         sync_scene();
     }
+    /// The GPUs of a node driven by this process: render() fans the rows out over them inside the call, where the
+    /// reference fans out over rayon's threads (tracer.rs:29-32).
+    Tracer(Scene* scene, const std::vector<int>& devices, uint64_t seed = 1) : scene_(scene), seed_(seed) {
+        check(rpt_create_multi(&ctx_, devices.data(), (int)devices.size()), nullptr);
+        sync_scene();
+    }
+    void set_tile_rows(uint32_t tile_rows) { check(rpt_set_tile_rows(ctx_, tile_rows), ctx_); }
     ~Tracer() { rpt_destroy(ctx_); }
     Tracer(const Tracer&) = delete;
     Tracer& operator=(const Tracer&) = delete;

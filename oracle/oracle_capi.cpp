@@ -122,6 +122,21 @@ int oracle_render(const rpt_scene_desc* desc, float* pixels, uint32_t width, uin
     return 0;
 }
 
+// The same with RPT_RENDER_* flags (only RPT_RENDER_RUSSIAN_ROULETTE changes what the oracle computes).
+int oracle_render_flags(const rpt_scene_desc* desc, float* pixels, uint32_t width, uint32_t height, uint64_t frames_done,
+                        uint32_t spp, uint64_t seed, uint32_t row_begin, uint32_t row_end, int nthreads, uint32_t render_flags)
+{
+    if (!desc || !pixels || width == 0 || height == 0 || row_end > height || row_begin > row_end) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    Scene scene(*desc);
+    Tracer tracer(scene);
+    tracer.russian_roulette = (render_flags & RPT_RENDER_RUSSIAN_ROULETTE) != 0;
+    tracer.render(pixels, width, height, frames_done, spp, seed, row_begin, row_end);
+    return 0;
+}
+
 // Radiance of single pixel-samples (no accumulation): out[3*k..] for k-th (col,row,frame).
 int oracle_sample_pixels(const rpt_scene_desc* desc, const uint32_t* cols, const uint32_t* rows, const uint64_t* frames,
                          uint64_t n, uint32_t width, uint32_t height, uint64_t seed, float* out)
@@ -277,6 +292,26 @@ void oracle_disney_sample(const float* m, float eta, const float* v, const float
     out[0] = raw(f.x); out[1] = raw(f.y); out[2] = raw(f.z);
     out[3] = raw(l.x); out[4] = raw(l.y); out[5] = raw(l.z);
     out[6] = raw(pdf); out[7] = (float)(rng.counter - counter);
+}
+
+// sample_light with an explicit RNG position: light = rpt_light; out = {normal[3], emission[3], direction[3], dist, pdf, draws_used}
+void oracle_sample_light(const rpt_light* light, const float* scatter_pos, uint32_t n_lights, uint32_t scene_flags,
+                         uint32_t fkey, uint32_t pixel, uint32_t counter, float* out)
+{
+    rpt_scene_desc d; build_analytical(&d);
+    std::vector<rpt_light> lights(n_lights ? n_lights : 1, *light);                // number_of_lights() scales the emission
+    d.n_lights = n_lights; d.lights = lights.data();
+    d.flags = scene_flags;
+    Scene scene(d);
+    Tracer tr(scene);
+    Rng rng(fkey, pixel);
+    rng.counter = counter;
+    LightSampleRec ls;
+    tr.sample_light(*light, F3(scatter_pos[0], scatter_pos[1], scatter_pos[2]), ls, rng);
+    out[0] = raw(ls.normal.x); out[1] = raw(ls.normal.y); out[2] = raw(ls.normal.z);
+    out[3] = raw(ls.emission.x); out[4] = raw(ls.emission.y); out[5] = raw(ls.emission.z);
+    out[6] = raw(ls.direction.x); out[7] = raw(ls.direction.y); out[8] = raw(ls.direction.z);
+    out[9] = raw(ls.dist); out[10] = raw(ls.pdf); out[11] = (float)(rng.counter - counter);
 }
 
 // RNG stream: first n u32 draws of (seed, frame, pixel)

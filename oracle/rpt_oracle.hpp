@@ -456,6 +456,36 @@ struct Scene {
                         hit = true;
                     }
                 }
+            } else if (light.type == RPT_LIGHT_RECTANGULAR && (d.flags & RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES)) {
+                // PROJECT-DEFINED (include/rpt.h, rpt_light): the reference intersects spherical lights only (scene.rs:68).
+                // The parallelogram position + a*u + b*v, seen from the side its normal points to.
+                F3 pos(light.position[0], light.position[1], light.position[2]);
+                F3 u(light.u[0], light.u[1], light.u[2]), v(light.v[0], light.v[1], light.v[2]);
+                F3 n = normalize(cross(u, v));
+                if (dot(n, ray.direction) > F(0.0f)) continue;                     // back side: invisible
+                F plane_w = dot(n, pos);
+                F3 uu = u.mult_f(F(1.0f) / dot(u, u));
+                F3 vv = v.mult_f(F(1.0f) / dot(v, v));
+                F dt = dot(ray.direction, n);
+                F dd = (plane_w - dot(n, ray.origin)) / dt;
+                if (dd >= F(0.0f)) {                                               // (NaN and -inf fail this test)
+                    F3 vi = ray.at(dd) - pos;
+                    F a1 = dot(uu, vi);
+                    if (a1 >= F(0.0f) && a1 <= F(1.0f)) {
+                        F a2 = dot(vv, vi);
+                        if (a2 >= F(0.0f) && a2 <= F(1.0f)) {
+                            if (dd < dist) {
+                                dist = dd;
+                                F cos_theta = dot(-ray.direction, n);
+                                light_sample.pdf = (dist * dist) / (F(light.area) * cos_theta);
+                                light_sample.emission = F3(light.emission[0], light.emission[1], light.emission[2]);
+                                state.is_emitter = true;
+                                state.hit_dist = dd;
+                                hit = true;
+                            }
+                        }
+                    }
+                }
             }
         }
         return hit;
@@ -544,6 +574,7 @@ struct Scene {
 struct Tracer {
     F eps;
     const Scene& scene;
+    bool russian_roulette = false;                                                 // project extension, see sample_pixel
     explicit Tracer(const Scene& s) : eps(s.d.eps), scene(s) {}                    // tracer.rs:13-19
 
     static F power_heuristic(F a, F b) { F t = a * a; return t / (b * b + t); }    // tracer.rs:223-226
@@ -859,7 +890,33 @@ struct Tracer {
     // tracer.rs:173-220 (only LightType::Spherical does anything)
     void sample_light(const rpt_light& light, const F3& scatter_pos, LightSampleRec& light_sample, Rng& rng) const
     {
-        if (light.type != RPT_LIGHT_SPHERICAL) return;
+        if (light.type != RPT_LIGHT_SPHERICAL) {
+            // tracer.rs:217: `_ => {}` — the reference does nothing for the other two declared types.
+            if (!(scene.d.flags & RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES)) return;
+            // PROJECT-DEFINED from here (include/rpt.h, rpt_light)
+            F3 position(light.position[0], light.position[1], light.position[2]);
+            F3 emission(light.emission[0], light.emission[1], light.emission[2]);
+            if (light.type == RPT_LIGHT_RECTANGULAR) {
+                F r1 = rng.gen();
+                F r2 = rng.gen();
+                F3 u(light.u[0], light.u[1], light.u[2]), v(light.v[0], light.v[1], light.v[2]);
+                F3 light_surface_pos = position + r1 * u + r2 * v;
+                light_sample.direction = light_surface_pos - scatter_pos;
+                light_sample.dist = length(light_sample.direction);
+                F dist_sq = light_sample.dist * light_sample.dist;
+                light_sample.direction /= F3::new_x(light_sample.dist);
+                light_sample.normal = normalize(cross(u, v));
+                light_sample.emission = F((float)scene.number_of_lights()) * emission;
+                light_sample.pdf = dist_sq / (F(light.area) * f_abs(dot(light_sample.normal, light_sample.direction)));
+            } else {                                                               // RPT_LIGHT_DISTANT: no draws
+                light_sample.direction = normalize(position);
+                light_sample.normal = normalize(scatter_pos - position);
+                light_sample.emission = F((float)scene.number_of_lights()) * emission;
+                light_sample.dist = F(INFINITY);
+                light_sample.pdf = F(1.0f);
+            }
+            return;
+        }
         F r1 = rng.gen();
         F r2 = rng.gen();
         F3 light_position(light.position[0], light.position[1], light.position[2]);
@@ -968,6 +1025,15 @@ struct Tracer {
             else { log_event('x'); break; }
             ray.direction = scatter_sample.l;
             ray.origin = state.fhp + eps * ray.direction;
+            // PROJECT-DEFINED, off by default (include/rpt.h, RPT_RENDER_RUSSIAN_ROULETTE): the reference's loop has no
+            // roulette (tracer.rs:61-103).  One more draw, after all other draws of the bounce.
+            if (russian_roulette && (uint32_t)bounce + 1u >= 2u && (uint32_t)bounce + 1u < (uint32_t)state.depth) {
+                F q = f_max(f_max(throughput.x, throughput.y), throughput.z);
+                q = f_clamp(q, 0.05f, 1.0f);
+                F r = rng.gen();
+                if (r >= q) { log_event('r'); break; }
+                throughput = throughput / F3::new_x(q);
+            }
         }
         log_event('.');
         return radiance;

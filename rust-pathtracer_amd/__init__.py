@@ -6,4 +6,4 @@ The directory is named `rust-pathtracer_amd`; import it as `rust_pathtracer_amd`
 from . import _abi  # noqa: F401
 from ._lib import RptError, lib  # noqa: F401
 from .api import (AnalyticalLight, AnalyticalScene, ColorBuffer, DeviceColorBuffer, Material, Pinhole, Scene,  # noqa: F401
-                  Tracer)
+                  Tracer, comm_unique_id)

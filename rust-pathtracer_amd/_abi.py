@@ -1,7 +1,7 @@
 """ctypes mirror of include/rpt.h (the C ABI).  Plain data only."""
 import ctypes as C
 
-RPT_ABI_VERSION = 1
+RPT_ABI_VERSION = 2
 
 RPT_OK = 0
 RPT_ERR_INVALID_ARG = -1
@@ -9,6 +9,7 @@ RPT_ERR_NO_DEVICE = -2
 RPT_ERR_HIP = -3
 RPT_ERR_NO_SCENE = -4
 RPT_ERR_UNSUPPORTED = -5
+RPT_ERR_RCCL = -6
 
 RPT_MAT_RGB = 1 << 0
 RPT_MAT_EMISSION = 1 << 1
@@ -36,6 +37,7 @@ RPT_BG_CONSTANT = 0
 RPT_BG_GRADIENT_Y = 1
 
 RPT_SCENE_ANYHIT_USES_MAX_DIST = 1 << 0
+RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES = 1 << 1
 
 RPT_RENDER_DEFAULT = 0
 RPT_RENDER_NESTED_LOOPS = 1 << 0
@@ -43,8 +45,14 @@ RPT_RENDER_FAST_MATH = 1 << 1
 RPT_RENDER_SDF_INLINE_MARCH = 1 << 2
 RPT_RENDER_GRID_RESUMABLE_WALK = 1 << 3
 RPT_RENDER_SDF_POOL_MARCH = 1 << 4
+RPT_RENDER_RUSSIAN_ROULETTE = 1 << 5
 
 RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG = range(7)
+(RPT_PROBE_FN_GEN_RAY, RPT_PROBE_FN_HIT_SPHERE, RPT_PROBE_FN_HIT_PLANE, RPT_PROBE_FN_SAMPLE_LIGHT, RPT_PROBE_FN_DISNEY_EVAL,
+ RPT_PROBE_FN_DISNEY_SAMPLE, RPT_PROBE_FN_COUNT) = range(7)
+RPT_PROBE_IN_STRIDE = 32
+RPT_PROBE_OUT_STRIDE = 16
+RPT_UNIQUE_ID_BYTES = 128
 
 F3 = C.c_float * 3
 F4 = C.c_float * 4
@@ -109,8 +117,30 @@ class rpt_scene_desc(C.Structure):
     ]
 
 
+class rpt_tile_plan(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("full_blocks", "block_rows", "host_row0", "host_row_stride", "ragged_rows",
+                                           "ragged_host_row0", "ragged_tile_row0")]
+
+
+class rpt_unique_id(C.Structure):
+    _fields_ = [("bytes", C.c_char * RPT_UNIQUE_ID_BYTES)]
+
+
 # every symbol include/rpt.h declares: name -> (restype, argtypes)
 SYMBOLS = {
+    "rpt_sizeof_scene_desc": (C.c_uint32, []),
+    "rpt_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
+    "rpt_comm_unique_id": (C.c_int, [C.POINTER(rpt_unique_id)]),
+    "rpt_create_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(rpt_unique_id)]),
+    "rpt_world": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rpt_set_tile_rows": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rpt_resident_gather_device": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rpt_resident_sync": (C.c_int, [C.c_void_p]),
+    "rpt_resident_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "rpt_resident_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "rpt_tile_rows_padded": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rpt_tile_copy_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(rpt_tile_plan)]),
+    "rpt_probe_fn": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rpt_scene_analytical": (C.c_int, [C.POINTER(rpt_scene_desc)]),
     "rpt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "rpt_destroy": (None, [C.c_void_p]),

@@ -22,7 +22,7 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(
-                "%s not found: build it with `python -m rust_pathtracer_amd.build` or __graft_entry__.build(); "
+                "%s not found: build it with `python rust-pathtracer_amd/build.py` or __graft_entry__.build(); "
                 "the product path has no CPU fallback" % LIB_PATH)
         # torch bundles its own libamdhip64.so.7 / libhsa-runtime64.so.1.  If this library were
         # loaded first it would bind to /opt/rocm's copies and torch would then bring in a second

@@ -39,20 +39,34 @@ class Pinhole:
 
 
 class AnalyticalLight:
-    """light.rs:6-28"""
+    """light.rs:6-28 (globals.rs:76-84 for the fields)"""
 
-    def __init__(self, light_type, position, emission, radius, area):
+    def __init__(self, light_type, position, emission, radius, area, u=(0.0, 0.0, 0.0), v=(0.0, 0.0, 0.0)):
         self.light_type = light_type
         self.position = tuple(position)
         self.emission = tuple(emission)
         self.radius = float(radius)
         self.area = float(area)
+        self.u = tuple(u)
+        self.v = tuple(v)
 
     @staticmethod
     def spherical(position, radius, emission):
         r = np.float32(radius)
         area = np.float32(4.0) * np.float32(math.pi) * r * r          # light.rs:22, f32 left to right
         return AnalyticalLight(_abi.RPT_LIGHT_SPHERICAL, position, emission, radius, float(area))
+
+    @staticmethod
+    def rectangular(position, u, v, emission):
+        """LightType::Rectangular (globals.rs:70): the parallelogram position + a*u + b*v.  The reference declares the type
+        and has no constructor or sampling code for it; sampled only in scenes with sample_all_light_types (include/rpt.h)."""
+        c = np.cross(np.asarray(u, dtype=np.float64), np.asarray(v, dtype=np.float64))
+        return AnalyticalLight(_abi.RPT_LIGHT_RECTANGULAR, position, emission, 0.0, float(np.float32(np.sqrt((c * c).sum()))), u, v)
+
+    @staticmethod
+    def distant(position, emission):
+        """LightType::Distant (globals.rs:72): light from the direction normalize(position); area 0 = no MIS (tracer.rs:158)."""
+        return AnalyticalLight(_abi.RPT_LIGHT_DISTANT, position, emission, 0.0, 0.0)
 
 
 class Material:
@@ -102,6 +116,7 @@ class Scene:
         self.eps = 0.005         # tracer.rs:16
         self.max_depth = 4       # scene.rs:28-30
         self.any_hit_uses_max_dist = False
+        self.sample_all_light_types = False   # rectangular / distant lights do something (project-defined; off = the reference)
         self.sdf = None          # dict(prims=[(kind, center, (p0, p1))], material, smooth_k, max_steps, hit_eps, max_t, normal_eps)
         self._keep = None
 
@@ -118,7 +133,8 @@ class Scene:
         """-> rpt_scene_desc (keeps the backing arrays alive on self)."""
         d = _abi.rpt_scene_desc()
         d.abi_version = _abi.RPT_ABI_VERSION
-        d.flags = _abi.RPT_SCENE_ANYHIT_USES_MAX_DIST if self.any_hit_uses_max_dist else 0
+        d.flags = (_abi.RPT_SCENE_ANYHIT_USES_MAX_DIST if self.any_hit_uses_max_dist else 0) | \
+                  (_abi.RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES if self.sample_all_light_types else 0)
         d.camera.origin = _abi.F3(*self.camera.origin)
         d.camera.center = _abi.F3(*self.camera.center)
         d.camera.fov_deg = self.camera.fov
@@ -141,7 +157,7 @@ class Scene:
         li = (_abi.rpt_light * max(1, len(self.lights)))()
         for i, L in enumerate(self.lights):
             li[i].type = L.light_type; li[i].position = _abi.F3(*L.position); li[i].emission = _abi.F3(*L.emission)
-            li[i].radius = L.radius; li[i].area = L.area
+            li[i].radius = L.radius; li[i].area = L.area; li[i].u = _abi.F3(*L.u); li[i].v = _abi.F3(*L.v)
         ma = (_abi.rpt_material * max(1, len(self.materials)))()
         for i, M in enumerate(self.materials):
             ma[i] = M.to_c()
@@ -262,17 +278,49 @@ def _convert_to_u8_tensor(pixels, width, height):
     return out
 
 
-class Tracer:
-    """tracer.rs:5-19.  Owns the scene; render() is the boundary into the HIP library."""
+def comm_unique_id():
+    """128 opaque bytes from rank 0 that every rank passes to Tracer(..., rank=, world=, unique_id=) (ncclGetUniqueId)."""
+    uid = _abi.rpt_unique_id()
+    check(lib().rpt_comm_unique_id(C.byref(uid)))
+    return C.string_at(C.byref(uid), _abi.RPT_UNIQUE_ID_BYTES)
 
-    def __init__(self, scene, device=0, seed=1):
+
+class Tracer:
+    """tracer.rs:5-19.  Owns the scene; render() is the boundary into the HIP library.
+
+    Tracer(scene, device=0)                       one GPU
+    Tracer(scene, devices=[0, 1, ...])            the GPUs of a node driven by this process: render() fans out over them
+                                                  inside the call, where the reference fans out over rayon threads
+    Tracer(scene, device=d, rank=r, world=n,      one process per GPU (torch.distributed.run): collective construction;
+           unique_id=comm_unique_id() of rank 0)  the resident_* calls are then collective too"""
+
+    def __init__(self, scene, device=0, seed=1, devices=None, rank=None, world=None, unique_id=None):
         self._scene = scene
         self.seed = int(seed)
-        self.device = int(device)
         self.flags = 0                 # RPT_RENDER_* bits (0 = the strict, bit-exact regenerating kernel)
         self._h = C.c_void_p()
-        check(lib().rpt_create(C.byref(self._h), self.device))
+        if devices is not None:
+            ids = (C.c_int * len(devices))(*devices)
+            self.device = int(devices[0])
+            check(lib().rpt_create_multi(C.byref(self._h), ids, len(devices)))
+        elif world is not None:
+            uid = _abi.rpt_unique_id()
+            C.memmove(C.byref(uid), unique_id, _abi.RPT_UNIQUE_ID_BYTES)
+            self.device = int(device)
+            check(lib().rpt_create_rank(C.byref(self._h), self.device, int(rank), int(world), C.byref(uid)))
+        else:
+            self.device = int(device)
+            check(lib().rpt_create(C.byref(self._h), self.device))
         self.upload_scene()
+
+    def world(self):
+        """(rank of this context's first device, ranks in all, devices this context drives)"""
+        r, w, n = C.c_int(), C.c_int(), C.c_int()
+        check(lib().rpt_world(self._h, C.byref(r), C.byref(w), C.byref(n)), self._h)
+        return r.value, w.value, n.value
+
+    def set_tile_rows(self, tile_rows):
+        check(lib().rpt_set_tile_rows(self._h, int(tile_rows)), self._h)
 
     def upload_scene(self):
         """Call after mutating the scene returned by scene()."""
@@ -312,6 +360,7 @@ class Tracer:
         return f.value
 
     def resident_to_host(self, width, height):
+        """Collective on a multi-process tracer; every rank gets a ColorBuffer, only rank 0's is filled."""
         b = ColorBuffer(width, height)
         check(lib().rpt_resident_download(self._h, b.pixels.ctypes.data), self._h)
         b.frames = self.resident_frames()
@@ -324,6 +373,24 @@ class Tracer:
 
     def resident_reset(self):
         check(lib().rpt_resident_reset(self._h), self._h)
+
+    def resident_upload(self, buffer):
+        """Start the resident buffer from a host ColorBuffer (resume; each rank takes the rows it owns)."""
+        assert buffer.pixels.dtype == np.float32 and buffer.pixels.size == buffer.width * buffer.height * 4
+        check(lib().rpt_resident_upload(self._h, buffer.pixels.ctypes.data, buffer.width, buffer.height, buffer.frames), self._h)
+
+    def resident_gather(self, image=None):
+        """Enqueue the assembly of the resident image on the root device (RCCL gather over xGMI + scatter kernel).
+        image: a [h, w, 4] f32 CUDA tensor on rank 0's device, or None (the library's own staging image)."""
+        check(lib().rpt_resident_gather_device(self._h, image.data_ptr() if image is not None else None), self._h)
+
+    def resident_sync(self):
+        check(lib().rpt_resident_sync(self._h), self._h)
+
+    def resident_kernel_ms(self):
+        ms = C.c_float(0.0)
+        check(lib().rpt_resident_kernel_ms(self._h, C.byref(ms)), self._h)
+        return ms.value
 
     def render_tile(self, tile_pixels, width, height, frames_done, spp, tile_rows, rank, world):
         """Render this rank's rows of a row-tiled image into its compact tile tensor."""

@@ -1,7 +1,14 @@
-"""Build the HIP extension (librpt_hip.so) for gfx950, in-tree."""
+"""Build the HIP extension (librpt_hip.so) for gfx950, in-tree.
+
+    python rust-pathtracer_amd/build.py            # the shipped library
+    python rust-pathtracer_amd/build.py --ab       # + the measured-slower A/B kernel forms (csrc/ab/, -DRPT_AB_KERNELS)
+"""
+import glob
 import os
 import shutil
 import subprocess
+import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
@@ -9,8 +16,6 @@ LIB = os.path.join(HERE, "librpt_hip.so")
 SOURCES = ["kernels.hip", "kernels_fast.hip", "capi.hip"]
 # kernels_fast.hip: the same kernels with relaxed arithmetic (RPT_RENDER_FAST_MATH); every other file is strict
 EXTRA_FLAGS = {"kernels_fast.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"]}
-HEADERS = ["dev_math.h", "dev_prof.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_large.h", "dev_integrator.h", "launch.h", "host_scene.h",
-           os.path.join("..", "..", "include", "rpt.h"), os.path.join("..", "..", "include", "rpt_strict_math.h")]
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
 # fused operations are the explicit fma calls of rpt_strict_math.h.
 # -mllvm -disable-machine-licm: MachineLICM hoists the materialisation of ~70 literal constants (the
@@ -21,46 +26,67 @@ HEADERS = ["dev_math.h", "dev_prof.h", "dev_bsdf.h", "dev_scene.h", "dev_scene_l
 # -mllvm -amdgpu-sched-strategy=max-ilp: the machine scheduler interleaves independent chains (the three divides of a
 #   normalize, the three pow of the background) instead of minimising register pressure first: +2 % on configs[1]
 #   and [3] at the same 96 VGPRs (iterative-ilp / iterative-minreg: no gain).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize",
-         "-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-fPIC"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
 # The two -mllvm options are tuning only (they change instruction order / register use, never a result); a toolchain that
-# does not know them still builds the library without them.
+# does not know them still builds the library without them (probed once, on an empty translation unit).
 TUNING_FLAGS = ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+
+_tuning_ok = None
 
 
 def _hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
-def needs_build():
-    if not os.path.exists(LIB):
+def _tuning_flags():
+    """TUNING_FLAGS if this hipcc accepts them, else []."""
+    global _tuning_ok
+    if _tuning_ok is None:
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "empty.hip")
+            open(src, "w").write("#include <hip/hip_runtime.h>\n__global__ void k() {}\n")
+            r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3"] + TUNING_FLAGS + ["-c", src, "-o", os.path.join(d, "empty.o")],
+                               capture_output=True)
+            _tuning_ok = r.returncode == 0
+            if not _tuning_ok:
+                print("build.py: this hipcc rejects the -mllvm tuning options; building without them")
+    return TUNING_FLAGS if _tuning_ok else []
+
+
+def _deps():
+    """Every file a change of which means a rebuild: all sources and headers under csrc/ (csrc/ab/ too) and include/."""
+    inc = os.path.join(HERE, "..", "include")
+    return (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "ab", "*.h")) +
+            glob.glob(os.path.join(inc, "*.h")) + [os.path.abspath(__file__)])
+
+
+def needs_build(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    t = os.path.getmtime(lib)
+    return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="build"):
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="build", ab=False):
     """Compile csrc/*.hip -> librpt_hip.so.  hipcc cross-compiles gfx950 without a GPU.
-    `extra_flags` / `lib` / `objdir_name`: experiment builds next to the product library (tools/)."""
-    if not force and not needs_build():
+    `extra_flags` / `lib` / `objdir_name`: experiment builds next to the product library (tools/); `ab`: include the A/B kernels."""
+    if not force and not needs_build(lib):
         return lib
     objdir = os.path.join(HERE, objdir_name)
     os.makedirs(objdir, exist_ok=True)
+    flags = BASE_FLAGS + _tuning_flags() + (["-DRPT_AB_KERNELS"] if ab else [])
     procs, objs = [], []
     for src in SOURCES:                                   # one object per source (each with its own flags), in parallel
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
         objs.append(obj)
-    for cmd, p in procs:
-        if p.wait() != 0:
-            plain = [c for c in cmd if c not in TUNING_FLAGS]
-            print("build.py: retrying without the -mllvm tuning options: " + " ".join(plain))
-            subprocess.run(plain, check=True, cwd=CSRC)
-    link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-o", lib]
+    failed = [" ".join(cmd) for cmd, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("build.py: compilation failed:\n" + "\n".join(failed))
+    link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-ldl", "-o", lib]
     if verbose:
         print(" ".join(link))
     subprocess.run(link, check=True, cwd=CSRC)
@@ -68,4 +94,4 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="buil
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force=True, verbose=True, ab="--ab" in sys.argv[1:]))

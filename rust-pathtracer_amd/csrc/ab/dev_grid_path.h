@@ -16,7 +16,7 @@
 // loop, and the outcome is handed to the unchanged plane / light / shading code through GridInjectedQuery, so images
 // are bit-identical to the bounce-granular kernel (tests/test_gpu_parity.py, large-scene cases).
 #pragma once
-#include "dev_scene_large.h"
+#include "../dev_scene_large.h"
 
 namespace rptdev {
 

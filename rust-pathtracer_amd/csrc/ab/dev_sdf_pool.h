@@ -26,7 +26,7 @@
 // and the outcome feeds the same closest_hit / any_hit code, so images stay bit-identical
 // (tests/test_gpu_parity.py, SDF cases run all three kernel forms).
 #pragma once
-#include "dev_sdf_path.h"
+#include "../dev_sdf_path.h"
 
 namespace rptdev {
 

@@ -1,10 +1,15 @@
-// capi.hip — the C ABI of include/rpt.h: contexts, scene upload, launches.  Host code only; the kernels
-// and their launch wrappers are in kernels.hip (launch.h).
+// capi.hip — the C ABI of include/rpt.h: contexts (one device, the devices of a node in one process, or one rank of a
+// multi-process job), scene upload, launches, the RCCL gather.  Host code only; the kernels and their launch wrappers
+// are in kernels.hip (launch.h).
 //
 // There is NO CPU fallback: without a gfx950 device every entry point that computes returns
 // RPT_ERR_NO_DEVICE / RPT_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>              // types and prototypes only: librccl.so.1 is loaded on demand (rccl_api)
 
+#include <dlfcn.h>
+
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -18,25 +23,48 @@
 #include "launch.h"
 
 using namespace rptdev;
-using rpthost::HostGrid;
-using rpthost::build_grid;
+using rpthost::HostAccel;
+using rpthost::build_accel;
 using rpthost::make_camera;
 
-struct rpt_ctx {
+// What one device of a context owns.
+struct DevState {
     int device = -1;
+    int rank = 0;                     // this device's rank in the world (row blocks b with b % world == rank)
     hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr, ev_ready = nullptr;
+    SceneLarge scene_large;           // device pointers into `tables`
+    void* tables = nullptr;           // one allocation holding a large scene's tables
+    float* fb = nullptr;              // staging for the host-pointer API (this device's rows, or a whole image)
+    size_t fb_bytes = 0;
+    float* tile = nullptr;            // resident ColorBuffer rows of this rank: rows_padded x width RGBA f32
+    ncclComm_t comm = nullptr;
+};
+
+struct rpt_ctx {
+    std::vector<DevState> devs;       // devs[0] is the context's "own" device (rank 0 in a multi context)
+    int world = 1;
+    bool use_comm = false;            // tiles are gathered through RCCL (false: world 1, or peer copies)
+    bool peer_gather = false;         // single process, RPT_GATHER=p2p: hipMemcpyPeerAsync instead of RCCL
+    uint32_t tile_rows = 2;
     bool has_scene = false;
     bool large = false;               // scene exceeds the kernarg tables: SceneLarge + device tables
     SceneSmallSdf scene;              // camera part is filled per launch (depends on width/height); sdf.n_prims == 0: plain
-    SceneLarge scene_large;
-    void* tables = nullptr;           // one device allocation holding the large scene's tables
     rpt_camera camera;
-    float* fb = nullptr;              // device framebuffer for the host-pointer API
-    size_t fb_bytes = 0;
-    float* res = nullptr;             // resident ColorBuffer: pixels (f32 RGBA) followed by the u8 frame
-    uint32_t res_w = 0, res_h = 0;
+    // resident ColorBuffer (buffer.rs:6-14): pixels as per-rank tiles + frames
+    uint32_t res_w = 0, res_h = 0, res_tile_rows = 0, res_rows_padded = 0;
     uint64_t res_frames = 0;
+    bool has_res = false;
+    // on the root device: rank-major gathered tiles, the assembled image, the u8 frame
+    float* gathered = nullptr;
+    float* image = nullptr;
+    uint8_t* frame_u8 = nullptr;
+    hipEvent_t gather_consumed = nullptr;   // peer gather: recorded behind the scatter kernel that reads `gathered`
+    bool timed = false;               // ev_begin / ev_end bracket a render
     std::string err;
+
+    bool is_root() const { return devs[0].rank == 0; }
+    bool plain() const { return world == 1 && !use_comm; }           // rpt_create: the tile IS the image
 };
 
 static thread_local std::string g_err;
@@ -61,7 +89,7 @@ static void set_err(rpt_ctx* ctx, const char* fmt, ...)
         }                                                                                         \
     } while (0)
 
-// Every entry point runs on its context's device and puts the caller's current device back afterwards
+// Every entry point runs on its context's device(s) and puts the caller's current device back afterwards
 // (the caller may be a torch process with its own idea of the current device).
 struct DeviceGuard {
     int prev = -1;
@@ -71,11 +99,65 @@ struct DeviceGuard {
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         status = (prev == device) ? hipSuccess : hipSetDevice(device);
     }
+    hipError_t to(int device) { return hipSetDevice(device); }
     ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
 };
-#define RPT_ON_DEVICE(ctx)                 \
-    DeviceGuard guard_((ctx)->device);     \
+#define RPT_ON_DEVICE(ctx)                        \
+    DeviceGuard guard_((ctx)->devs[0].device);    \
     RPT_HIP_CHECK(ctx, guard_.status)
+
+// ---- RCCL, loaded on demand ------------------------------------------------------------------------------
+// Only multi-GPU contexts need it, and a host process (torch) may already have its own copy of librccl.so.1 loaded:
+// dlopen by soname then returns that one instead of bringing in a second runtime.
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string error;
+};
+
+static RcclApi* rccl_api()
+{
+    static RcclApi api;
+    static bool tried = false;
+    if (tried) return api.handle ? &api : nullptr;
+    tried = true;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) { api.error = dlerror() ? dlerror() : "dlopen(librccl.so.1) failed"; return nullptr; }
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(api.handle, name); if (!p) { ok = false; api.error = std::string("librccl: missing symbol ") + name; } return p; };
+    api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
+    api.CommInitRank = (decltype(api.CommInitRank))sym("ncclCommInitRank");
+    api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+    api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+    api.Send = (decltype(api.Send))sym("ncclSend");
+    api.Recv = (decltype(api.Recv))sym("ncclRecv");
+    api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+    api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+    api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+    if (!ok) { dlclose(api.handle); api.handle = nullptr; return nullptr; }
+    return &api;
+}
+
+#define RPT_RCCL_CHECK(ctx, api, call)                                                            \
+    do {                                                                                          \
+        ncclResult_t r_ = (call);                                                                 \
+        if (r_ != ncclSuccess) {                                                                  \
+            set_err(ctx, "%s failed: %s (%s:%d)", #call, (api)->GetErrorString(r_), __FILE__, __LINE__); \
+            return RPT_ERR_RCCL;                                                                  \
+        }                                                                                         \
+    } while (0)
 
 // Lanes that must be parked on a surface hit before a wave runs its shading block (1..64).
 // RPT_SHADE_THRESHOLD overrides the default for tuning runs.
@@ -95,9 +177,190 @@ static uint32_t sdf_pool_min_batch() { static const uint32_t v = env_lanes("RPT_
 static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_POOL_PATIENCE") ? (uint32_t)atoi(getenv("RPT_SDF_POOL_PATIENCE")) : 8u; return v; }
 static uint32_t grid_walk_min_lanes() { static const uint32_t v = env_lanes("RPT_GRID_WALK_MIN_LANES", 8); return v; }
 
+// ---- descriptor -> device tables ---------------------------------------------------------------------------
+static DevPlane dev_plane(const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; }
+static DevLight dev_light(const rpt_light& a)
+{
+    return DevLight{a.type, a.position[0], a.position[1], a.position[2], a.emission[0], a.emission[1], a.emission[2], a.radius, a.area,
+                    a.u[0], a.u[1], a.u[2], a.v[0], a.v[1], a.v[2]};
+}
+static DevMaterial dev_material(const rpt_material& a)
+{
+    DevMaterial m;
+    m.mask = a.mask; m.proc_kind = a.proc_kind;
+    for (int k = 0; k < 3; ++k) { m.rgb[k] = a.rgb[k]; m.emission[k] = a.emission[k]; }
+    m.anisotropic = a.anisotropic; m.metallic = a.metallic; m.roughness = a.roughness; m.subsurface = a.subsurface;
+    m.specular_tint = a.specular_tint; m.sheen = a.sheen; m.sheen_tint = a.sheen_tint; m.clearcoat = a.clearcoat;
+    m.clearcoat_gloss = a.clearcoat_gloss; m.spec_trans = a.spec_trans; m.ior = a.ior;
+    for (int k = 0; k < 4; ++k) m.proc_params[k] = a.proc_params[k];
+    return m;
+}
+static DevBackground dev_background(const rpt_background& b)
+{
+    return DevBackground{b.kind, b.colour_a[0], b.colour_a[1], b.colour_a[2], b.colour_b[0], b.colour_b[1], b.colour_b[2], b.gamma, b.scale};
+}
+
+static void free_dev(DevState& d)
+{
+    DeviceGuard guard(d.device);
+    if (d.fb) (void)hipFree(d.fb);
+    if (d.tile) (void)hipFree(d.tile);
+    if (d.tables) (void)hipFree(d.tables);
+    if (d.ev_begin) (void)hipEventDestroy(d.ev_begin);
+    if (d.ev_end) (void)hipEventDestroy(d.ev_end);
+    if (d.ev_ready) (void)hipEventDestroy(d.ev_ready);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    d = DevState();
+}
+
+// device checks + stream/events for one device of a context
+static int open_dev(DevState& d, int device_id, int rank, const char* who)
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_err(nullptr, "%s: no HIP device (%s); this library has no CPU fallback", who, e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+        return RPT_ERR_NO_DEVICE;
+    }
+    if (device_id < 0 || device_id >= count) { set_err(nullptr, "%s: device %d out of range [0,%d)", who, device_id, count); return RPT_ERR_INVALID_ARG; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { set_err(nullptr, "%s: hipGetDeviceProperties failed", who); return RPT_ERR_HIP; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_err(nullptr, "%s: device %d is %s; this library is built for gfx950 only", who, device_id, prop.gcnArchName);
+        return RPT_ERR_NO_DEVICE;
+    }
+    d.device = device_id;
+    d.rank = rank;
+    DeviceGuard guard(device_id);
+    if (guard.status != hipSuccess || hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&d.ev_begin) != hipSuccess || hipEventCreate(&d.ev_end) != hipSuccess ||
+        hipEventCreateWithFlags(&d.ev_ready, hipEventDisableTiming) != hipSuccess) {
+        set_err(nullptr, "%s: cannot create a stream on device %d", who, device_id);
+        free_dev(d);
+        return RPT_ERR_HIP;
+    }
+    return RPT_OK;
+}
+
+static void free_resident(rpt_ctx* ctx)
+{
+    for (DevState& d : ctx->devs) {
+        DeviceGuard guard(d.device);
+        if (d.tile) { (void)hipFree(d.tile); d.tile = nullptr; }
+    }
+    DeviceGuard guard(ctx->devs[0].device);
+    if (ctx->gathered) { (void)hipFree(ctx->gathered); ctx->gathered = nullptr; }
+    if (ctx->image) { (void)hipFree(ctx->image); ctx->image = nullptr; }
+    if (ctx->frame_u8) { (void)hipFree(ctx->frame_u8); ctx->frame_u8 = nullptr; }
+    if (ctx->gather_consumed) { (void)hipEventDestroy(ctx->gather_consumed); ctx->gather_consumed = nullptr; }
+    ctx->has_res = false;
+    ctx->res_w = ctx->res_h = ctx->res_tile_rows = ctx->res_rows_padded = 0;
+    ctx->res_frames = 0;
+}
+
+static uint32_t rows_padded_for(uint32_t height, uint32_t tile_rows, uint32_t world)
+{
+    uint32_t m = 0;
+    for (uint32_t r = 0; r < world; ++r) { const uint32_t n = tile_row_count(height, tile_rows, r, world); m = n > m ? n : m; }
+    return m;
+}
+
+// Copy the rows rank `rank` owns between a host top-down image and its compact tile (either direction), following
+// rpt_tile_copy_plan: one strided copy for the full blocks plus one plain copy when the rank owns the image's short last block.
+static hipError_t copy_rank_rows(bool to_device, float* host_image, float* tile, uint32_t width, uint32_t height, uint32_t tile_rows,
+                                 uint32_t rank, uint32_t world, hipStream_t st)
+{
+    const size_t row_bytes = (size_t)width * 16u;
+    const hipMemcpyKind kind = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    rpt_tile_plan p;
+    if (rpt_tile_copy_plan(height, tile_rows, rank, world, &p) != RPT_OK) return hipErrorInvalidValue;
+    char* h0 = reinterpret_cast<char*>(host_image);
+    char* t0 = reinterpret_cast<char*>(tile);
+    if (p.full_blocks) {
+        const size_t block_bytes = row_bytes * p.block_rows;
+        char* h = h0 + row_bytes * p.host_row0;
+        const size_t hpitch = row_bytes * p.host_row_stride;
+        hipError_t e;
+        if (p.full_blocks == 1) e = to_device ? hipMemcpyAsync(t0, h, block_bytes, kind, st) : hipMemcpyAsync(h, t0, block_bytes, kind, st);
+        else e = to_device ? hipMemcpy2DAsync(t0, block_bytes, h, hpitch, block_bytes, p.full_blocks, kind, st)
+                           : hipMemcpy2DAsync(h, hpitch, t0, block_bytes, block_bytes, p.full_blocks, kind, st);
+        if (e != hipSuccess) return e;
+    }
+    if (p.ragged_rows) {
+        char* h = h0 + row_bytes * p.ragged_host_row0;
+        char* t = t0 + row_bytes * p.ragged_tile_row0;
+        return to_device ? hipMemcpyAsync(t, h, row_bytes * p.ragged_rows, kind, st) : hipMemcpyAsync(h, t, row_bytes * p.ragged_rows, kind, st);
+    }
+    return hipSuccess;
+}
+
+// One render launch sequence on one device.
+static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp,
+                         uint64_t seed, uint32_t flags, uint32_t tile_rows, uint32_t rank, uint32_t world, hipStream_t stream)
+{
+    if (world == 1) tile_rows = height;                              // one block: local row == global row
+    SceneSmallSdf scs = ctx->scene;
+    SceneLarge scl = d.scene_large;
+    scs.cam = scl.cam = make_camera(ctx->camera, (float)width, (float)height);
+
+    RenderParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.pixels = pixels_dev;
+    rp.width = width; rp.height = height;
+    rp.rows_local = tile_row_count(height, tile_rows, rank, world);
+    rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
+    rp.seed = seed;
+    rp.tiles_x = (width + 15u) / 16u;
+    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : ((flags & RPT_RENDER_SDF_POOL_MARCH) ? 2u : 1u);
+    rp.pool_shade_lanes = sdf_pool_shade_lanes();
+    rp.pool_resolve_lanes = sdf_pool_resolve_lanes();
+    rp.pool_min_batch = sdf_pool_min_batch();
+    rp.pool_patience = sdf_pool_patience();
+    rp.shade_threshold = shade_threshold();
+    rp.march_min_lanes = sdf_march_min_lanes();
+    rp.walk_min_lanes = grid_walk_min_lanes();
+    rp.grid_resumable_walk = (flags & RPT_RENDER_GRID_RESUMABLE_WALK) ? 1u : 0u;
+    if (flags & RPT_RENDER_RUSSIAN_ROULETTE) { scs.flags |= kSceneFlagRussianRoulette; scl.flags |= kSceneFlagRussianRoulette; }
+    if (rp.rows_local == 0) return RPT_OK;
+    const uint32_t tiles_y = (rp.rows_local + 15u) / 16u;
+    const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;
+    if (nblocks > 0x7FFFFFFFull) { set_err(ctx, "render: grid too large"); return RPT_ERR_INVALID_ARG; }
+#ifndef RPT_AB_KERNELS
+    if (flags & (RPT_RENDER_SDF_POOL_MARCH | RPT_RENDER_GRID_RESUMABLE_WALK)) {
+        set_err(ctx, "render: the A/B kernels (RPT_RENDER_SDF_POOL_MARCH, RPT_RENDER_GRID_RESUMABLE_WALK) are not in this build (-DRPT_AB_KERNELS)");
+        return RPT_ERR_UNSUPPORTED;
+    }
+#endif
+
+    // The LDS tables of the regenerating kernel hold a bounded number of samples: larger batches are
+    // split into consecutive launches (the running mean carries over in the framebuffer).
+    const uint32_t max_chunk = rptlaunch::max_spp_per_launch();
+    for (uint32_t done = 0; done < spp;) {
+        const uint32_t chunk = (spp - done > max_chunk) ? max_chunk : (spp - done);
+        rp.spp = chunk;
+        rp.frames_done = frames_done + done;
+        const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
+        if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
+        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
+        done += chunk;
+    }
+    return RPT_OK;
+}
+
+static int ensure_fb(rpt_ctx* ctx, DevState& d, size_t bytes)
+{
+    if (bytes > d.fb_bytes) {
+        if (d.fb) { RPT_HIP_CHECK(ctx, hipFree(d.fb)); d.fb = nullptr; d.fb_bytes = 0; }
+        RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.fb, bytes));
+        d.fb_bytes = bytes;
+    }
+    return RPT_OK;
+}
+
 extern "C" {
 
 uint32_t rpt_abi_version(void) { return RPT_ABI_VERSION; }
+uint32_t rpt_sizeof_scene_desc(void) { return (uint32_t)sizeof(rpt_scene_desc); }
 
 const char* rpt_last_error(const rpt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -162,43 +425,126 @@ int rpt_create(rpt_ctx** out, int device_id)
 {
     if (!out) { set_err(nullptr, "rpt_create: out is NULL"); return RPT_ERR_INVALID_ARG; }
     *out = nullptr;
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0) {
-        set_err(nullptr, "rpt_create: no HIP device (%s); this library has no CPU fallback",
-                e != hipSuccess ? hipGetErrorString(e) : "device count 0");
-        return RPT_ERR_NO_DEVICE;
-    }
-    if (device_id < 0 || device_id >= count) { set_err(nullptr, "rpt_create: device %d out of range [0,%d)", device_id, count); return RPT_ERR_INVALID_ARG; }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) { set_err(nullptr, "rpt_create: hipGetDeviceProperties failed"); return RPT_ERR_HIP; }
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        set_err(nullptr, "rpt_create: device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
-        return RPT_ERR_NO_DEVICE;
+    rpt_ctx* ctx = new (std::nothrow) rpt_ctx();
+    if (!ctx) return RPT_ERR_HIP;
+    ctx->devs.resize(1);
+    int rc = open_dev(ctx->devs[0], device_id, 0, "rpt_create");
+    if (rc != RPT_OK) { delete ctx; return rc; }
+    *out = ctx;
+    return RPT_OK;
+}
+
+int rpt_create_multi(rpt_ctx** out, const int* device_ids, int n_devices)
+{
+    if (!out) { set_err(nullptr, "rpt_create_multi: out is NULL"); return RPT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) { set_err(nullptr, "rpt_create_multi: need 1..64 device ids"); return RPT_ERR_INVALID_ARG; }
+    const char* g = getenv("RPT_GATHER");
+    const bool peer = g && strcmp(g, "p2p") == 0;
+    bool distinct = true;
+    for (int i = 0; i < n_devices; ++i)
+        for (int j = 0; j < i; ++j) distinct = distinct && device_ids[i] != device_ids[j];
+    if (!distinct && !peer) {
+        set_err(nullptr, "rpt_create_multi: device ids must be distinct (RCCL needs one device per rank); RPT_GATHER=p2p "
+                         "gathers with peer copies instead and accepts repeated ids (virtual ranks, for tests)");
+        return RPT_ERR_INVALID_ARG;
     }
     rpt_ctx* ctx = new (std::nothrow) rpt_ctx();
     if (!ctx) return RPT_ERR_HIP;
-    ctx->device = device_id;
+    ctx->devs.resize((size_t)n_devices);
+    ctx->world = n_devices;
+    ctx->peer_gather = peer;
+    ctx->use_comm = !peer;
+    for (int i = 0; i < n_devices; ++i) {
+        int rc = open_dev(ctx->devs[(size_t)i], device_ids[i], i, "rpt_create_multi");
+        if (rc != RPT_OK) { for (DevState& d : ctx->devs) if (d.device >= 0) free_dev(d); delete ctx; return rc; }
+    }
+    if (ctx->use_comm) {
+        RcclApi* api = rccl_api();
+        int rc = RPT_OK;
+        if (!api) { set_err(nullptr, "rpt_create_multi: cannot load RCCL"); rc = RPT_ERR_RCCL; }
+        else {
+            std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
+            DeviceGuard guard(device_ids[0]);
+            ncclResult_t r = api->CommInitAll(comms.data(), n_devices, device_ids);
+            if (r != ncclSuccess) { set_err(nullptr, "rpt_create_multi: ncclCommInitAll failed: %s", api->GetErrorString(r)); rc = RPT_ERR_RCCL; }
+            else for (int i = 0; i < n_devices; ++i) ctx->devs[(size_t)i].comm = comms[(size_t)i];
+        }
+        if (rc != RPT_OK) { for (DevState& d : ctx->devs) free_dev(d); delete ctx; return rc; }
+    }
+    *out = ctx;
+    return RPT_OK;
+}
+
+int rpt_comm_unique_id(rpt_unique_id* out)
+{
+    static_assert(sizeof(rpt_unique_id) == sizeof(ncclUniqueId), "rpt_unique_id carries an ncclUniqueId");
+    if (!out) { set_err(nullptr, "rpt_comm_unique_id: out is NULL"); return RPT_ERR_INVALID_ARG; }
+    RcclApi* api = rccl_api();
+    if (!api) { set_err(nullptr, "rpt_comm_unique_id: cannot load RCCL"); return RPT_ERR_RCCL; }
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) { set_err(nullptr, "rpt_comm_unique_id: ncclGetUniqueId failed: %s", api->GetErrorString(r)); return RPT_ERR_RCCL; }
+    memcpy(out->bytes, &id, sizeof(id));
+    return RPT_OK;
+}
+
+int rpt_create_rank(rpt_ctx** out, int device_id, int rank, int world, const rpt_unique_id* id)
+{
+    if (!out) { set_err(nullptr, "rpt_create_rank: out is NULL"); return RPT_ERR_INVALID_ARG; }
+    *out = nullptr;
+    if (!id || world < 1 || rank < 0 || rank >= world) { set_err(nullptr, "rpt_create_rank: invalid argument (rank %d of %d)", rank, world); return RPT_ERR_INVALID_ARG; }
+    RcclApi* api = rccl_api();
+    if (!api) { set_err(nullptr, "rpt_create_rank: cannot load RCCL"); return RPT_ERR_RCCL; }
+    rpt_ctx* ctx = new (std::nothrow) rpt_ctx();
+    if (!ctx) return RPT_ERR_HIP;
+    ctx->devs.resize(1);
+    ctx->world = world;
+    ctx->use_comm = true;
+    int rc = open_dev(ctx->devs[0], device_id, rank, "rpt_create_rank");
+    if (rc != RPT_OK) { delete ctx; return rc; }
     {
         DeviceGuard guard(device_id);
-        if (guard.status != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
-            set_err(nullptr, "rpt_create: cannot create a stream on device %d", device_id);
+        ncclUniqueId nid;
+        memcpy(&nid, id->bytes, sizeof(nid));
+        ncclResult_t r = api->CommInitRank(&ctx->devs[0].comm, world, nid, rank);
+        if (r != ncclSuccess) {
+            set_err(nullptr, "rpt_create_rank: ncclCommInitRank failed: %s", api->GetErrorString(r));
+            free_dev(ctx->devs[0]);
             delete ctx;
-            return RPT_ERR_HIP;
+            return RPT_ERR_RCCL;
         }
     }
     *out = ctx;
     return RPT_OK;
 }
 
+int rpt_world(const rpt_ctx* ctx, int* rank, int* world, int* n_local)
+{
+    if (!ctx) return RPT_ERR_INVALID_ARG;
+    if (rank) *rank = ctx->devs[0].rank;
+    if (world) *world = ctx->world;
+    if (n_local) *n_local = (int)ctx->devs.size();
+    return RPT_OK;
+}
+
+int rpt_set_tile_rows(rpt_ctx* ctx, uint32_t tile_rows)
+{
+    if (!ctx || tile_rows == 0) { set_err(ctx, "rpt_set_tile_rows: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    ctx->tile_rows = tile_rows;
+    return RPT_OK;
+}
+
 void rpt_destroy(rpt_ctx* ctx)
 {
     if (!ctx) return;
-    DeviceGuard guard(ctx->device);
-    if (ctx->fb) (void)hipFree(ctx->fb);
-    if (ctx->res) (void)hipFree(ctx->res);
-    if (ctx->tables) (void)hipFree(ctx->tables);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (DevState& d : ctx->devs) { DeviceGuard guard(d.device); (void)hipStreamSynchronize(d.stream); }
+    free_resident(ctx);
+    RcclApi* api = ctx->use_comm ? rccl_api() : nullptr;
+    for (DevState& d : ctx->devs) {
+        if (d.comm && api) { DeviceGuard guard(d.device); (void)api->CommDestroy(d.comm); d.comm = nullptr; }
+        free_dev(d);
+    }
     delete ctx;
 }
 
@@ -222,22 +568,8 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         if (s->spheres[i].material >= s->n_materials) { set_err(ctx, "rpt_upload_scene: sphere %u material out of range", i); return RPT_ERR_INVALID_ARG; }
     for (uint32_t i = 0; i < s->n_planes; ++i)
         if (s->planes[i].material >= s->n_materials) { set_err(ctx, "rpt_upload_scene: plane %u material out of range", i); return RPT_ERR_INVALID_ARG; }
-
-    auto dev_plane = [](const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; };
-    auto dev_light = [](const rpt_light& a) { return DevLight{a.type, a.position[0], a.position[1], a.position[2], a.emission[0], a.emission[1], a.emission[2], a.radius, a.area}; };
-    auto dev_material = [](const rpt_material& a) {
-        DevMaterial m;
-        m.mask = a.mask; m.proc_kind = a.proc_kind;
-        for (int k = 0; k < 3; ++k) { m.rgb[k] = a.rgb[k]; m.emission[k] = a.emission[k]; }
-        m.anisotropic = a.anisotropic; m.metallic = a.metallic; m.roughness = a.roughness; m.subsurface = a.subsurface;
-        m.specular_tint = a.specular_tint; m.sheen = a.sheen; m.sheen_tint = a.sheen_tint; m.clearcoat = a.clearcoat;
-        m.clearcoat_gloss = a.clearcoat_gloss; m.spec_trans = a.spec_trans; m.ior = a.ior;
-        for (int k = 0; k < 4; ++k) m.proc_params[k] = a.proc_params[k];
-        return m;
-    };
-    auto dev_background = [](const rpt_background& b) {
-        return DevBackground{b.kind, b.colour_a[0], b.colour_a[1], b.colour_a[2], b.colour_b[0], b.colour_b[1], b.colour_b[2], b.gamma, b.scale};
-    };
+    for (uint32_t i = 0; i < s->n_lights; ++i)
+        if (s->lights[i].type > RPT_LIGHT_DISTANT) { set_err(ctx, "rpt_upload_scene: light %u has an unknown type", i); return RPT_ERR_INVALID_ARG; }
 
     if (s->sdf.n_prims) {
         if (s->sdf.n_prims > (uint32_t)kMaxSdfPrims || !s->sdf.prims || s->sdf.material >= s->n_materials || !(s->sdf.smooth_k > 0.0f)) {
@@ -258,20 +590,26 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
                              "(mask == RPT_MAT_ALL, no procedural part); sphere %u does not", kMaxSpheres, kMaxLights, kMaxMaterials, i);
                 return RPT_ERR_UNSUPPORTED;
             }
+            // the acceleration structure is built from these numbers: they must be numbers
+            const rpt_sphere& sp = s->spheres[i];
+            if (!std::isfinite(sp.center[0]) || !std::isfinite(sp.center[1]) || !std::isfinite(sp.center[2]) || !std::isfinite(sp.radius) || sp.radius < 0.0f) {
+                set_err(ctx, "rpt_upload_scene: sphere %u has a non-finite centre or a negative / non-finite radius", i);
+                return RPT_ERR_INVALID_ARG;
+            }
         }
-        RPT_ON_DEVICE(ctx);
         const size_t sz_sph = sizeof(float4) * s->n_spheres;
         const size_t sz_smat = (sizeof(uint32_t) * s->n_spheres + 15) & ~(size_t)15;
         const size_t sz_lights = (sizeof(DevLight) * (s->n_lights ? s->n_lights : 1) + 15) & ~(size_t)15;
-        const size_t sz_mats = sizeof(DevMaterial) * (s->n_materials ? s->n_materials : 1);
-        const bool use_grid = s->n_spheres >= 64 && !getenv("RPT_NO_GRID");
-        HostGrid grid;
-        if (use_grid) { const char* e = getenv("RPT_GRID_SPHERES_PER_CELL"); grid = build_grid(s->spheres, s->n_spheres, e ? atof(e) : 1.0); }
-        const size_t sz_tables = (sz_sph + sz_smat + sz_lights + sz_mats + 15) & ~(size_t)15;
-        const size_t sz_cstart = (sizeof(uint32_t) * grid.cell_start.size() + 15) & ~(size_t)15;
-        const size_t sz_items = (sizeof(uint32_t) * grid.items.size() + 15) & ~(size_t)15;
-        const size_t sz_cell_sph = sizeof(float4) * grid.items.size();
-        std::vector<unsigned char> host(sz_tables + sz_cstart + sz_items + sz_cell_sph, 0);
+        const size_t sz_mats = (sizeof(DevMaterial) * (s->n_materials ? s->n_materials : 1) + 15) & ~(size_t)15;
+        const bool use_accel = s->n_spheres >= 64 && !getenv("RPT_NO_GRID");
+        HostAccel accel;
+        if (use_accel) {
+            std::string why;
+            if (!build_accel(s->spheres, s->n_spheres, accel, why)) { set_err(ctx, "rpt_upload_scene: %s", why.c_str()); return RPT_ERR_UNSUPPORTED; }
+        }
+        const size_t sz_tables = sz_sph + sz_smat + sz_lights + sz_mats;
+        const size_t sz_accel = accel.bytes();
+        std::vector<unsigned char> host(sz_tables + sz_accel, 0);
         float4* h_sph = reinterpret_cast<float4*>(host.data());
         uint32_t* h_smat = reinterpret_cast<uint32_t*>(host.data() + sz_sph);
         DevLight* h_lights = reinterpret_cast<DevLight*>(host.data() + sz_sph + sz_smat);
@@ -282,38 +620,27 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         }
         for (uint32_t i = 0; i < s->n_lights; ++i) h_lights[i] = dev_light(s->lights[i]);
         for (uint32_t i = 0; i < s->n_materials; ++i) h_mats[i] = dev_material(s->materials[i]);
-        if (use_grid) {
-            memcpy(host.data() + sz_tables, grid.cell_start.data(), sizeof(uint32_t) * grid.cell_start.size());
-            memcpy(host.data() + sz_tables + sz_cstart, grid.items.data(), sizeof(uint32_t) * grid.items.size());
-            // the spheres again, in cell-list order: the walk reads a cell's spheres without going through the index
-            float4* h_cell_sph = reinterpret_cast<float4*>(host.data() + sz_tables + sz_cstart + sz_items);
-            for (size_t k = 0; k < grid.items.size(); ++k) h_cell_sph[k] = h_sph[grid.items[k]];
-        }
-        if (ctx->tables) { RPT_HIP_CHECK(ctx, hipFree(ctx->tables)); ctx->tables = nullptr; }
-        RPT_HIP_CHECK(ctx, hipMalloc(&ctx->tables, host.size()));
-        RPT_HIP_CHECK(ctx, hipMemcpy(ctx->tables, host.data(), host.size(), hipMemcpyHostToDevice));
-        unsigned char* base = reinterpret_cast<unsigned char*>(ctx->tables);
-        SceneLarge& L = ctx->scene_large;
-        memset(&L, 0, sizeof(L));
-        L.n_spheres = s->n_spheres; L.n_planes = s->n_planes; L.n_lights = s->n_lights; L.n_materials = s->n_materials;
-        L.flags = s->flags; L.max_depth = s->max_depth; L.eps = s->eps; L.n_lights_f = (float)s->n_lights;
-        L.bg = dev_background(s->background);
-        L.spheres = reinterpret_cast<const float4*>(base);
-        L.sphere_material = reinterpret_cast<const uint32_t*>(base + sz_sph);
-        L.lights = reinterpret_cast<const DevLight*>(base + sz_sph + sz_smat);
-        L.materials = reinterpret_cast<const DevMaterial*>(base + sz_sph + sz_smat + sz_lights);
-        for (uint32_t i = 0; i < s->n_planes; ++i) L.planes[i] = dev_plane(s->planes[i]);
-        L.use_grid = use_grid ? 1u : 0u;
-        if (use_grid) {
-            for (int a = 0; a < 3; ++a) {
-                L.gn[a] = grid.n[a]; L.gmin[a] = grid.gmin[a]; L.gmax[a] = grid.gmax[a];
-                L.cell_size[a] = grid.cs[a]; L.inv_cell_size[a] = grid.inv_cs[a];
-                L.gcenter[a] = grid.center[a];
-            }
-            L.safe_r2 = grid.safe_r2;
-            L.cell_start = reinterpret_cast<const uint32_t*>(base + sz_tables);
-            L.cell_items = reinterpret_cast<const uint32_t*>(base + sz_tables + sz_cstart);
-            L.cell_spheres = reinterpret_cast<const float4*>(base + sz_tables + sz_cstart + sz_items);
+        if (use_accel) accel.write(host.data() + sz_tables);
+        for (DevState& d : ctx->devs) {
+            DeviceGuard guard(d.device);
+            RPT_HIP_CHECK(ctx, guard.status);
+            RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));       // a running launch may still read the old tables
+            if (d.tables) { RPT_HIP_CHECK(ctx, hipFree(d.tables)); d.tables = nullptr; }
+            RPT_HIP_CHECK(ctx, hipMalloc(&d.tables, host.size()));
+            RPT_HIP_CHECK(ctx, hipMemcpy(d.tables, host.data(), host.size(), hipMemcpyHostToDevice));
+            unsigned char* base = reinterpret_cast<unsigned char*>(d.tables);
+            SceneLarge& L = d.scene_large;
+            memset(&L, 0, sizeof(L));
+            L.n_spheres = s->n_spheres; L.n_planes = s->n_planes; L.n_lights = s->n_lights; L.n_materials = s->n_materials;
+            L.flags = s->flags; L.max_depth = s->max_depth; L.eps = s->eps; L.n_lights_f = (float)s->n_lights;
+            L.bg = dev_background(s->background);
+            L.spheres = reinterpret_cast<const float4*>(base);
+            L.sphere_material = reinterpret_cast<const uint32_t*>(base + sz_sph);
+            L.lights = reinterpret_cast<const DevLight*>(base + sz_sph + sz_smat);
+            L.materials = reinterpret_cast<const DevMaterial*>(base + sz_sph + sz_smat + sz_lights);
+            for (uint32_t i = 0; i < s->n_planes; ++i) L.planes[i] = dev_plane(s->planes[i]);
+            L.use_accel = use_accel ? 1u : 0u;
+            if (use_accel) accel.bind(L, base + sz_tables);
         }
         ctx->camera = s->camera;
         ctx->large = true;
@@ -321,6 +648,14 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         return RPT_OK;
     }
 
+    for (DevState& d : ctx->devs) {                                 // a small scene needs no tables: drop a previous large scene's
+        if (!d.tables) continue;
+        DeviceGuard guard(d.device);
+        RPT_HIP_CHECK(ctx, guard.status);
+        RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
+        RPT_HIP_CHECK(ctx, hipFree(d.tables));
+        d.tables = nullptr;
+    }
     SceneSmallSdf& d = ctx->scene;
     memset(&d, 0, sizeof(d));
     d.n_spheres = s->n_spheres; d.n_planes = s->n_planes; d.n_lights = s->n_lights; d.n_materials = s->n_materials;
@@ -328,33 +663,14 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
     d.max_depth = s->max_depth;
     d.eps = s->eps;
     d.n_lights_f = (float)s->n_lights;
-    d.bg.kind = s->background.kind;
-    d.bg.ax = s->background.colour_a[0]; d.bg.ay = s->background.colour_a[1]; d.bg.az = s->background.colour_a[2];
-    d.bg.bx = s->background.colour_b[0]; d.bg.by = s->background.colour_b[1]; d.bg.bz = s->background.colour_b[2];
-    d.bg.gamma = s->background.gamma;
-    d.bg.scale = s->background.scale;
+    d.bg = dev_background(s->background);
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const rpt_sphere& a = s->spheres[i];
         d.spheres[i] = DevSphere{a.center[0], a.center[1], a.center[2], a.radius, a.material};
     }
-    for (uint32_t i = 0; i < s->n_planes; ++i) {
-        const rpt_plane& a = s->planes[i];
-        d.planes[i] = DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t};
-    }
-    for (uint32_t i = 0; i < s->n_lights; ++i) {
-        const rpt_light& a = s->lights[i];
-        d.lights[i] = DevLight{a.type, a.position[0], a.position[1], a.position[2], a.emission[0], a.emission[1], a.emission[2], a.radius, a.area};
-    }
-    for (uint32_t i = 0; i < s->n_materials; ++i) {
-        const rpt_material& a = s->materials[i];
-        DevMaterial& m = d.materials[i];
-        m.mask = a.mask; m.proc_kind = a.proc_kind;
-        for (int k = 0; k < 3; ++k) { m.rgb[k] = a.rgb[k]; m.emission[k] = a.emission[k]; }
-        m.anisotropic = a.anisotropic; m.metallic = a.metallic; m.roughness = a.roughness; m.subsurface = a.subsurface;
-        m.specular_tint = a.specular_tint; m.sheen = a.sheen; m.sheen_tint = a.sheen_tint; m.clearcoat = a.clearcoat;
-        m.clearcoat_gloss = a.clearcoat_gloss; m.spec_trans = a.spec_trans; m.ior = a.ior;
-        for (int k = 0; k < 4; ++k) m.proc_params[k] = a.proc_params[k];
-    }
+    for (uint32_t i = 0; i < s->n_planes; ++i) d.planes[i] = dev_plane(s->planes[i]);
+    for (uint32_t i = 0; i < s->n_lights; ++i) d.lights[i] = dev_light(s->lights[i]);
+    for (uint32_t i = 0; i < s->n_materials; ++i) d.materials[i] = dev_material(s->materials[i]);
     d.sdf.n_prims = s->sdf.n_prims; d.sdf.max_steps = s->sdf.max_steps; d.sdf.material = s->sdf.material;
     d.sdf.smooth_k = s->sdf.smooth_k; d.sdf.hit_eps = s->sdf.hit_eps; d.sdf.max_t = s->sdf.max_t; d.sdf.normal_eps = s->sdf.normal_eps;
     d.sdf.inv_smooth_k = s->sdf.n_prims ? 1.0f / s->sdf.smooth_k : 0.0f;
@@ -379,6 +695,37 @@ uint32_t rpt_tile_global_row(uint32_t local_row, uint32_t tile_rows, uint32_t ra
     return tile_global_row(local_row, tile_rows, rank, world);
 }
 
+uint32_t rpt_tile_rows_padded(uint32_t height, uint32_t tile_rows, uint32_t world)
+{
+    if (tile_rows == 0 || world == 0) return 0;
+    return rows_padded_for(height, tile_rows, world);
+}
+
+int rpt_tile_copy_plan(uint32_t height, uint32_t tile_rows, uint32_t rank, uint32_t world, rpt_tile_plan* out)
+{
+    if (!out || tile_rows == 0 || world == 0 || rank >= world || height == 0) return RPT_ERR_INVALID_ARG;
+    memset(out, 0, sizeof(*out));
+    if (world == 1) {                                                // everything is one block
+        out->full_blocks = 1; out->block_rows = height; out->host_row0 = 0; out->host_row_stride = height;
+        return RPT_OK;
+    }
+    const uint32_t nblocks = (height + tile_rows - 1u) / tile_rows;
+    if (rank >= nblocks) return RPT_OK;                              // this rank owns no row
+    const uint32_t nb = (nblocks - rank + world - 1u) / world;       // blocks of this rank: rank, rank + world, ...
+    const uint32_t last_b = rank + (nb - 1u) * world;
+    const bool ragged = (last_b == nblocks - 1u) && (height % tile_rows != 0u);
+    out->full_blocks = ragged ? nb - 1u : nb;
+    out->block_rows = tile_rows;
+    out->host_row0 = rank * tile_rows;
+    out->host_row_stride = world * tile_rows;
+    if (ragged) {
+        out->ragged_rows = height - last_b * tile_rows;
+        out->ragged_host_row0 = last_b * tile_rows;
+        out->ragged_tile_row0 = (nb - 1u) * tile_rows;
+    }
+    return RPT_OK;
+}
+
 int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp,
                       uint64_t seed, uint32_t flags, uint32_t tile_rows, uint32_t rank, uint32_t world, void* stream)
 {
@@ -392,47 +739,8 @@ int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t 
     if ((uint64_t)width * height > 0xFFFFFFFFull) { set_err(ctx, "rpt_render_device: image too large for 32-bit pixel indices"); return RPT_ERR_INVALID_ARG; }
     if (((uintptr_t)pixels_dev & 15u) != 0) { set_err(ctx, "rpt_render_device: pixels must be 16-byte aligned"); return RPT_ERR_INVALID_ARG; }
     if (spp == 0) return RPT_OK;
-    if (world == 1) tile_rows = height;                              // one block: local row == global row
-
     RPT_ON_DEVICE(ctx);
-    SceneSmallSdf scs = ctx->scene;
-    SceneLarge scl = ctx->scene_large;
-    scs.cam = scl.cam = make_camera(ctx->camera, (float)width, (float)height);
-
-    RenderParams rp;
-    rp.pixels = pixels_dev;
-    rp.width = width; rp.height = height;
-    rp.rows_local = tile_row_count(height, tile_rows, rank, world);
-    rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
-    rp.seed = seed;
-    rp.tiles_x = (width + 15u) / 16u;
-    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : ((flags & RPT_RENDER_SDF_POOL_MARCH) ? 2u : 1u);
-    rp.pool_shade_lanes = sdf_pool_shade_lanes();
-    rp.pool_resolve_lanes = sdf_pool_resolve_lanes();
-    rp.pool_min_batch = sdf_pool_min_batch();
-    rp.pool_patience = sdf_pool_patience();
-    rp.shade_threshold = shade_threshold();
-    rp.march_min_lanes = sdf_march_min_lanes();
-    rp.walk_min_lanes = grid_walk_min_lanes();
-    rp.grid_resumable_walk = (flags & RPT_RENDER_GRID_RESUMABLE_WALK) ? 1u : 0u;
-    if (rp.rows_local == 0) return RPT_OK;
-    const uint32_t tiles_y = (rp.rows_local + 15u) / 16u;
-    const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;
-    if (nblocks > 0x7FFFFFFFull) { set_err(ctx, "rpt_render_device: grid too large"); return RPT_ERR_INVALID_ARG; }
-
-    // The LDS tables of the regenerating kernel hold a bounded number of samples: larger batches are
-    // split into consecutive launches (the running mean carries over in the framebuffer).
-    const uint32_t max_chunk = rptlaunch::max_spp_per_launch();
-    for (uint32_t done = 0; done < spp;) {
-        const uint32_t chunk = (spp - done > max_chunk) ? max_chunk : (spp - done);
-        rp.spp = chunk;
-        rp.frames_done = frames_done + done;
-        const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
-        if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, (hipStream_t)stream));
-        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, (hipStream_t)stream));
-        done += chunk;
-    }
-    return RPT_OK;
+    return launch_render(ctx, ctx->devs[0], pixels_dev, width, height, frames_done, spp, seed, flags, tile_rows, rank, world, (hipStream_t)stream);
 }
 
 int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp, uint64_t seed,
@@ -440,29 +748,64 @@ int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height, uin
 {
     if (!ctx) { set_err(nullptr, "rpt_render: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (!pixels || width == 0 || height == 0) { set_err(ctx, "rpt_render: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    if ((uint64_t)width * height > 0xFFFFFFFFull) { set_err(ctx, "rpt_render: image too large for 32-bit pixel indices"); return RPT_ERR_INVALID_ARG; }
     if (!ctx->has_scene) { set_err(ctx, "rpt_render: no scene uploaded"); return RPT_ERR_NO_SCENE; }
-    RPT_ON_DEVICE(ctx);
-    const size_t bytes = (size_t)width * height * 4 * sizeof(float);
-    if (bytes > ctx->fb_bytes) {
-        if (ctx->fb) { RPT_HIP_CHECK(ctx, hipFree(ctx->fb)); ctx->fb = nullptr; ctx->fb_bytes = 0; }
-        RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fb, bytes));
-        ctx->fb_bytes = bytes;
+    if ((size_t)ctx->world != ctx->devs.size()) {
+        set_err(ctx, "rpt_render: a host ColorBuffer needs every rank in this process (rpt_create / rpt_create_multi); "
+                     "with one process per GPU use the resident buffer (rpt_resident_*)");
+        return RPT_ERR_UNSUPPORTED;
     }
-    RPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->fb, pixels, bytes, hipMemcpyHostToDevice, ctx->stream));
-    int rc = rpt_render_device(ctx, ctx->fb, width, height, frames_done, spp, seed, flags, height, 0, 1, ctx->stream);
-    if (rc != RPT_OK) return rc;
-    RPT_HIP_CHECK(ctx, hipMemcpyAsync(pixels, ctx->fb, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    RPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    // The fan-out of tracer.rs:29-32: every device takes its rows of the caller's buffer (one strided copy each way,
+    // each device over its own PCIe link), all devices render concurrently, one host thread.
+    DeviceGuard guard(ctx->devs[0].device);
+    const uint32_t world = (uint32_t)ctx->world;
+    const uint32_t tile_rows = world == 1 ? height : ctx->tile_rows;
+    const uint32_t rows_padded = rows_padded_for(height, tile_rows, world);
+    for (DevState& d : ctx->devs) {
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        int rc = ensure_fb(ctx, d, (size_t)rows_padded * width * 16u);
+        if (rc != RPT_OK) return rc;
+        RPT_HIP_CHECK(ctx, copy_rank_rows(true, pixels, d.fb, width, height, tile_rows, (uint32_t)d.rank, world, d.stream));
+        rc = launch_render(ctx, d, d.fb, width, height, frames_done, spp, seed, flags, tile_rows, (uint32_t)d.rank, world, d.stream);
+        if (rc != RPT_OK) return rc;
+        RPT_HIP_CHECK(ctx, copy_rank_rows(false, pixels, d.fb, width, height, tile_rows, (uint32_t)d.rank, world, d.stream));
+    }
+    for (DevState& d : ctx->devs) {
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
+    }
     return RPT_OK;
 }
+
+// ---- resident ColorBuffer ------------------------------------------------------------------------------------
 
 int rpt_resident_reset(rpt_ctx* ctx)
 {
     if (!ctx) { set_err(nullptr, "rpt_resident_reset: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
-    RPT_ON_DEVICE(ctx);
-    if (ctx->res) { RPT_HIP_CHECK(ctx, hipFree(ctx->res)); ctx->res = nullptr; }
-    ctx->res_w = ctx->res_h = 0;
+    for (DevState& d : ctx->devs) { DeviceGuard guard(d.device); RPT_HIP_CHECK(ctx, guard.status); RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream)); }
+    free_resident(ctx);
+    return RPT_OK;
+}
+
+// ColorBuffer::new(width, height) (buffer.rs:18-26) as per-rank tiles
+static int resident_begin(rpt_ctx* ctx, uint32_t width, uint32_t height)
+{
+    const uint32_t world = (uint32_t)ctx->world;
+    const uint32_t tile_rows = ctx->plain() ? height : ctx->tile_rows;
+    if (ctx->has_res && ctx->res_w == width && ctx->res_h == height && ctx->res_tile_rows == tile_rows) return RPT_OK;
+    int rc = rpt_resident_reset(ctx);
+    if (rc != RPT_OK) return rc;
+    const uint32_t rows_padded = rows_padded_for(height, tile_rows, world);
+    const size_t tile_bytes = (size_t)rows_padded * width * 16u;
+    DeviceGuard guard(ctx->devs[0].device);
+    for (DevState& d : ctx->devs) {
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.tile, tile_bytes));
+        RPT_HIP_CHECK(ctx, hipMemsetAsync(d.tile, 0, tile_bytes, d.stream));
+    }
+    ctx->res_w = width; ctx->res_h = height; ctx->res_tile_rows = tile_rows; ctx->res_rows_padded = rows_padded;
     ctx->res_frames = 0;
+    ctx->has_res = true;
     return RPT_OK;
 }
 
@@ -470,19 +813,37 @@ int rpt_resident_render(rpt_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
 {
     if (!ctx) { set_err(nullptr, "rpt_resident_render: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (width == 0 || height == 0) { set_err(ctx, "rpt_resident_render: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    if ((uint64_t)width * height > 0xFFFFFFFFull) { set_err(ctx, "rpt_resident_render: image too large for 32-bit pixel indices"); return RPT_ERR_INVALID_ARG; }
     if (!ctx->has_scene) { set_err(ctx, "rpt_resident_render: no scene uploaded"); return RPT_ERR_NO_SCENE; }
-    RPT_ON_DEVICE(ctx);
-    if (!ctx->res || ctx->res_w != width || ctx->res_h != height) {             // ColorBuffer::new(width, height)
-        int rc = rpt_resident_reset(ctx);
-        if (rc != RPT_OK) return rc;
-        const size_t n = (size_t)width * height;
-        RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->res, n * 16 + n * 4));
-        RPT_HIP_CHECK(ctx, hipMemsetAsync(ctx->res, 0, n * 16, ctx->stream));
-        ctx->res_w = width; ctx->res_h = height;
-    }
-    int rc = rpt_render_device(ctx, ctx->res, width, height, ctx->res_frames, spp, seed, flags, height, 0, 1, ctx->stream);
+    int rc = resident_begin(ctx, width, height);
     if (rc != RPT_OK) return rc;
+    DeviceGuard guard(ctx->devs[0].device);
+    for (DevState& d : ctx->devs) {
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        RPT_HIP_CHECK(ctx, hipEventRecord(d.ev_begin, d.stream));
+        rc = launch_render(ctx, d, d.tile, width, height, ctx->res_frames, spp, seed, flags, ctx->res_tile_rows, (uint32_t)d.rank, (uint32_t)ctx->world, d.stream);
+        if (rc != RPT_OK) return rc;
+        RPT_HIP_CHECK(ctx, hipEventRecord(d.ev_end, d.stream));
+    }
+    ctx->timed = true;
     ctx->res_frames += spp;                                                      // tracer.rs:121
+    return RPT_OK;
+}
+
+int rpt_resident_kernel_ms(rpt_ctx* ctx, float* ms)
+{
+    if (!ctx || !ms) { set_err(ctx, "rpt_resident_kernel_ms: NULL argument"); return RPT_ERR_INVALID_ARG; }
+    if (!ctx->timed) { set_err(ctx, "rpt_resident_kernel_ms: no rpt_resident_render yet"); return RPT_ERR_INVALID_ARG; }
+    float worst = 0.0f;
+    DeviceGuard guard(ctx->devs[0].device);
+    for (DevState& d : ctx->devs) {
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        RPT_HIP_CHECK(ctx, hipEventSynchronize(d.ev_end));
+        float t = 0.0f;
+        RPT_HIP_CHECK(ctx, hipEventElapsedTime(&t, d.ev_begin, d.ev_end));
+        worst = t > worst ? t : worst;
+    }
+    *ms = worst;
     return RPT_OK;
 }
 
@@ -493,29 +854,125 @@ int rpt_resident_frames(const rpt_ctx* ctx, uint64_t* frames)
     return RPT_OK;
 }
 
+int rpt_resident_upload(rpt_ctx* ctx, const float* pixels, uint32_t width, uint32_t height, uint64_t frames)
+{
+    if (!ctx) { set_err(nullptr, "rpt_resident_upload: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!pixels || width == 0 || height == 0) { set_err(ctx, "rpt_resident_upload: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    int rc = resident_begin(ctx, width, height);
+    if (rc != RPT_OK) return rc;
+    DeviceGuard guard(ctx->devs[0].device);
+    for (DevState& d : ctx->devs) {
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        RPT_HIP_CHECK(ctx, copy_rank_rows(true, const_cast<float*>(pixels), d.tile, width, height, ctx->res_tile_rows, (uint32_t)d.rank, (uint32_t)ctx->world, d.stream));
+        RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));          // the caller may free `pixels` on return
+    }
+    ctx->res_frames = frames;
+    return RPT_OK;
+}
+
+// Tiles -> rank-major `gathered` on the root -> top-down image on the root, all enqueued (no host wait).
+// Returns the device pointer of the assembled image in *image_out (root only).
+static int gather_to_root(rpt_ctx* ctx, float* image_dst, float** image_out)
+{
+    const uint32_t w = ctx->res_w, h = ctx->res_h, world = (uint32_t)ctx->world;
+    DevState& root = ctx->devs[0];
+    DeviceGuard guard(root.device);
+    RPT_HIP_CHECK(ctx, guard.status);
+    if (ctx->plain()) {                                              // the tile is the image
+        if (image_dst && image_dst != root.tile) RPT_HIP_CHECK(ctx, hipMemcpyAsync(image_dst, root.tile, (size_t)w * h * 16u, hipMemcpyDeviceToDevice, root.stream));
+        if (image_out) *image_out = image_dst ? image_dst : root.tile;
+        return RPT_OK;
+    }
+    const size_t count = (size_t)ctx->res_rows_padded * w * 4u;      // floats per rank
+    if (ctx->is_root()) {
+        if (!ctx->gathered) RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->gathered, count * 4u * world));
+        if (!image_dst && !ctx->image) RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->image, (size_t)w * h * 16u));
+    }
+    if (ctx->peer_gather) {
+        // single process: peer copies over xGMI into the root's buffer, each on its source device's stream
+        for (DevState& d : ctx->devs) {
+            RPT_HIP_CHECK(ctx, guard.to(d.device));
+            if (ctx->gather_consumed) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(d.stream, ctx->gather_consumed, 0));   // the previous scatter still reads `gathered`
+            RPT_HIP_CHECK(ctx, hipMemcpyPeerAsync(ctx->gathered + (size_t)d.rank * count, root.device, d.tile, d.device, count * 4u, d.stream));
+            RPT_HIP_CHECK(ctx, hipEventRecord(d.ev_ready, d.stream));
+        }
+        RPT_HIP_CHECK(ctx, guard.to(root.device));
+        for (DevState& d : ctx->devs) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(root.stream, d.ev_ready, 0));
+    } else {
+        // RCCL gather over xGMI: every rank sends its tile to rank 0, which posts one receive per rank; one group, so the
+        // 7 incoming transfers use 7 links at once.  Each operation is ordered behind the render on its device's stream.
+        RcclApi* api = rccl_api();
+        if (!api) { set_err(ctx, "gather: cannot load RCCL"); return RPT_ERR_RCCL; }
+        RPT_RCCL_CHECK(ctx, api, api->GroupStart());
+        for (DevState& d : ctx->devs) {
+            if (d.rank == 0)
+                for (uint32_t r = 0; r < world; ++r)
+                    RPT_RCCL_CHECK(ctx, api, api->Recv(ctx->gathered + (size_t)r * count, count, ncclFloat, (int)r, d.comm, d.stream));
+            RPT_RCCL_CHECK(ctx, api, api->Send(d.tile, count, ncclFloat, 0, d.comm, d.stream));
+        }
+        RPT_RCCL_CHECK(ctx, api, api->GroupEnd());
+    }
+    if (ctx->is_root()) {
+        RPT_HIP_CHECK(ctx, guard.to(root.device));
+        float* img = image_dst ? image_dst : ctx->image;
+        RPT_HIP_CHECK(ctx, rptlaunch::untile(ctx->gathered, img, w, h, ctx->res_tile_rows, world, ctx->res_rows_padded, root.stream));
+        if (ctx->peer_gather) {
+            if (!ctx->gather_consumed) RPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->gather_consumed, hipEventDisableTiming));
+            RPT_HIP_CHECK(ctx, hipEventRecord(ctx->gather_consumed, root.stream));
+        }
+        if (image_out) *image_out = img;
+    } else if (image_out) *image_out = nullptr;
+    return RPT_OK;
+}
+
+int rpt_resident_gather_device(rpt_ctx* ctx, float* image_dev)
+{
+    if (!ctx) { set_err(nullptr, "rpt_resident_gather_device: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!ctx->has_res) { set_err(ctx, "rpt_resident_gather_device: no resident buffer"); return RPT_ERR_INVALID_ARG; }
+    if (((uintptr_t)image_dev & 15u) != 0) { set_err(ctx, "rpt_resident_gather_device: image must be 16-byte aligned"); return RPT_ERR_INVALID_ARG; }
+    return gather_to_root(ctx, image_dev, nullptr);
+}
+
+int rpt_resident_sync(rpt_ctx* ctx)
+{
+    if (!ctx) { set_err(nullptr, "rpt_resident_sync: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    DeviceGuard guard(ctx->devs[0].device);
+    for (DevState& d : ctx->devs) {
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
+    }
+    return RPT_OK;
+}
+
 int rpt_resident_download(rpt_ctx* ctx, float* pixels)
 {
     if (!ctx) { set_err(nullptr, "rpt_resident_download: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
-    if (!pixels || !ctx->res) { set_err(ctx, "rpt_resident_download: no resident buffer or NULL destination"); return RPT_ERR_INVALID_ARG; }
-    RPT_ON_DEVICE(ctx);
-    const size_t n = (size_t)ctx->res_w * ctx->res_h;
-    RPT_HIP_CHECK(ctx, hipMemcpyAsync(pixels, ctx->res, n * 16, hipMemcpyDeviceToHost, ctx->stream));
-    RPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return RPT_OK;
+    if (!ctx->has_res || (ctx->is_root() && !pixels)) { set_err(ctx, "rpt_resident_download: no resident buffer or NULL destination"); return RPT_ERR_INVALID_ARG; }
+    float* img = nullptr;
+    int rc = gather_to_root(ctx, nullptr, &img);
+    if (rc != RPT_OK) return rc;
+    DevState& root = ctx->devs[0];
+    DeviceGuard guard(root.device);
+    if (ctx->is_root()) RPT_HIP_CHECK(ctx, hipMemcpyAsync(pixels, img, (size_t)ctx->res_w * ctx->res_h * 16u, hipMemcpyDeviceToHost, root.stream));
+    return rpt_resident_sync(ctx);
 }
 
 int rpt_resident_download_u8(rpt_ctx* ctx, uint8_t* frame)
 {
     if (!ctx) { set_err(nullptr, "rpt_resident_download_u8: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
-    if (!frame || !ctx->res) { set_err(ctx, "rpt_resident_download_u8: no resident buffer or NULL destination"); return RPT_ERR_INVALID_ARG; }
-    RPT_ON_DEVICE(ctx);
-    const size_t n = (size_t)ctx->res_w * ctx->res_h;
-    uint8_t* out_dev = reinterpret_cast<uint8_t*>(ctx->res) + n * 16;
-    int rc = rpt_convert_to_u8_device(ctx, ctx->res, out_dev, ctx->res_w, ctx->res_h, ctx->stream);
+    if (!ctx->has_res || (ctx->is_root() && !frame)) { set_err(ctx, "rpt_resident_download_u8: no resident buffer or NULL destination"); return RPT_ERR_INVALID_ARG; }
+    float* img = nullptr;
+    int rc = gather_to_root(ctx, nullptr, &img);
     if (rc != RPT_OK) return rc;
-    RPT_HIP_CHECK(ctx, hipMemcpyAsync(frame, out_dev, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return RPT_OK;
+    DevState& root = ctx->devs[0];
+    DeviceGuard guard(root.device);
+    if (ctx->is_root()) {
+        const size_t n = (size_t)ctx->res_w * ctx->res_h;
+        if (!ctx->frame_u8) RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->frame_u8, n * 4u));
+        RPT_HIP_CHECK(ctx, rptlaunch::convert_to_u8(img, ctx->frame_u8, n, root.stream));
+        RPT_HIP_CHECK(ctx, hipMemcpyAsync(frame, ctx->frame_u8, n * 4u, hipMemcpyDeviceToHost, root.stream));
+    }
+    return rpt_resident_sync(ctx);
 }
 
 int rpt_untile_device(rpt_ctx* ctx, const float* gathered_dev, float* image_dev, uint32_t width, uint32_t height,
@@ -523,8 +980,7 @@ int rpt_untile_device(rpt_ctx* ctx, const float* gathered_dev, float* image_dev,
 {
     if (!ctx) { set_err(nullptr, "rpt_untile_device: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (!gathered_dev || !image_dev || width == 0 || height == 0 || tile_rows == 0 || world == 0) { set_err(ctx, "rpt_untile_device: invalid argument"); return RPT_ERR_INVALID_ARG; }
-    for (uint32_t r = 0; r < world; ++r)
-        if (tile_row_count(height, tile_rows, r, world) > rows_padded) { set_err(ctx, "rpt_untile_device: rows_padded %u too small", rows_padded); return RPT_ERR_INVALID_ARG; }
+    if (rows_padded_for(height, tile_rows, world) > rows_padded) { set_err(ctx, "rpt_untile_device: rows_padded %u too small", rows_padded); return RPT_ERR_INVALID_ARG; }
     RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, rptlaunch::untile(gathered_dev, image_dev, width, height, tile_rows, world, rows_padded, (hipStream_t)stream));
     return RPT_OK;
@@ -557,19 +1013,16 @@ int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_
     if (!ctx) { set_err(nullptr, "rpt_convert_to_u8: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     if (!pixels || !frame || width == 0 || height == 0) { set_err(ctx, "rpt_convert_to_u8: invalid argument"); return RPT_ERR_INVALID_ARG; }
     RPT_ON_DEVICE(ctx);
+    DevState& d = ctx->devs[0];
     const size_t n = (size_t)width * height;
-    const size_t bytes = n * 16 + n * 4;                              // f32 RGBA in, u8 RGBA out, one allocation
-    if (bytes > ctx->fb_bytes) {
-        if (ctx->fb) { RPT_HIP_CHECK(ctx, hipFree(ctx->fb)); ctx->fb = nullptr; ctx->fb_bytes = 0; }
-        RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->fb, bytes));
-        ctx->fb_bytes = bytes;
-    }
-    uint8_t* out_dev = reinterpret_cast<uint8_t*>(ctx->fb) + n * 16;
-    RPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->fb, pixels, n * 16, hipMemcpyHostToDevice, ctx->stream));
-    int rc = rpt_convert_to_u8_device(ctx, ctx->fb, out_dev, width, height, ctx->stream);
+    int rc = ensure_fb(ctx, d, n * 16 + n * 4);                       // f32 RGBA in, u8 RGBA out, one allocation
     if (rc != RPT_OK) return rc;
-    RPT_HIP_CHECK(ctx, hipMemcpyAsync(frame, out_dev, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    RPT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    uint8_t* out_dev = reinterpret_cast<uint8_t*>(d.fb) + n * 16;
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(d.fb, pixels, n * 16, hipMemcpyHostToDevice, d.stream));
+    rc = rpt_convert_to_u8_device(ctx, d.fb, out_dev, width, height, d.stream);
+    if (rc != RPT_OK) return rc;
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(frame, out_dev, n * 4, hipMemcpyDeviceToHost, d.stream));
+    RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
     return RPT_OK;
 }
 
@@ -588,8 +1041,8 @@ int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint6
     if (!rays_dev || !out_dev) { set_err(ctx, "rpt_probe_rays: invalid argument"); return RPT_ERR_INVALID_ARG; }
     if (n == 0) return RPT_OK;
     RPT_ON_DEVICE(ctx);
-    SceneLarge sc = ctx->scene_large;
-    if (!use_grid) sc.use_grid = 0;
+    SceneLarge sc = ctx->devs[0].scene_large;
+    if (!use_grid) sc.use_accel = 0;
     RPT_HIP_CHECK(ctx, rptlaunch::probe_rays(sc, rays_dev, out_dev, n, (hipStream_t)stream));
     return RPT_OK;
 }
@@ -601,6 +1054,23 @@ int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b
     if (n == 0) return RPT_OK;
     RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, rptlaunch::probe_math(fn, a_dev, b_dev, out_dev, n, (hipStream_t)stream));
+    return RPT_OK;
+}
+
+int rpt_probe_fn(rpt_ctx* ctx, uint32_t fn, const float* in_dev, float* out_dev, uint64_t n, const float* params, void* stream)
+{
+    if (!ctx) { set_err(nullptr, "rpt_probe_fn: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!in_dev || !out_dev || fn >= RPT_PROBE_FN_COUNT) { set_err(ctx, "rpt_probe_fn: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    DevCamera cam;
+    memset(&cam, 0, sizeof(cam));
+    if (fn == RPT_PROBE_FN_GEN_RAY) {
+        if (!ctx->has_scene) { set_err(ctx, "rpt_probe_fn: GEN_RAY uses the uploaded scene's camera"); return RPT_ERR_NO_SCENE; }
+        if (!params) { set_err(ctx, "rpt_probe_fn: GEN_RAY needs params = {width, height}"); return RPT_ERR_INVALID_ARG; }
+        cam = make_camera(ctx->camera, params[0], params[1]);
+    }
+    if (n == 0) return RPT_OK;
+    RPT_ON_DEVICE(ctx);
+    RPT_HIP_CHECK(ctx, rptlaunch::probe_fn(fn, cam, in_dev, out_dev, n, (hipStream_t)stream));
     return RPT_OK;
 }
 

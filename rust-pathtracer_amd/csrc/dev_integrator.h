@@ -212,14 +212,12 @@ struct EmitterHit {
     v3 light_emission;
 };
 
-// Scene::sample_lights, scene.rs:36-86, over the kernarg light table
-RPT_DEV bool sample_lights_small(const SceneSmall& sc, const RayD& ray, PathState& ps, EmitterHit& e, bool hit)
+// One light of Scene::sample_lights (scene.rs:65-85): spherical lights as in the reference; rectangular ones
+// (project-defined, include/rpt.h rpt_light) when the scene opts in.  `ldist` is the loop's running distance.
+RPT_DEV bool light_intersect(const DevLight& L, uint32_t scene_flags, const RayD& ray, PathState& ps, EmitterHit& e, float& ldist)
 {
-    float ldist = ps.hit_dist;
-    for (uint32_t i = 0; i < sc.n_lights; ++i) {
-        const DevLight& L = sc.lights[i];
-        if (L.type != RPT_LIGHT_SPHERICAL) continue;
-        v3 pos = mk3(L.px, L.py, L.pz);
+    v3 pos = mk3(L.px, L.py, L.pz);
+    if (L.type == RPT_LIGHT_SPHERICAL) {
         float t;
         if (hit_sphere(ray, pos, L.radius, t)) {
             if (t < ldist) {
@@ -230,9 +228,47 @@ RPT_DEV bool sample_lights_small(const SceneSmall& sc, const RayD& ray, PathStat
                 e.light_emission = mk3(L.ex, L.ey, L.ez);
                 e.is_emitter = true;
                 ps.hit_dist = t;
-                hit = true;
+                return true;
             }
         }
+    } else if (L.type == RPT_LIGHT_RECTANGULAR && (scene_flags & RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES)) {
+        const v3 u = mk3(L.ux, L.uy, L.uz), v = mk3(L.vx, L.vy, L.vz);
+        const v3 n = norm3(cross3(u, v));
+        if (dot3(n, ray.d) > 0.0f) return false;                    // back side: invisible
+        const float plane_w = dot3(n, pos);
+        const v3 uu = scale3(u, 1.0f / dot3(u, u));
+        const v3 vv = scale3(v, 1.0f / dot3(v, v));
+        const float dt = dot3(ray.d, n);
+        const float t = (plane_w - dot3(n, ray.o)) / dt;
+        if (t >= 0.0f) {
+            const v3 vi = (ray.o + t * ray.d) - pos;
+            const float a1 = dot3(uu, vi);
+            if (a1 >= 0.0f && a1 <= 1.0f) {
+                const float a2 = dot3(vv, vi);
+                if (a2 >= 0.0f && a2 <= 1.0f) {
+                    if (t < ldist) {
+                        ldist = t;
+                        const float cos_theta = dot3(-ray.d, n);
+                        e.light_pdf = (ldist * ldist) / (L.area * cos_theta);
+                        e.light_emission = mk3(L.ex, L.ey, L.ez);
+                        e.is_emitter = true;
+                        ps.hit_dist = t;
+                        return true;
+                    }
+                }
+            }
+        }
+    }
+    return false;
+}
+
+// Scene::sample_lights, scene.rs:36-86, over the kernarg light table
+RPT_DEV bool sample_lights_small(const SceneSmall& sc, const RayD& ray, PathState& ps, EmitterHit& e, bool hit)
+{
+    float ldist = ps.hit_dist;
+    for (uint32_t i = 0; i < sc.n_lights; ++i) {
+        const DevLight& L = sc.lights[i];
+        hit = light_intersect(L, sc.flags, ray, ps, e, ldist) || hit;
     }
     return hit;
 }
@@ -413,7 +449,31 @@ RPT_DEV void sample_light(const S& sc, const DevLight& L, v3 scatter_pos, LightS
 {
     ls.normal = mk3(0.0f, 0.0f, 0.0f); ls.emission = mk3(0.0f, 0.0f, 0.0f); ls.direction = mk3(0.0f, 0.0f, 0.0f);
     ls.dist = 0.0f; ls.pdf = 0.0f;                                  // LightSampleRec::new, globals.rs:119-129
-    if (L.type != RPT_LIGHT_SPHERICAL) return;
+    if (L.type != RPT_LIGHT_SPHERICAL) {
+        // tracer.rs:217: the reference does nothing for the other declared types; project-defined when the scene opts in
+        if (!(sc.flags & RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES)) return;
+        const v3 position = mk3(L.px, L.py, L.pz);
+        if (L.type == RPT_LIGHT_RECTANGULAR) {
+            float r1 = rng.gen();
+            float r2 = rng.gen();
+            const v3 u = mk3(L.ux, L.uy, L.uz), v = mk3(L.vx, L.vy, L.vz);
+            v3 surface_pos = position + r1 * u + r2 * v;
+            ls.direction = surface_pos - scatter_pos;
+            ls.dist = len3(ls.direction);
+            float dist_sq = ls.dist * ls.dist;
+            ls.direction = divs3(ls.direction, ls.dist);
+            ls.normal = norm3(cross3(u, v));
+            ls.emission = sc.n_lights_f * mk3(L.ex, L.ey, L.ez);
+            ls.pdf = dist_sq / (L.area * __builtin_fabsf(dot3(ls.normal, ls.direction)));
+        } else {                                                    // RPT_LIGHT_DISTANT: no draws
+            ls.direction = norm3(position);
+            ls.normal = norm3(scatter_pos - position);
+            ls.emission = sc.n_lights_f * mk3(L.ex, L.ey, L.ez);
+            ls.dist = __builtin_inff();
+            ls.pdf = 1.0f;
+        }
+        return;
+    }
     float r1 = rng.gen();
     float r2 = rng.gen();
     v3 lpos = mk3(L.px, L.py, L.pz);
@@ -450,6 +510,8 @@ RPT_DEV DevLight light_at(const SceneSmall& sc, uint32_t index)
         L.px = pick ? Li.px : L.px; L.py = pick ? Li.py : L.py; L.pz = pick ? Li.pz : L.pz;
         L.ex = pick ? Li.ex : L.ex; L.ey = pick ? Li.ey : L.ey; L.ez = pick ? Li.ez : L.ez;
         L.radius = pick ? Li.radius : L.radius; L.area = pick ? Li.area : L.area;
+        L.ux = pick ? Li.ux : L.ux; L.uy = pick ? Li.uy : L.uy; L.uz = pick ? Li.uz : L.uz;
+        L.vx = pick ? Li.vx : L.vx; L.vy = pick ? Li.vy : L.vy; L.vz = pick ? Li.vz : L.vz;
     }
     return L;
 }
@@ -623,7 +685,15 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
     p.ray.o = fhp2 + sc.eps * scatter_l;
     p.ray.d = scatter_l;
     p.bounce += 1;
-    return p.bounce >= sc.max_depth;
+    if (p.bounce >= sc.max_depth) return true;
+    if ((sc.flags & kSceneFlagRussianRoulette) && p.bounce >= 2u) {   // project extension, include/rpt.h RPT_RENDER_RUSSIAN_ROULETTE
+        float q = rmax(rmax(p.throughput.x, p.throughput.y), p.throughput.z);
+        q = clampf(q, 0.05f, 1.0f);
+        const float r = p.rng.gen();
+        if (r >= q) return true;
+        p.throughput = divs3(p.throughput, q);
+    }
+    return false;
 }
 
 

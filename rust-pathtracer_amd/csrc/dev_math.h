@@ -64,6 +64,12 @@ RPT_DEV float clamp01(float x)
     float r = (x > 1.0f) ? 1.0f : x;
     return (x < 0.0f) ? 0.0f : r;
 }
+// f32::clamp(lo, hi): NaN stays NaN.
+RPT_DEV float clampf(float x, float lo, float hi)
+{
+    float r = (x > hi) ? hi : x;
+    return (x < lo) ? lo : r;
+}
 // a % 2.0 for Rust f32 (C fmodf): exact via trunc for every finite a; +-inf and NaN
 // give NaN like fmodf.  (Sign of a zero result can differ from fmodf; callers only
 // compare the result with 1.0.)

@@ -38,6 +38,8 @@ struct DevLight {
     float px, py, pz;
     float ex, ey, ez;
     float radius, area;
+    float ux, uy, uz;          // Light.u / Light.v (globals.rs:80-81): the edges of a rectangular light
+    float vx, vy, vz;
 };
 
 struct DevMaterial {
@@ -80,6 +82,9 @@ struct DevSdf {
     float inv_smooth_k;        // 1.0f / smooth_k (f32), computed by the host
     DevSdfPrim prims[kMaxSdfPrims];
 };
+
+// Scene flags above the public ones of rpt.h (rpt_scene_desc.flags): set per launch from the render flags.
+constexpr uint32_t kSceneFlagRussianRoulette = 1u << 31;       // RPT_RENDER_RUSSIAN_ROULETTE
 
 struct SceneSmall {
     uint32_t n_spheres, n_planes, n_lights, n_materials;

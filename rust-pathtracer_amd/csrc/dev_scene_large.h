@@ -36,8 +36,8 @@ struct SceneLarge {
     DevPlane planes[kMaxPlanes];
     // Uniform grid over the spheres (built on the host at upload, host_scene.h build_grid):
     // cell (ix,iy,iz) -> items[cell_start[c] .. cell_start[c+1]) = indices of the spheres whose
-    // padded bounding box overlaps the cell, ascending.  use_grid == 0: brute-force streaming.
-    uint32_t use_grid;
+    // padded bounding box overlaps the cell, ascending.  use_accel == 0: brute-force streaming.
+    uint32_t use_accel;
     uint32_t gn[3];
     float gmin[3], gmax[3], cell_size[3], inv_cell_size[3];
     float gcenter[3];
@@ -60,13 +60,15 @@ RPT_DEV float4 sphere_uniform(const SceneLarge& sc, uint32_t i)     // i wave-un
 
 RPT_DEV DevLight light_uniform(const SceneLarge& sc, uint32_t i)
 {
-    static_assert(sizeof(DevLight) == 9 * 4, "DevLight is 9 dwords");
-    cfloat_p p = (cfloat_p)sc.lights + 9u * i;
+    static_assert(sizeof(DevLight) == 15 * 4, "DevLight is 15 dwords");
+    cfloat_p p = (cfloat_p)sc.lights + 15u * i;
     DevLight L;
     L.type = ((cuint_p)p)[0];
     L.px = p[1]; L.py = p[2]; L.pz = p[3];
     L.ex = p[4]; L.ey = p[5]; L.ez = p[6];
     L.radius = p[7]; L.area = p[8];
+    L.ux = p[9]; L.uy = p[10]; L.uz = p[11];
+    L.vx = p[12]; L.vy = p[13]; L.vz = p[14];
     return L;
 }
 
@@ -306,21 +308,7 @@ RPT_DEV bool closest_geom_finish(const SceneLarge& sc, const RayD& ray, PathStat
     float ldist = ps.hit_dist;
     for (uint32_t i = 0; i < sc.n_lights; ++i) {
         const DevLight L = light_uniform(sc, i);
-        if (L.type != RPT_LIGHT_SPHERICAL) continue;
-        v3 pos = mk3(L.px, L.py, L.pz);
-        float t;
-        if (hit_sphere(ray, pos, L.radius, t)) {
-            if (t < ldist) {
-                ldist = t;
-                v3 hit_point = ray.o + t * ray.d;
-                float cos_theta = dot3(-ray.d, norm3(hit_point - pos));
-                e.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
-                e.light_emission = mk3(L.ex, L.ey, L.ez);
-                e.is_emitter = true;
-                ps.hit_dist = t;
-                hit = true;
-            }
-        }
+        hit = light_intersect(L, sc.flags, ray, ps, e, ldist) || hit;
     }
     return hit;
 }
@@ -330,7 +318,7 @@ RPT_DEV bool closest_geom(const SceneLarge& sc, const RayD& ray, PathState& ps, 
     float dist = 3.40282347e+38f;
     bool hit = false;
     uint32_t best = 0xFFFFFFFFu;                                    // nearest sphere so far
-    if (sc.use_grid) grid_closest_sphere(sc, ray, dist, best, hit);
+    if (sc.use_accel) grid_closest_sphere(sc, ray, dist, best, hit);
     else brute_closest_sphere(sc, ray, dist, best, hit);
     return closest_geom_finish(sc, ray, ps, dist, best, hit, g, e);
 }
@@ -411,7 +399,7 @@ RPT_DEV bool any_hit_finish(const SceneLarge& sc, const RayD& ray, float max_dis
 RPT_DEV bool any_hit(const SceneLarge& sc, const RayD& ray, float max_dist)
 {
     bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
-    bool occluded = sc.use_grid ? grid_any_sphere(sc, ray, use_max, max_dist) : brute_any_sphere(sc, ray, use_max, max_dist);
+    bool occluded = sc.use_accel ? grid_any_sphere(sc, ray, use_max, max_dist) : brute_any_sphere(sc, ray, use_max, max_dist);
     for (uint32_t k = 0; k < sc.n_planes; ++k) {
         float t;
         bool h = hit_plane(ray, sc.planes[k], t);

@@ -5,11 +5,15 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
 #include <vector>
 
 #include "../../include/rpt.h"
 #include "../../include/rpt_strict_math.h"
 #include "dev_scene.h"
+#include "dev_scene_large.h"
 
 namespace rpthost {
 
@@ -63,9 +67,10 @@ struct HostGrid {
     std::vector<uint32_t> cell_start, items;
 };
 
-inline HostGrid build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per_cell = 1.0)
+// false (with `why`): the cell lists would not fit 32-bit offsets (e.g. tens of thousands of large overlapping
+// spheres, each listed in most cells).
+inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per_cell, HostGrid& g, std::string& why)
 {
-    HostGrid g;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (uint32_t i = 0; i < count; ++i)
         for (int a = 0; a < 3; ++a) {
@@ -108,27 +113,74 @@ inline HostGrid build_grid(const rpt_sphere* sph, uint32_t count, double spheres
         c0 = std::max(0, std::min((int)g.n[a] - 1, c0));
         c1 = std::max(0, std::min((int)g.n[a] - 1, c1));
     };
-    g.cell_start.assign(ncell + 1, 0);
-    for (int pass = 0; pass < 2; ++pass) {
-        std::vector<uint32_t> cursor;
-        if (pass == 1) {
-            for (size_t c = 0; c < ncell; ++c) g.cell_start[c + 1] += g.cell_start[c];      // counts -> exclusive prefix sums
-            cursor.assign(g.cell_start.begin(), g.cell_start.end() - 1);
-            g.items.assign(g.cell_start[ncell], 0);
-        }
-        for (uint32_t i = 0; i < count; ++i) {                                               // ascending sphere index within a cell
-            int x0, x1, y0, y1, z0, z1;
-            range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
-            for (int z = z0; z <= z1; ++z)
-                for (int y = y0; y <= y1; ++y)
-                    for (int x = x0; x <= x1; ++x) {
-                        const size_t c = ((size_t)z * g.n[1] + y) * g.n[0] + x;
-                        if (pass == 0) g.cell_start[c + 1] += 1;
-                        else g.items[cursor[c]++] = i;
-                    }
-        }
+    std::vector<size_t> counts(ncell + 1, 0);                       // size_t: the total is checked before it becomes an offset
+    for (uint32_t i = 0; i < count; ++i) {
+        int x0, x1, y0, y1, z0, z1;
+        range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0; x <= x1; ++x) counts[((size_t)z * g.n[1] + y) * g.n[0] + x + 1] += 1;
     }
-    return g;
+    for (size_t c = 0; c < ncell; ++c) counts[c + 1] += counts[c];  // counts -> exclusive prefix sums
+    if (counts[ncell] > 0x7FFFFFFFull) {
+        why = "the scene's spheres overlap too many grid cells (" + std::to_string(counts[ncell]) + " list entries; the limit is 2^31)";
+        return false;
+    }
+    g.cell_start.assign(counts.begin(), counts.end());
+    std::vector<uint32_t> cursor(g.cell_start.begin(), g.cell_start.end() - 1);
+    g.items.assign(g.cell_start[ncell], 0);
+    for (uint32_t i = 0; i < count; ++i) {                          // ascending sphere index within a cell
+        int x0, x1, y0, y1, z0, z1;
+        range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y)
+                for (int x = x0; x <= x1; ++x) g.items[cursor[((size_t)z * g.n[1] + y) * g.n[0] + x]++] = i;
+    }
+    return true;
+}
+
+// The acceleration structure of a large scene as capi.hip sees it: built once on the host, serialised into the
+// device table allocation after the plain tables, then bound to each device's SceneLarge.
+struct HostAccel {
+    HostGrid grid;
+    std::vector<float> cell_spheres;          // {cx, cy, cz, r} of items[k] at k: a cell's spheres are one load away from its bounds
+    size_t sz_cstart = 0, sz_items = 0, sz_cell_sph = 0;
+
+    size_t bytes() const { return sz_cstart + sz_items + sz_cell_sph; }
+    void write(unsigned char* dst) const
+    {
+        std::memcpy(dst, grid.cell_start.data(), sizeof(uint32_t) * grid.cell_start.size());
+        std::memcpy(dst + sz_cstart, grid.items.data(), sizeof(uint32_t) * grid.items.size());
+        std::memcpy(dst + sz_cstart + sz_items, cell_spheres.data(), sizeof(float) * cell_spheres.size());
+    }
+    void bind(rptdev::SceneLarge& L, const unsigned char* base) const
+    {
+        for (int a = 0; a < 3; ++a) {
+            L.gn[a] = grid.n[a]; L.gmin[a] = grid.gmin[a]; L.gmax[a] = grid.gmax[a];
+            L.cell_size[a] = grid.cs[a]; L.inv_cell_size[a] = grid.inv_cs[a];
+            L.gcenter[a] = grid.center[a];
+        }
+        L.safe_r2 = grid.safe_r2;
+        L.cell_start = reinterpret_cast<const uint32_t*>(base);
+        L.cell_items = reinterpret_cast<const uint32_t*>(base + sz_cstart);
+        L.cell_spheres = reinterpret_cast<const float4*>(base + sz_cstart + sz_items);
+    }
+};
+
+inline bool build_accel(const rpt_sphere* sph, uint32_t count, HostAccel& a, std::string& why)
+{
+    const char* e = getenv("RPT_GRID_SPHERES_PER_CELL");
+    if (!build_grid(sph, count, e ? atof(e) : 1.0, a.grid, why)) return false;
+    a.cell_spheres.resize(a.grid.items.size() * 4);
+    for (size_t k = 0; k < a.grid.items.size(); ++k) {
+        const rpt_sphere& s = sph[a.grid.items[k]];
+        a.cell_spheres[4 * k + 0] = s.center[0]; a.cell_spheres[4 * k + 1] = s.center[1];
+        a.cell_spheres[4 * k + 2] = s.center[2]; a.cell_spheres[4 * k + 3] = s.radius;
+    }
+    a.sz_cstart = (sizeof(uint32_t) * a.grid.cell_start.size() + 15) & ~(size_t)15;
+    a.sz_items = (sizeof(uint32_t) * a.grid.items.size() + 15) & ~(size_t)15;
+    a.sz_cell_sph = sizeof(float) * a.cell_spheres.size();
+    return true;
 }
 
 }  // namespace rpthost

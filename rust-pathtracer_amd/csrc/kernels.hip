@@ -9,9 +9,11 @@
 #include "../../include/rpt.h"
 #include "dev_integrator.h"
 #include "dev_sdf_path.h"
-#include "dev_sdf_pool.h"
 #include "dev_scene_large.h"
-#include "dev_grid_path.h"
+#ifdef RPT_AB_KERNELS                 // measured-slower kernel forms kept for A/B runs only; not in the shipped library
+#include "ab/dev_sdf_pool.h"
+#include "ab/dev_grid_path.h"
+#endif
 #include "launch.h"
 
 // This file is compiled twice: as is (strict arithmetic: -ffp-contract=off, correctly rounded divide/sqrt) and
@@ -223,7 +225,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
 #ifndef RPT_SMALL_WAVES_PER_SIMD
 #define RPT_SMALL_WAVES_PER_SIMD RPT_WAVES_PER_SIMD
 #endif
-#ifdef RPT_SCENE_IN_LDS
+#if defined(RPT_AB_KERNELS) && defined(RPT_SCENE_IN_LDS)
 // A/B build ("why not the other shapes"): the scene tables staged in LDS and read from there (ds_read of a
 // wave-uniform address, value in a VGPR) instead of from the kernarg segment (s_load, value in an SGPR).
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp)
@@ -346,6 +348,7 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
 
+#ifdef RPT_AB_KERNELS
 // SDF scenes, workgroup-wide march pool (dev_sdf_pool.h): the lane states are those of the march kernel above, but a
 // lane in MARCH_P / MARCH_S has SUBMITTED its march and only polls for the answer; the marching itself is done by
 // whichever lanes of the workgroup are serving the queue.  Per pass a wave either runs one of its own blocks — when
@@ -565,6 +568,8 @@ RPT_DEV void render_large_walk_body(const SceneLarge& sc, const RenderParams& rp
 #endif
 __global__ __launch_bounds__(256, RPT_WALK_WAVES_PER_SIMD) void RPT_K(render_large_walk_kernel)(const SceneLarge sc, const RenderParams rp) { render_large_walk_body(sc, rp); }
 
+#endif  // RPT_AB_KERNELS
+
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
 __global__ __launch_bounds__(256) void RPT_K(untile_kernel)(const float4* __restrict__ gathered, float4* __restrict__ image,
                                                      uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
@@ -643,6 +648,93 @@ __global__ __launch_bounds__(256) void RPT_K(probe_math_kernel)(uint32_t fn, con
     out[i] = r;
 }
 
+// One integrator function per record (include/rpt.h, rpt_probe_fn): the same device functions the megakernel inlines.
+struct ProbeLightScene {                                             // what sample_light reads of a scene
+    float n_lights_f;
+    uint32_t flags;
+};
+
+RPT_DEV void probe_material(const float* r, Mat& m)
+{
+    m.rgb = mk3(r[0], r[1], r[2]); m.emission = mk3(r[3], r[4], r[5]);
+    m.anisotropic = r[6]; m.metallic = r[7]; m.roughness = r[8]; m.subsurface = r[9]; m.specular_tint = r[10];
+    m.sheen = r[11]; m.sheen_tint = r[12]; m.clearcoat = r[13]; m.clearcoat_gloss = r[14]; m.spec_trans = r[15]; m.ior = r[16];
+    m.clearcoat_roughness = 0.0f; m.ax = 0.0f; m.ay = 0.0f;
+    mat_finalize(m);
+}
+
+__global__ __launch_bounds__(256) void RPT_K(probe_fn_kernel)(uint32_t fn, const DevCamera cam, const float* __restrict__ in, float* __restrict__ out, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = in + i * RPT_PROBE_IN_STRIDE;
+    float* o = out + i * RPT_PROBE_OUT_STRIDE;
+    for (int k = 0; k < RPT_PROBE_OUT_STRIDE; ++k) o[k] = 0.0f;
+    switch (fn) {
+    case RPT_PROBE_FN_GEN_RAY: {
+        const RayD ray = camera_ray(cam, r[0], r[1], r[2], r[3]);
+        o[0] = ray.o.x; o[1] = ray.o.y; o[2] = ray.o.z; o[3] = ray.d.x; o[4] = ray.d.y; o[5] = ray.d.z;
+        break;
+    }
+    case RPT_PROBE_FN_HIT_SPHERE: {
+        float t = 0.0f;
+        const bool h = hit_sphere(RayD{mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])}, mk3(r[6], r[7], r[8]), r[9], t);
+        o[0] = h ? 1.0f : 0.0f; o[1] = h ? t : 0.0f;
+        break;
+    }
+    case RPT_PROBE_FN_HIT_PLANE: {
+        float t = 0.0f;
+        const DevPlane p{r[6], r[7], r[8], r[9], r[10], r[11], r[12], 0u, r[13]};
+        const bool h = hit_plane(RayD{mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])}, p, t);
+        o[0] = h ? 1.0f : 0.0f; o[1] = h ? t : 0.0f;
+        break;
+    }
+    case RPT_PROBE_FN_SAMPLE_LIGHT: {
+        const DevLight L{rpt_f2u(r[0]), r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11], r[12], r[13], r[14]};
+        const ProbeLightScene sc{r[18], rpt_f2u(r[19])};
+        Rng rng;
+        rng.init(rpt_f2u(r[20]), rpt_f2u(r[21]));
+        rng.counter = rpt_f2u(r[22]);
+        const uint32_t c0 = rng.counter;
+        LightSample ls;
+        sample_light(sc, L, mk3(r[15], r[16], r[17]), ls, rng);
+        o[0] = ls.normal.x; o[1] = ls.normal.y; o[2] = ls.normal.z;
+        o[3] = ls.emission.x; o[4] = ls.emission.y; o[5] = ls.emission.z;
+        o[6] = ls.direction.x; o[7] = ls.direction.y; o[8] = ls.direction.z;
+        o[9] = ls.dist; o[10] = ls.pdf; o[11] = (float)(rng.counter - c0);
+        break;
+    }
+    case RPT_PROBE_FN_DISNEY_EVAL: {
+        Mat m;
+        probe_material(r, m);
+        const float eta = r[17];
+        const v3 v = mk3(r[18], r[19], r[20]), nn = mk3(r[21], r[22], r[23]), l = mk3(r[24], r[25], r[26]);
+        const ShadeFrame fr = make_frame(m, eta, v, nn);
+        float pdf;
+        const v3 f = disney_eval(m, eta, fr, nn, l, pdf);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
+        break;
+    }
+    case RPT_PROBE_FN_DISNEY_SAMPLE: {
+        Mat m;
+        probe_material(r, m);
+        const float eta = r[17];
+        const v3 v = mk3(r[18], r[19], r[20]), nn = mk3(r[21], r[22], r[23]);
+        v3 l = mk3(r[24], r[25], r[26]);
+        Rng rng;
+        rng.init(rpt_f2u(r[27]), rpt_f2u(r[28]));
+        rng.counter = rpt_f2u(r[29]);
+        const uint32_t c0 = rng.counter;
+        const ShadeFrame fr = make_frame(m, eta, v, nn);
+        float pdf;
+        const v3 f = disney_sample(m, eta, fr, nn, l, pdf, rng);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = l.x; o[4] = l.y; o[5] = l.z; o[6] = pdf; o[7] = (float)(rng.counter - c0);
+        break;
+    }
+    default: break;
+    }
+}
+
 __global__ __launch_bounds__(256) void RPT_K(probe_rays_kernel)(const SceneLarge sc, const float* __restrict__ rays, uint32_t* __restrict__ out, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -653,7 +745,7 @@ __global__ __launch_bounds__(256) void RPT_K(probe_rays_kernel)(const SceneLarge
     uint32_t best = 0xFFFFFFFFu;
     bool hit = false;
     bool any;
-    if (sc.use_grid) {
+    if (sc.use_accel) {
         grid_closest_sphere(sc, ray, dist, best, hit);
         any = grid_any_sphere(sc, ray, true, r[6]);
     } else {
@@ -682,11 +774,14 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 {
     const bool has_sdf = !large && scs.sdf.n_prims > 0;
     const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
+    (void)hipGetLastError();                                         // the thread's sticky error may be somebody else's (a host process's own HIP calls)
     if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
-    else if (large && scl.use_grid && rp.grid_resumable_walk) hipLaunchKernelGGL(RPT_K(render_large_walk_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
+#ifdef RPT_AB_KERNELS
+    else if (large && scl.use_accel && rp.grid_resumable_walk) hipLaunchKernelGGL(RPT_K(render_large_walk_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
+    else if (has_sdf && !nested && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
+#endif
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), dim3(nblocks), dim3(256), 0, st, scl, rp);
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
-    else if (has_sdf && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), dim3(nblocks), dim3(256), 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), dim3(nblocks), dim3(256), 0, st, sc, rp);
@@ -703,6 +798,7 @@ hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t 
                   uint32_t rows_padded, hipStream_t st)
 {
     const uint64_t total = (uint64_t)width * height;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(RPT_K(untile_kernel), dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, (const float4*)gathered, (float4*)image,
                        width, height, tile_rows, world, rows_padded);
     return hipGetLastError();
@@ -710,6 +806,7 @@ hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t 
 
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st)
 {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(RPT_K(convert_to_u8_kernel), dim3((uint32_t)((n_pixels + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, (uint32_t*)out, n_pixels);
     return hipGetLastError();
 }
@@ -718,6 +815,7 @@ hipError_t convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8
                             uint32_t height, hipStream_t st)
 {
     const uint64_t n = (uint64_t)width * height;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(RPT_K(convert_to_u8_at_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, (const float4*)pixels, bw, bh,
                        (uint32_t*)frame, at0, at1, width, height);
     return hipGetLastError();
@@ -725,7 +823,15 @@ hipError_t convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8
 
 hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t st)
 {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(RPT_K(probe_math_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, fn, a, b, out, n);
+    return hipGetLastError();
+}
+
+hipError_t probe_fn(uint32_t fn, const DevCamera& cam, const float* in, float* out, uint64_t n, hipStream_t st)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(RPT_K(probe_fn_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, fn, cam, in, out, n);
     return hipGetLastError();
 }
 
@@ -742,6 +848,7 @@ hipError_t prof_read(unsigned long long* out)
 
 hipError_t probe_rays(const SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st)
 {
+    (void)hipGetLastError();
     hipLaunchKernelGGL(RPT_K(probe_rays_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, sc, rays, out, n);
     return hipGetLastError();
 }

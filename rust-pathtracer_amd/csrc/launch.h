@@ -45,6 +45,7 @@ hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, h
 hipError_t convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8_t* frame, uint32_t at0, uint32_t at1, uint32_t width,
                             uint32_t height, hipStream_t st);
 hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t st);
+hipError_t probe_fn(uint32_t fn, const rptdev::DevCamera& cam, const float* in, float* out, uint64_t n, hipStream_t st);
 hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st);
 
 }  // namespace rptlaunch

@@ -1,17 +1,16 @@
-"""Row tiling of the image across the GPUs of a node, and the gather of the tiles.
+"""Row tiling of the image across the GPUs of a node — a thin caller of the library.
 
-The path shards per pixel (tracer.rs:33 touches only its own pixel), so ranks exchange
-nothing while rendering.  Rows are dealt cyclically in blocks of `tile_rows` rows
-(block b -> rank b % world): contiguous slabs would give the sky rows to some GPUs and
-the floor/sphere rows (3-4x more work per sample) to others.  Each rank accumulates
-its rows in a compact tile; one gather (RCCL over xGMI, torch.distributed backend
-"nccl") brings the tiles to every rank when the image is needed.
+The tiling, the per-rank tiles, the RCCL gather to rank 0 and the scatter into the image all live behind the C ABI
+(include/rpt.h: rpt_create_rank / rpt_create_multi, rpt_resident_render, rpt_resident_gather_device).  This module only
+  * distributes rank 0's RCCL unique id over whatever channel the job already has (torch.distributed, any backend), and
+  * keeps index helpers and a CPU-tensor untile for the world-size-2 gloo tests (which have no GPU).
 """
 import ctypes as C
 
 import torch
 
 from . import _lib
+from .api import Tracer, comm_unique_id
 
 
 def tile_row_count(height, tile_rows, rank, world):
@@ -26,13 +25,12 @@ def tile_global_rows(height, tile_rows, rank, world):
 
 
 def padded_rows(height, tile_rows, world):
-    return max(tile_row_count(height, tile_rows, r, world) for r in range(world))
+    return _lib.lib().rpt_tile_rows_padded(height, tile_rows, world)
 
 
 def untile(gathered, width, height, tile_rows, world, tracer=None):
-    """gathered: [world, rows_padded, width, 4] (rank-major, as all_gather returns) ->
-    [height, width, 4].  On CUDA tensors this is the HIP scatter kernel; on CPU tensors
-    (gloo tests) it is an index permutation."""
+    """gathered: [world, rows_padded, width, 4] (rank-major) -> [height, width, 4].  On CUDA tensors this is the
+    library's scatter kernel; on CPU tensors (gloo tests) an index permutation."""
     rows_padded = gathered.shape[1]
     if gathered.is_cuda:
         assert tracer is not None
@@ -50,59 +48,55 @@ def untile(gathered, width, height, tile_rows, world, tracer=None):
     return gathered[src_rank, src_row]
 
 
-def all_gather_tiles(tile, world, group=None):
-    """All-gather equal-size tiles -> [world, rows_padded, width, 4] (rank-major).  The output is
-    allocated in the concatenated form, which both the nccl (RCCL) and gloo backends accept."""
+def gather_tiles(tile, world, group=None, dst=0):
+    """CPU-tensor stand-in of the library's gather (gloo tests): equal-size tiles -> [world, rows_padded, width, 4] on
+    rank `dst`, None elsewhere."""
     import torch.distributed as dist
-    out = torch.empty((world * tile.shape[0],) + tuple(tile.shape[1:]), dtype=tile.dtype, device=tile.device)
-    dist.all_gather_into_tensor(out, tile, group=group)
-    return out.view((world,) + tuple(tile.shape))
+    rank = dist.get_rank(group)
+    out = [torch.empty_like(tile) for _ in range(world)] if rank == dst else None
+    dist.gather(tile, out, dst=dst, group=group)
+    return torch.stack(out) if rank == dst else None
+
+
+def rank_tracer(scene, local_device, seed=1, group=None):
+    """One process per GPU: build this rank's Tracer.  Rank 0 asks the library for an RCCL unique id, the job's
+    torch.distributed group (gloo or nccl, it only carries 128 bytes) hands it to everybody, and every rank joins
+    the library's own communicator (collective)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return Tracer(scene, device=local_device, seed=seed, rank=rank, world=world, unique_id=box[0])
 
 
 class TiledRender:
-    """Progressive render of one image over the ranks of a torch.distributed group."""
+    """Progressive render of one image over the ranks of `tracer` (a rank tracer, a multi-device tracer or a plain one):
+    render_n() accumulates into the per-rank tiles in HBM, gather() assembles the image on rank 0's device."""
 
-    def __init__(self, tracer, width, height, tile_rows=2, group=None, device=None):
-        import torch.distributed as dist
-        self.dist = dist
-        self.group = group
+    def __init__(self, tracer, width, height, tile_rows=2):
         self.tracer = tracer
         self.width, self.height, self.tile_rows = width, height, tile_rows
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rows = tile_row_count(height, tile_rows, self.rank, self.world)
-        self.rows_padded = padded_rows(height, tile_rows, self.world)
-        self.device = device if device is not None else torch.device("cuda", tracer.device)
-        self.tile = torch.zeros(self.rows_padded, width, 4, dtype=torch.float32, device=self.device)
-        self.frames = 0
-        self._snapshot = None       # gather_begin: the tile as it was when the gather was requested
-        self._gathered = None       # all-gather destination, [world * rows_padded, width, 4]
+        self.rank, self.world, self.n_local = tracer.world()
+        tracer.set_tile_rows(tile_rows)
+        self.image = None
+
+    @property
+    def frames(self):
+        return self.tracer.resident_frames()
 
     def render_n(self, spp):
-        self.tracer.render_tile(self.tile, self.width, self.height, self.frames, spp, self.tile_rows, self.rank, self.world)
-        self.frames += spp
-
-    def gather(self):
-        """All ranks receive the full image (all-gather of equal-size tiles + scatter)."""
-        if self.world == 1:
-            return self.tile[: self.height].clone() if self.rows == self.height else untile(
-                self.tile.unsqueeze(0), self.width, self.height, self.tile_rows, 1, self.tracer)
-        return self.gather_end(self.gather_begin())
+        self.tracer.render_resident(self.width, self.height, spp)
 
     def gather_begin(self):
-        """Start the all-gather of the tile as it is NOW and return a handle for gather_end().  The collective runs on
-        the process group's own stream (RCCL over xGMI), so render_n() calls issued before gather_end() overlap with it;
-        the tile is snapshotted first (one device-to-device copy) because the next render_n() updates it in place.
-        At most one gather is in flight: call gather_end() before the next gather_begin()."""
-        assert self.world > 1
-        if self._snapshot is None:
-            self._snapshot = torch.empty_like(self.tile)
-            self._gathered = torch.empty((self.world * self.rows_padded, self.width, 4), dtype=torch.float32, device=self.device)
-        self._snapshot.copy_(self.tile)
-        return self.dist.all_gather_into_tensor(self._gathered, self._snapshot, group=self.group, async_op=True)
+        """Enqueue gather + scatter behind the renders (no host wait); the image is valid after gather_end()."""
+        if self.rank == 0 and self.image is None:
+            self.image = torch.empty(self.height, self.width, 4, dtype=torch.float32, device=torch.device("cuda", self.tracer.device))
+        self.tracer.resident_gather(self.image if self.rank == 0 else None)
 
-    def gather_end(self, work):
-        """Wait for gather_begin()'s collective (a stream-level wait on device tensors) and scatter the tiles into the image."""
-        work.wait()
-        out = self._gathered.view(self.world, self.rows_padded, self.width, 4)
-        return untile(out, self.width, self.height, self.tile_rows, self.world, self.tracer)
+    def gather_end(self):
+        self.tracer.resident_sync()
+        return self.image
+
+    def gather(self):
+        self.gather_begin()
+        return self.gather_end()

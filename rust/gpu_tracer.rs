@@ -1,5 +1,7 @@
-//! Reference-side binding for the MI355X render path (source only: this image has no Rust toolchain,
-//! so this file has not been compiled here; it mirrors include/rpt.h one to one).
+//! Reference-side binding for the MI355X render path (source only: this image has no Rust toolchain, so this
+//! file has not been compiled here; tests/test_rust_binding.py checks every `#[repr(C)]` struct and every
+//! `extern "C"` signature below against include/rpt.h mechanically — field order, types, offsets, sizes,
+//! argument lists — and `GpuTracer::new` asserts `size_of::<RptSceneDesc>()` against the loaded library).
 //!
 //! Drop this file into `rust-pathtracer/src/`, add `pub mod gpu_tracer;` to `lib.rs`, link with
 //! `-L <repo>/rust-pathtracer_amd -l rpt_hip`, and replace `Tracer::new(scene)` by
@@ -22,7 +24,14 @@ pub struct RptMaterial {
 pub struct RptLight { pub light_type: u32, pub position: [f32; 3], pub emission: [f32; 3], pub u: [f32; 3], pub v: [f32; 3], pub radius: f32, pub area: f32 }
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptCamera { pub origin: [f32; 3], pub center: [f32; 3], pub fov_deg: f32 }
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptBackground { pub kind: u32, pub colour_a: [f32; 3], pub colour_b: [f32; 3], pub gamma: f32, pub scale: f32 }
-#[repr(C)]
+#[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptSdfPrim { pub kind: u32, pub center: [f32; 3], pub params: [f32; 2] }
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct RptSdf {
+    pub n_prims: u32, pub max_steps: u32, pub material: u32,
+    pub smooth_k: f32, pub hit_eps: f32, pub max_t: f32, pub normal_eps: f32,
+    pub prims: *const RptSdfPrim,
+}
+#[repr(C)] #[derive(Clone, Copy)]
 pub struct RptSceneDesc {
     pub abi_version: u32, pub flags: u32,
     pub camera: RptCamera, pub background: RptBackground,
@@ -31,12 +40,29 @@ pub struct RptSceneDesc {
     pub n_planes: u32, pub planes: *const RptPlane,
     pub n_lights: u32, pub lights: *const RptLight,
     pub n_materials: u32, pub materials: *const RptMaterial,
+    pub sdf: RptSdf,
+}
+#[repr(C)] #[derive(Clone, Copy)] pub struct RptUniqueId { pub bytes: [c_char; 128] }
+
+pub const RPT_ABI_VERSION: u32 = 2;
+
+impl RptSceneDesc {
+    /// All zeros (no primitives, no SDF object): the starting point of every `describe()`.
+    pub fn zeroed() -> Self { unsafe { std::mem::zeroed() } }
 }
 
 #[repr(C)] pub struct RptCtx { _private: [u8; 0] }
 
 extern "C" {
+    fn rpt_abi_version() -> u32;
+    fn rpt_sizeof_scene_desc() -> u32;
     fn rpt_create(out: *mut *mut RptCtx, device_id: c_int) -> c_int;
+    fn rpt_create_multi(out: *mut *mut RptCtx, device_ids: *const c_int, n_devices: c_int) -> c_int;
+    #[allow(dead_code)]
+    fn rpt_comm_unique_id(out: *mut RptUniqueId) -> c_int;
+    #[allow(dead_code)]
+    fn rpt_create_rank(out: *mut *mut RptCtx, device_id: c_int, rank: c_int, world: c_int, id: *const RptUniqueId) -> c_int;
+    fn rpt_set_tile_rows(ctx: *mut RptCtx, tile_rows: u32) -> c_int;
     fn rpt_destroy(ctx: *mut RptCtx);
     fn rpt_last_error(ctx: *const RptCtx) -> *const c_char;
     fn rpt_upload_scene(ctx: *mut RptCtx, scene: *const RptSceneDesc) -> c_int;
@@ -44,6 +70,7 @@ extern "C" {
     fn rpt_render(ctx: *mut RptCtx, pixels: *mut f32, width: u32, height: u32,
                   frames_done: u64, spp: u32, seed: u64, flags: u32) -> c_int;
     fn rpt_resident_render(ctx: *mut RptCtx, width: u32, height: u32, spp: u32, seed: u64, flags: u32) -> c_int;
+    fn rpt_resident_upload(ctx: *mut RptCtx, pixels: *const f32, width: u32, height: u32, frames: u64) -> c_int;
     fn rpt_resident_download(ctx: *mut RptCtx, pixels: *mut f32) -> c_int;
     fn rpt_resident_download_u8(ctx: *mut RptCtx, frame: *mut u8) -> c_int;
     fn rpt_resident_frames(ctx: *const RptCtx, frames: *mut u64) -> c_int;
@@ -56,7 +83,8 @@ extern "C" {
 /// A scene that can describe itself as data.  `trait Scene` (scene.rs:5-90) is callbacks and cannot
 /// run on the device; scenes that implement only `Scene` keep using the CPU `Tracer`.
 pub trait GpuScene: Scene {
-    /// The backing arrays must outlive the returned descriptor (keep them in `self`).
+    /// The backing arrays must outlive the returned descriptor (keep them in `self`).  Start from
+    /// `RptSceneDesc::zeroed()` and set `abi_version = RPT_ABI_VERSION`.
     fn describe(&self) -> RptSceneDesc;
 }
 
@@ -64,27 +92,42 @@ pub trait GpuScene: Scene {
 pub struct GpuTracer {
     ctx: *mut RptCtx,
     scene: Box<dyn GpuScene>,
+    dirty: bool,
     pub seed: u64,
+    pub flags: u32,
 }
 
 impl GpuTracer {
-    pub fn new(scene: Box<dyn GpuScene>) -> Self {
+    /// `Tracer::new` (tracer.rs:13-19) on GPU 0.
+    pub fn new(scene: Box<dyn GpuScene>) -> Self { Self::with_devices(scene, &[0]) }
+
+    /// The same over several GPUs of the node: `render` fans the image rows out over them inside the call,
+    /// exactly where the reference fans out over rayon's threads (tracer.rs:29-32).
+    pub fn with_devices(scene: Box<dyn GpuScene>, devices: &[i32]) -> Self {
+        assert!(unsafe { rpt_abi_version() } == RPT_ABI_VERSION, "librpt_hip ABI version mismatch");
+        assert!(unsafe { rpt_sizeof_scene_desc() } as usize == std::mem::size_of::<RptSceneDesc>(),
+                "RptSceneDesc does not match the library's rpt_scene_desc");
         let mut ctx: *mut RptCtx = std::ptr::null_mut();
-        let rc = unsafe { rpt_create(&mut ctx, 0) };
+        let rc = if devices.len() == 1 { unsafe { rpt_create(&mut ctx, devices[0] as c_int) } }
+                 else { unsafe { rpt_create_multi(&mut ctx, devices.as_ptr() as *const c_int, devices.len() as c_int) } };
         assert!(rc == 0, "rpt_create failed: {}", Self::err(std::ptr::null()));
-        let t = Self { ctx, scene, seed: 1 };
+        let mut t = Self { ctx, scene, dirty: true, seed: 1, flags: 0 };
         t.upload();
         t
     }
+
+    /// Rows per cyclic block of the multi-GPU row tiling (default 2).
+    pub fn set_tile_rows(&mut self, tile_rows: u32) { unsafe { rpt_set_tile_rows(self.ctx, tile_rows); } }
 
     fn err(ctx: *const RptCtx) -> String {
         unsafe { std::ffi::CStr::from_ptr(rpt_last_error(ctx)).to_string_lossy().into_owned() }
     }
 
-    fn upload(&self) {
+    fn upload(&mut self) {
         let desc = self.scene.describe();
         let rc = unsafe { rpt_upload_scene(self.ctx, &desc) };
         assert!(rc == 0, "rpt_upload_scene failed: {}", Self::err(self.ctx));
+        self.dirty = false;
     }
 
     /// Render one frame and accumulate into the pixels buffer — the contract of tracer.rs:21-123:
@@ -95,9 +138,10 @@ impl GpuTracer {
 
     /// `spp` consecutive frames in one launch; bit-identical to calling `render` `spp` times.
     pub fn render_n(&mut self, buffer: &mut ColorBuffer, spp: u32) {
+        if self.dirty { self.upload(); }
         let rc = unsafe {
             rpt_render(self.ctx, buffer.pixels.as_mut_ptr(), buffer.width as u32, buffer.height as u32,
-                       buffer.frames as u64, spp, self.seed, 0)
+                       buffer.frames as u64, spp, self.seed, self.flags)
         };
         assert!(rc == 0, "rpt_render failed: {}", Self::err(self.ctx));
         buffer.frames += spp as usize;                       // tracer.rs:121
@@ -108,10 +152,17 @@ impl GpuTracer {
     /// cross PCIe instead of 32).  `frame.len() == width * height * 4`.
     pub fn render_resident_to_u8(&mut self, width: usize, height: usize, frame: &mut [u8]) {
         assert!(frame.len() == width * height * 4);
-        let rc = unsafe { rpt_resident_render(self.ctx, width as u32, height as u32, 1, self.seed, 0) };
+        if self.dirty { self.upload(); }
+        let rc = unsafe { rpt_resident_render(self.ctx, width as u32, height as u32, 1, self.seed, self.flags) };
         assert!(rc == 0, "rpt_resident_render failed: {}", Self::err(self.ctx));
         let rc = unsafe { rpt_resident_download_u8(self.ctx, frame.as_mut_ptr()) };
         assert!(rc == 0, "rpt_resident_download_u8 failed: {}", Self::err(self.ctx));
+    }
+
+    /// Continue a host ColorBuffer (pixels + frames) in the resident buffer.
+    pub fn resident_from(&mut self, buffer: &ColorBuffer) {
+        let rc = unsafe { rpt_resident_upload(self.ctx, buffer.pixels.as_ptr(), buffer.width as u32, buffer.height as u32, buffer.frames as u64) };
+        assert!(rc == 0, "rpt_resident_upload failed: {}", Self::err(self.ctx));
     }
 
     /// Copy the resident buffer back into a host ColorBuffer (pixels and frames).
@@ -125,9 +176,9 @@ impl GpuTracer {
 
     pub fn resident_reset(&mut self) { unsafe { rpt_resident_reset(self.ctx); } }
 
-    /// Return a mutable reference to the scene (tracer.rs:629); call `sync_scene` after mutating it.
-    pub fn scene(&mut self) -> &mut Box<dyn GpuScene> { &mut self.scene }
-    pub fn sync_scene(&mut self) { self.upload(); }
+    /// Return a mutable reference to the scene (tracer.rs:629).  The caller may mutate it through `as_any`
+    /// exactly as with `Tracer`; the next `render` re-describes and re-uploads it.
+    pub fn scene(&mut self) -> &mut Box<dyn GpuScene> { self.dirty = true; &mut self.scene }
 }
 
 impl Drop for GpuTracer {
@@ -136,6 +187,8 @@ impl Drop for GpuTracer {
 
 /// `describe()` for renderer/src/analytical.rs: the library already knows this scene.
 pub fn analytical_scene_desc() -> RptSceneDesc {
-    let mut d = std::mem::MaybeUninit::<RptSceneDesc>::zeroed();
-    unsafe { rpt_scene_analytical(d.as_mut_ptr()); d.assume_init() }
+    let mut d = RptSceneDesc::zeroed();
+    let rc = unsafe { rpt_scene_analytical(&mut d) };
+    assert!(rc == 0);
+    d
 }

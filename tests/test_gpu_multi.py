@@ -1,0 +1,123 @@
+"""Multi-GPU behind the C ABI, on the one GPU a test box has (needs an MI355X).
+
+  * rpt_create_multi with n = 1: the same code path an 8-device context takes (tiles, ncclCommInitAll, grouped
+    ncclSend / ncclRecv to rank 0, scatter kernel) with a one-rank communicator; every entry point must give the
+    single-device image bit for bit.
+  * rpt_create_rank with world = 1: the one-process-per-GPU construction (unique id, ncclCommInitRank).
+  * virtual ranks: RPT_GATHER=p2p accepts the same device id several times and gathers with peer copies instead of
+    RCCL (which needs distinct devices): n = 2, 3, 8 ranks of the real tiling, copies, gather offsets and scatter
+    through the real entry points.
+Bit-identical to the oracle throughout (the image must not depend on the number of ranks)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_bit_identical
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def _exercise(rpt, oracle, t, w, h, torch, what):
+    """render (host buffer), resident render in two steps, download f32 / u8, device gather, resume from a host buffer."""
+    want1 = oracle.render(oracle.scene_analytical(), w, h, 2, seed=1)
+    want2 = oracle.render(oracle.scene_analytical(), w, h, 5, seed=1)
+    buf = rpt.ColorBuffer(w, h)
+    t.render_n(buf, 2)
+    assert buf.frames == 2
+    assert_bit_identical(buf.image(), want1, what + ": rpt_render, host buffer")
+    t.render_n(buf, 3)                                                # resume through the host buffer
+    assert_bit_identical(buf.image(), want2, what + ": rpt_render resumed")
+
+    t.resident_reset()
+    t.render_resident(w, h, 2)
+    got = t.resident_to_host(w, h)
+    assert got.frames == 2
+    assert_bit_identical(got.image(), want1, what + ": resident step 1")
+    t.render_resident(w, h, 3)
+    assert t.resident_frames() == 5
+    img = torch.empty(h, w, 4, dtype=torch.float32, device="cuda:0")
+    t.resident_gather(img)
+    t.resident_sync()
+    assert_bit_identical(img.cpu().numpy(), want2, what + ": rpt_resident_gather_device")
+    assert t.resident_kernel_ms() > 0.0
+    u8 = t.resident_to_u8(w, h)
+    want_u8 = np.zeros(w * h * 4, dtype=np.uint8)
+    oracle.lib.oracle_convert_to_u8(want2.ctypes.data, want_u8.ctypes.data, w, h)
+    assert np.array_equal(u8, want_u8), what + ": rpt_resident_download_u8"
+
+    t.resident_reset()                                                # resume a cloned host ColorBuffer in the resident buffer
+    half = rpt.ColorBuffer(w, h)
+    half.pixels[:] = want1.reshape(-1)
+    half.frames = 2
+    t.resident_upload(half)
+    t.render_resident(w, h, 3)
+    assert_bit_identical(t.resident_to_host(w, h).image(), want2, what + ": rpt_resident_upload + render")
+
+
+@pytest.mark.parametrize("w,h", [(72, 54), (40, 27)])
+def test_multi_context_with_one_device_uses_rccl_and_matches(rpt, oracle, torch_cuda, w, h):
+    os.environ.pop("RPT_GATHER", None)
+    t = rpt.Tracer(rpt.AnalyticalScene(), devices=[0], seed=1)
+    assert t.world() == (0, 1, 1)
+    _exercise(rpt, oracle, t, w, h, torch_cuda, "rpt_create_multi n=1 (RCCL)")
+    t.close()
+
+
+def test_rank_context_world_one(rpt, oracle, torch_cuda):
+    uid = rpt.comm_unique_id()
+    assert len(uid) == 128
+    t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1, rank=0, world=1, unique_id=uid)
+    assert t.world() == (0, 1, 1)
+    _exercise(rpt, oracle, t, 72, 54, torch_cuda, "rpt_create_rank world=1 (RCCL)")
+    t.close()
+
+
+@pytest.mark.parametrize("n,tile_rows,w,h", [(2, 2, 72, 54), (3, 4, 72, 54), (8, 2, 72, 54), (4, 16, 40, 27), (8, 1, 24, 5), (2, 5, 40, 27)])
+def test_virtual_ranks_through_the_multi_context(rpt, oracle, torch_cuda, n, tile_rows, w, h):
+    """n ranks on one device (peer-copy gather): the real tiling arithmetic, strided host copies, gather offsets and
+    scatter kernel of an n-GPU context.  Sizes include ranks that own no row and a short last block."""
+    os.environ["RPT_GATHER"] = "p2p"
+    try:
+        t = rpt.Tracer(rpt.AnalyticalScene(), devices=[0] * n, seed=1)
+    finally:
+        os.environ.pop("RPT_GATHER", None)
+    assert t.world() == (0, n, n)
+    t.set_tile_rows(tile_rows)
+    _exercise(rpt, oracle, t, w, h, torch_cuda, "virtual ranks n=%d tile_rows=%d" % (n, tile_rows))
+    t.close()
+
+
+def test_duplicate_devices_need_peer_gather(rpt, torch_cuda):
+    os.environ.pop("RPT_GATHER", None)
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 0)
+    assert rpt.lib().rpt_create_multi(C.byref(h), ids, 2) == rpt._abi.RPT_ERR_INVALID_ARG
+    assert b"distinct" in rpt.lib().rpt_last_error(None)
+
+
+def test_multi_context_large_scene_and_progressive_gathers(rpt, oracle, torch_cuda):
+    """A scene with device tables (one copy per device of the context) on 3 virtual ranks, gathered after each of two
+    steps: the second gather reuses the staging buffers of the first."""
+    from rust_pathtracer_amd import scenes
+    s = scenes.random_spheres_scene(n_spheres=300, n_lights=6)
+    w, h = 64, 40
+    os.environ["RPT_GATHER"] = "p2p"
+    try:
+        t = rpt.Tracer(s, devices=[0, 0, 0], seed=3)
+    finally:
+        os.environ.pop("RPT_GATHER", None)
+    desc = s.describe()
+    t.render_resident(w, h, 1)
+    assert_bit_identical(t.resident_to_host(w, h).image(), oracle.render(desc, w, h, 1, seed=3), "large scene, step 1")
+    t.render_resident(w, h, 2)
+    assert_bit_identical(t.resident_to_host(w, h).image(), oracle.render(desc, w, h, 3, seed=3), "large scene, step 2")
+    t.close()

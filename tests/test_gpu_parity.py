@@ -291,7 +291,7 @@ def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
     w, h, spp = 96, 54, 3
     t = rpt.Tracer(s, device=0, seed=5)
     # default: the grid walk inside the bounce (from 64 spheres up); then the resumable walk; then nested loops
-    for flags in (0, rpt._abi.RPT_RENDER_GRID_RESUMABLE_WALK, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -323,7 +323,7 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
         s.any_hit_uses_max_dist = use_max
         t = rpt.Tracer(s, device=0, seed=9)
         want = oracle.render(s.describe(), w, h, spp, seed=9)
-        for flags in (0, rpt._abi.RPT_RENDER_SDF_POOL_MARCH, rpt._abi.RPT_RENDER_SDF_INLINE_MARCH, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+        for flags in (0, rpt._abi.RPT_RENDER_SDF_INLINE_MARCH, rpt._abi.RPT_RENDER_NESTED_LOOPS):
             t.flags = flags
             buf = rpt.ColorBuffer(w, h)
             t.render_n(buf, spp)
@@ -505,7 +505,7 @@ def test_random_sdf_scenes_match_oracle(rpt, oracle, seed):
     w, h, spp = int(rng.integers(8, 90)), int(rng.integers(8, 60)), int(rng.integers(1, 4))
     want = oracle.render(s.describe(), w, h, spp, seed=seed)
     t = rpt.Tracer(s, device=0, seed=seed)
-    for flags in (0, A.RPT_RENDER_SDF_POOL_MARCH, A.RPT_RENDER_SDF_INLINE_MARCH, A.RPT_RENDER_NESTED_LOOPS):
+    for flags in (0, A.RPT_RENDER_SDF_INLINE_MARCH, A.RPT_RENDER_NESTED_LOOPS):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -556,12 +556,23 @@ def test_full_size_config5_frame(rpt, torch_cuda, oracle):
     finally:
         del os.environ["RPT_NO_GRID"]
     assert torch.equal(brute.pixels.view(torch.int32), grid.pixels.view(torch.int32))
-    t.upload_scene()                                       # with the grid again: the walk as a scheduling state
-    t.flags = rpt._abi.RPT_RENDER_GRID_RESUMABLE_WALK
-    walk = rpt.DeviceColorBuffer(w, h)
-    t.render_n(walk, spp)
-    torch.cuda.synchronize()
-    assert torch.equal(walk.pixels.view(torch.int32), grid.pixels.view(torch.int32))
+    t.close()
+
+
+def test_ab_kernels_are_not_in_the_shipped_library(rpt, torch_cuda):
+    """The measured-slower kernel forms (csrc/ab/) are only built with -DRPT_AB_KERNELS: the shipped library refuses
+    their flags loudly instead of silently running something else."""
+    from rust_pathtracer_amd import scenes
+    t = rpt.Tracer(scenes.sdf_scene(), device=0, seed=1)
+    buf = rpt.DeviceColorBuffer(16, 16)
+    for flag in (rpt._abi.RPT_RENDER_SDF_POOL_MARCH, rpt._abi.RPT_RENDER_GRID_RESUMABLE_WALK):
+        t.flags = flag
+        try:
+            t.render_n(buf, 1)
+        except rpt.RptError as e:
+            assert e.status == rpt._abi.RPT_ERR_UNSUPPORTED
+        else:
+            pytest.skip("this library was built with -DRPT_AB_KERNELS")
     t.close()
 
 

@@ -1,7 +1,8 @@
-"""The N > 1 path on CPU: two gloo ranks deal the image rows cyclically, each fills its compact tile
-(here with the CPU oracle standing in for the GPU kernel — this test is about the tiling, the
-all-gather and the untile step, not about rendering), all-gather, untile, and every rank must hold
-the single-process image bit for bit."""
+"""The N > 1 path on CPU, world size 2 over gloo.  There is no GPU here, so the kernel is replaced by the CPU oracle
+rendering exactly the rows a rank owns; what is under test is everything around it that the multi-process job relies on:
+the library's tile arithmetic (which rows a rank owns, where they sit in its compact tile, the padded tile size), the
+distribution of rank 0's communicator id over the job's process group, the gather of equal-size tiles to rank 0 and the
+scatter into the top-down image, and progressive accumulation across steps (frames carried between render calls)."""
 import os
 import sys
 
@@ -14,84 +15,83 @@ import torch.multiprocessing as mp
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, w, h, tile_rows, spp, out_dir):
+def _worker(rank, world, port, w, h, tile_rows, steps, out_dir):
     sys.path.insert(0, HERE)
-    import conftest
+    import conftest  # noqa: F401
     import oracle_lib
     from rust_pathtracer_amd import tiling
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        # the id hand-off of tiling.rank_tracer, with a stand-in for the library's rpt_comm_unique_id (no RCCL without a GPU)
+        box = [bytes(range(128)) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        assert box[0] == bytes(range(128))
+
         o = oracle_lib.Oracle()
         desc = o.scene_analytical()
         rows = tiling.tile_global_rows(h, tile_rows, rank, world)
         padded = tiling.padded_rows(h, tile_rows, world)
+        assert len(rows) <= padded
         tile = np.zeros((padded, w, 4), dtype=np.float32)
         full_scratch = np.zeros((h, w, 4), dtype=np.float32)
-        for lr, g in enumerate(rows):                       # this rank renders only the rows it owns
-            o.render(desc, w, h, spp, seed=1, pixels=full_scratch, rows=(g, g + 1), threads=1)
-            tile[lr] = full_scratch[g]
-        t = torch.from_numpy(tile)
-        img = tiling.all_gather_tiles(t, world)
-        img = tiling.untile(img, w, h, tile_rows, world)
-        np.save(os.path.join(out_dir, "rank%d.npy" % rank), img.numpy())
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("tile_rows", [2, 5])
-def test_two_rank_tiled_render_equals_single_process(tmp_path, oracle, tile_rows):
-    w, h, spp, world = 40, 27, 2, 2
-    port = 29500 + (os.getpid() % 2000) + tile_rows
-    mp.spawn(_worker, args=(world, port, w, h, tile_rows, spp, str(tmp_path)), nprocs=world, join=True)
-    want = oracle.render(oracle.scene_analytical(), w, h, spp, seed=1)
-    for r in range(world):
-        got = np.load(os.path.join(str(tmp_path), "rank%d.npy" % r))
-        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "rank %d" % r
-
-
-def _pipelined_worker(rank, world, port, w, h, tile_rows, out_dir):
-    """bench.py's N > 1 loop: the gather of step k is begun, step k+1 updates the tile in place, then the gather is
-    ended — it must deliver step k's image (the tile is snapshotted), and the next gather step k+1's."""
-    sys.path.insert(0, HERE)
-    import conftest
-    import oracle_lib
-    from rust_pathtracer_amd import tiling
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        o = oracle_lib.Oracle()
-        desc = o.scene_analytical()
-        job = tiling.TiledRender(None, w, h, tile_rows=tile_rows, device=torch.device("cpu"))
-        rows = tiling.tile_global_rows(h, tile_rows, rank, world)
-        full = np.zeros((h, w, 4), dtype=np.float32)
-
-        def render_step(frames_done, spp):                  # the oracle stands in for the kernel, rows of this rank only
+        frames = 0
+        for k, spp in enumerate(steps):                      # progressive: each step continues the rank's running means
             for lr, g in enumerate(rows):
-                o.render(desc, w, h, spp, seed=1, frames_done=frames_done, pixels=full, rows=(g, g + 1), threads=1)
-                job.tile[lr] = torch.from_numpy(full[g])
-
-        render_step(0, 2)
-        pending = job.gather_begin()
-        render_step(2, 1)                                   # updates job.tile in place while the gather is in flight
-        img1 = job.gather_end(pending).clone()
-        img2 = job.gather()
-        np.save(os.path.join(out_dir, "p%d_1.npy" % rank), img1.numpy())
-        np.save(os.path.join(out_dir, "p%d_2.npy" % rank), img2.numpy())
+                full_scratch[g] = tile[lr]
+                o.render(desc, w, h, spp, seed=1, frames_done=frames, pixels=full_scratch, rows=(g, g + 1), threads=1)
+                tile[lr] = full_scratch[g]
+            frames += spp
+            gathered = tiling.gather_tiles(torch.from_numpy(tile), world, dst=0)
+            if rank == 0:
+                img = tiling.untile(gathered, w, h, tile_rows, world)
+                np.save(os.path.join(out_dir, "step%d.npy" % k), img.numpy())
+            else:
+                assert gathered is None
     finally:
         dist.destroy_process_group()
 
 
-def test_pipelined_gather_delivers_the_step_it_was_begun_for(tmp_path, oracle):
-    w, h, world, tile_rows = 40, 27, 2, 2
-    port = 31500 + (os.getpid() % 2000)
-    mp.spawn(_pipelined_worker, args=(world, port, w, h, tile_rows, str(tmp_path)), nprocs=world, join=True)
-    want1 = oracle.render(oracle.scene_analytical(), w, h, 2, seed=1)
-    want2 = oracle.render(oracle.scene_analytical(), w, h, 3, seed=1)
-    for r in range(world):
-        got1 = np.load(os.path.join(str(tmp_path), "p%d_1.npy" % r))
-        got2 = np.load(os.path.join(str(tmp_path), "p%d_2.npy" % r))
-        assert np.array_equal(got1.view(np.uint32), want1.view(np.uint32)), "rank %d step 1" % r
-        assert np.array_equal(got2.view(np.uint32), want2.view(np.uint32)), "rank %d step 2" % r
+@pytest.mark.parametrize("tile_rows,h", [(2, 27), (5, 27), (2, 8), (16, 9)])
+def test_two_rank_tiled_render_equals_single_process(tmp_path, oracle, tile_rows, h):
+    w, world, steps = 40, 2, (2, 1)
+    port = 29500 + (os.getpid() % 2000) + tile_rows + h
+    mp.spawn(_worker, args=(world, port, w, h, tile_rows, steps, str(tmp_path)), nprocs=world, join=True)
+    total = 0
+    for k, spp in enumerate(steps):
+        total += spp
+        want = oracle.render(oracle.scene_analytical(), w, h, total, seed=1)
+        got = np.load(os.path.join(str(tmp_path), "step%d.npy" % k))
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "step %d" % k
+
+
+def test_tile_copy_plan_covers_exactly_the_ranks_rows(rpt):
+    """rpt_tile_copy_plan (what rpt_render / rpt_resident_upload follow for their one strided copy per device) against
+    the row-by-row definition rpt_tile_global_row, for every rank of many image / block / world sizes."""
+    import ctypes as C
+    lib = rpt.lib()
+    for height in (1, 2, 7, 9, 16, 27, 54, 600, 1080, 2160):
+        for tile_rows in (1, 2, 3, 5, 8, 16, 4000):
+            for world in (1, 2, 3, 4, 8):
+                seen = {}
+                for rank in range(world):
+                    plan = rpt._abi.rpt_tile_plan()
+                    assert lib.rpt_tile_copy_plan(height, tile_rows, rank, world, C.byref(plan)) == 0
+                    pairs = []                                   # (host row, tile row) the plan copies
+                    for b in range(plan.full_blocks):
+                        for r in range(plan.block_rows):
+                            pairs.append((plan.host_row0 + b * plan.host_row_stride + r, b * plan.block_rows + r))
+                    for r in range(plan.ragged_rows):
+                        pairs.append((plan.ragged_host_row0 + r, plan.ragged_tile_row0 + r))
+                    n = lib.rpt_tile_row_count(height, tile_rows, rank, world)
+                    want = [(lib.rpt_tile_global_row(i, tile_rows if world > 1 else height, rank, world), i) for i in range(n)]
+                    assert sorted(pairs, key=lambda p: p[1]) == want, (height, tile_rows, world, rank)
+                    assert n <= lib.rpt_tile_rows_padded(height, tile_rows, world)
+                    for g, _ in pairs:
+                        assert g not in seen and 0 <= g < height
+                        seen[g] = rank
+                assert len(seen) == height
+    bad = rpt._abi.rpt_tile_plan()
+    assert lib.rpt_tile_copy_plan(10, 0, 0, 1, C.byref(bad)) == rpt._abi.RPT_ERR_INVALID_ARG
+    assert lib.rpt_tile_copy_plan(10, 2, 3, 3, C.byref(bad)) == rpt._abi.RPT_ERR_INVALID_ARG
