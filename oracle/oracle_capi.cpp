@@ -314,6 +314,49 @@ void oracle_sample_light(const rpt_light* light, const float* scatter_pos, uint3
     out[9] = raw(ls.dist); out[10] = raw(ls.pdf); out[11] = (float)(rng.counter - counter);
 }
 
+// The record-per-call layouts of include/rpt.h's rpt_probe_fn, evaluated by the oracle (one call for n records).
+// cam = {origin[3], center[3], fov}; params = {width, height} (GEN_RAY only).
+static inline uint32_t fbits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+void oracle_probe_fn(uint32_t fn, const float* in, float* out, uint64_t n, const float* cam, const float* params)
+{
+    for (uint64_t i = 0; i < n; ++i) {
+        const float* r = in + i * RPT_PROBE_IN_STRIDE;
+        float* o = out + i * RPT_PROBE_OUT_STRIDE;
+        for (int k = 0; k < RPT_PROBE_OUT_STRIDE; ++k) o[k] = 0.0f;
+        switch (fn) {
+        case RPT_PROBE_FN_GEN_RAY: oracle_gen_ray(cam, r[0], r[1], r[2], r[3], params[0], params[1], o); break;
+        case RPT_PROBE_FN_HIT_SPHERE: {
+            float t = 0.0f;
+            int h = oracle_sphere(r, r + 3, r + 6, r[9], &t);
+            o[0] = h ? 1.0f : 0.0f; o[1] = h ? t : 0.0f;
+            break;
+        }
+        case RPT_PROBE_FN_HIT_PLANE: {
+            rpt_plane p;
+            std::memset(&p, 0, sizeof(p));
+            for (int k = 0; k < 3; ++k) { p.normal[k] = r[6 + k]; p.point[k] = r[9 + k]; }
+            p.min_denom = r[12]; p.max_t = r[13];
+            float t = 0.0f;
+            int h = oracle_plane(r, r + 3, &p, &t);
+            o[0] = h ? 1.0f : 0.0f; o[1] = h ? t : 0.0f;
+            break;
+        }
+        case RPT_PROBE_FN_SAMPLE_LIGHT: {
+            rpt_light L;
+            std::memset(&L, 0, sizeof(L));
+            L.type = fbits(r[0]);
+            for (int k = 0; k < 3; ++k) { L.position[k] = r[1 + k]; L.emission[k] = r[4 + k]; L.u[k] = r[9 + k]; L.v[k] = r[12 + k]; }
+            L.radius = r[7]; L.area = r[8];
+            oracle_sample_light(&L, r + 15, (uint32_t)r[18], fbits(r[19]), fbits(r[20]), fbits(r[21]), fbits(r[22]), o);
+            break;
+        }
+        case RPT_PROBE_FN_DISNEY_EVAL: oracle_disney_eval(r, r[17], r + 18, r + 21, r + 24, o); break;
+        case RPT_PROBE_FN_DISNEY_SAMPLE: oracle_disney_sample(r, r[17], r + 18, r + 21, r + 24, fbits(r[27]), fbits(r[28]), fbits(r[29]), o); break;
+        default: break;
+        }
+    }
+}
+
 // RNG stream: first n u32 draws of (seed, frame, pixel)
 void oracle_rng_u32(uint64_t seed, uint64_t frame, uint32_t pixel, uint32_t n, uint32_t* out)
 {

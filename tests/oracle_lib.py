@@ -54,13 +54,27 @@ class Oracle:
         self.lib.oracle_scene_analytical(C.byref(d))
         return d
 
-    def render(self, desc, width, height, spp, seed=1, frames_done=0, pixels=None, rows=None, threads=0):
+    def render(self, desc, width, height, spp, seed=1, frames_done=0, pixels=None, rows=None, threads=0, render_flags=0):
         if pixels is None:
             pixels = np.zeros((height, width, 4), dtype=np.float32)
         r0, r1 = rows if rows is not None else (0, height)
-        rc = self.lib.oracle_render(C.byref(desc), pixels.ctypes.data, width, height, frames_done, spp, seed, r0, r1, threads)
+        self.lib.oracle_render_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64,
+                                                 C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
+        rc = self.lib.oracle_render_flags(C.byref(desc), pixels.ctypes.data, width, height, frames_done, spp, seed, r0, r1, threads, render_flags)
         assert rc == 0
         return pixels
+
+    def probe_fn(self, fn, records, cam=None, params=None):
+        """include/rpt.h rpt_probe_fn's record layouts through the oracle: records [n, 32] f32 -> [n, 16] f32."""
+        A = _abi()
+        rec = np.ascontiguousarray(records, dtype=np.float32)
+        assert rec.ndim == 2 and rec.shape[1] == A.RPT_PROBE_IN_STRIDE
+        out = np.zeros((rec.shape[0], A.RPT_PROBE_OUT_STRIDE), dtype=np.float32)
+        cam = np.ascontiguousarray(cam if cam is not None else np.zeros(7), dtype=np.float32)
+        params = np.ascontiguousarray(params if params is not None else np.zeros(2), dtype=np.float32)
+        self.lib.oracle_probe_fn.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+        self.lib.oracle_probe_fn(fn, rec.ctypes.data, out.ctypes.data, rec.shape[0], cam.ctypes.data, params.ctypes.data)
+        return out
 
     def sample_pixels(self, desc, cols, rows, frames, width, height, seed=1):
         cols = np.ascontiguousarray(cols, dtype=np.uint32)
