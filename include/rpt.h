@@ -216,13 +216,12 @@ enum {
     /* Scenes with an SDF object: run the sphere march inside closest_hit / any_hit (one bounce per scheduling
      * step) instead of as a resumable scheduling state of its own.  Same image bit for bit; kept for A/B. */
     RPT_RENDER_SDF_INLINE_MARCH = 1u << 2,
-    /* Large scenes with the uniform grid: run the grid walk as a resumable scheduling state of its own (like the SDF
-     * march) instead of inside closest_hit / any_hit.  Same image bit for bit; measured SLOWER (the walk is bound by
-     * the latency of its dependent loads, not by lane utilisation: DESIGN.md 4b), kept for A/B only. */
+    /* REMOVED (accepted for source compatibility, rpt_render* return RPT_ERR_UNSUPPORTED): the grid walk of large scenes as a
+     * resumable scheduling state.  Measured slower in round 1. */
     RPT_RENDER_GRID_RESUMABLE_WALK = 1u << 3,
     /* Scenes with an SDF object: lanes submit their marches to a workgroup-wide queue in LDS that all four waves serve
      * (dev_sdf_pool.h) instead of marching their own ray.  Same image bit for bit; measured SLOWER (1.5 vs 2.2
-     * Gsamples/s: DESIGN.md 4b), kept for A/B only. */
+     * Gsamples/s: DESIGN.md 4b); only in builds with -DRPT_AB_KERNELS, otherwise RPT_ERR_UNSUPPORTED. */
     RPT_RENDER_SDF_POOL_MARCH = 1u << 4,
     /* Russian roulette (project-defined; the reference's bounce loop is a fixed `for _ in 0..depth` with three
      * early exits, tracer.rs:61-103).  After the throughput update and the next-ray set-up of bounce b (0-based),

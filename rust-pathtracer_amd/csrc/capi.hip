@@ -175,13 +175,6 @@ static uint32_t sdf_pool_shade_lanes() { static const uint32_t v = env_lanes("RP
 static uint32_t sdf_pool_resolve_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_RESOLVE_LANES", 16); return v; }
 static uint32_t sdf_pool_min_batch() { static const uint32_t v = env_lanes("RPT_SDF_POOL_MIN_BATCH", 32); return v; }
 static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_POOL_PATIENCE") ? (uint32_t)atoi(getenv("RPT_SDF_POOL_PATIENCE")) : 8u; return v; }
-static uint32_t chunks_per_block()
-{
-    static const uint32_t v = [] { const char* e = getenv("RPT_CHUNKS_PER_BLOCK"); long t = e ? strtol(e, nullptr, 10) : 4; return (uint32_t)(t < 1 ? 1 : (t > 1024 ? 1024 : t)); }();
-    return v;
-}
-static uint32_t grid_walk_min_lanes() { static const uint32_t v = env_lanes("RPT_GRID_WALK_MIN_LANES", 8); return v; }
-
 // ---- descriptor -> device tables ---------------------------------------------------------------------------
 static DevPlane dev_plane(const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; }
 static DevLight dev_light(const rpt_light& a)
@@ -323,23 +316,15 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     rp.pool_patience = sdf_pool_patience();
     rp.shade_threshold = shade_threshold();
     rp.march_min_lanes = sdf_march_min_lanes();
-    rp.walk_min_lanes = grid_walk_min_lanes();
-    rp.grid_resumable_walk = (flags & RPT_RENDER_GRID_RESUMABLE_WALK) ? 1u : 0u;
     if (flags & RPT_RENDER_RUSSIAN_ROULETTE) { scs.flags |= kSceneFlagRussianRoulette; scl.flags |= kSceneFlagRussianRoulette; }
     if (rp.rows_local == 0) return RPT_OK;
     const uint32_t tiles_y = (rp.rows_local + 15u) / 16u;
     const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;
-    rp.chunks_x = (width + 7u) / 8u;
-    const uint64_t n_chunks = (uint64_t)rp.chunks_x * ((rp.rows_local + 7u) / 8u);
-    if (nblocks > 0x7FFFFFFFull || n_chunks > 0x7FFFFFFFull) { set_err(ctx, "render: grid too large"); return RPT_ERR_INVALID_ARG; }
-    rp.n_chunks = (uint32_t)n_chunks;
-    // Chunks per workgroup strip (kernels.hip, queue_assign): one per wave; RPT_CHUNKS_PER_BLOCK overrides (tuning runs).
-    const uint32_t per_block = chunks_per_block();
-    const uint64_t queue_blocks = (n_chunks + per_block - 1u) / per_block;
-    rp.chunks_per_block = per_block;
+    if (nblocks > 0x7FFFFFFFull) { set_err(ctx, "render: grid too large"); return RPT_ERR_INVALID_ARG; }
+    if (flags & RPT_RENDER_GRID_RESUMABLE_WALK) { set_err(ctx, "render: RPT_RENDER_GRID_RESUMABLE_WALK was removed (measured slower, DESIGN.md 4b)"); return RPT_ERR_UNSUPPORTED; }
 #ifndef RPT_AB_KERNELS
-    if (flags & (RPT_RENDER_SDF_POOL_MARCH | RPT_RENDER_GRID_RESUMABLE_WALK)) {
-        set_err(ctx, "render: the A/B kernels (RPT_RENDER_SDF_POOL_MARCH, RPT_RENDER_GRID_RESUMABLE_WALK) are not in this build (-DRPT_AB_KERNELS)");
+    if (flags & RPT_RENDER_SDF_POOL_MARCH) {
+        set_err(ctx, "render: the A/B kernel RPT_RENDER_SDF_POOL_MARCH is not in this build (-DRPT_AB_KERNELS)");
         return RPT_ERR_UNSUPPORTED;
     }
 #endif
@@ -352,8 +337,8 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         const uint32_t chunk = (spp - done > max_chunk) ? max_chunk : (spp - done);
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
-        if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, (uint32_t)queue_blocks, stream));
-        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, (uint32_t)queue_blocks, stream));
+        if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
+        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
         done += chunk;
     }
     return RPT_OK;

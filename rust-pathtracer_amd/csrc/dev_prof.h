@@ -30,6 +30,8 @@ enum ProfBlock : uint32_t {
     PB_LOBE_SPEC,
     PB_SAMPLE_TAIL,    //   to_world, throughput, next ray
     PB_PASS,           // one pass of the scheduling loop (votes included)
+    PB_GRID_BEGIN,     // large scenes: DDA set-up of one grid walk
+    PB_GRID_CELL,      // large scenes: one cell of a grid walk (record tests + step + prefetch)
     PB_COUNT
 };
 

@@ -114,10 +114,7 @@ struct RenderParams {
     uint32_t spp;
     uint64_t frames_done;
     uint64_t seed;
-    uint32_t tiles_x;          // ceil(width / 16): the one-workgroup-per-tile kernels (nested loops, A/B forms)
-    uint32_t chunks_x;         // ceil(width / 8): the queue kernels' 8x8-pixel chunks
-    uint32_t n_chunks;         // chunks_x * ceil(rows_local / 8)
-    uint32_t chunks_per_block; // chunks in a workgroup's strip (default 4: one per wave)
+    uint32_t tiles_x;          // ceil(width / 16)
     uint32_t shade_threshold;  // lanes that must be waiting before a wave runs the shading block
     uint32_t march_min_lanes;      // SDF scenes: a wave keeps marching while at least this many lanes are marching
     uint32_t sdf_resumable_march;  // SDF scenes: 0 march inside closest_hit / any_hit, 1 as a scheduling state of the lane (dev_sdf_path.h),
@@ -126,8 +123,6 @@ struct RenderParams {
     uint32_t pool_resolve_lanes;
     uint32_t pool_min_batch;       // ... serves the queue when it can fill this many lanes with jobs ...
     uint32_t pool_patience;        // ... and after this many idle passes does whatever there is to do
-    uint32_t walk_min_lanes;       // grid scenes: a wave keeps walking while at least this many lanes are walking
-    uint32_t grid_resumable_walk;  // grid scenes: the DDA walk as a scheduling state (dev_grid_path.h) instead of inside closest_hit / any_hit
 };
 
 }  // namespace rptdev

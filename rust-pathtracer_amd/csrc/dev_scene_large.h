@@ -230,13 +230,15 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
         float t;
         if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; hit = true; }
     }
-    GridWalk g = grid_begin(sc, ray);
+    GridWalk g;
+    { RPT_PROF(PB_GRID_BEGIN); g = grid_begin(sc, ray); }
     // The walk is bound by the latency of its dependent loads (cell -> list bounds -> spheres), not by
     // arithmetic, so the next cell's list bounds are requested before this cell's spheres are tested.
     // A DDA crosses at most nx+ny+nz cells; the guard guarantees every wave leaves the loop.
     uint32_t k0 = 0, k1 = 0;
     if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
     for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
+        RPT_PROF(PB_GRID_CELL);
         const float t_exit = grid_cell_exit(g);                     // of the cell whose list is [k0, k1)
         grid_step(sc, g);                                           // g is the NEXT cell from here on
         uint32_t n0 = 0, n1 = 0;
@@ -258,10 +260,12 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
 RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max, float max_dist)
 {
     if (!grid_usable(sc, ray)) return brute_any_sphere(sc, ray, use_max, max_dist);
-    GridWalk g = grid_begin(sc, ray);
+    GridWalk g;
+    { RPT_PROF(PB_GRID_BEGIN); g = grid_begin(sc, ray); }
     uint32_t k0 = 0, k1 = 0;
     if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
     for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
+        RPT_PROF(PB_GRID_CELL);
         const float t_exit = grid_cell_exit(g);
         grid_step(sc, g);                                           // as in grid_closest_sphere
         uint32_t n0 = 0, n1 = 0;

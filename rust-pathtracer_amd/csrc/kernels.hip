@@ -12,7 +12,6 @@
 #include "dev_scene_large.h"
 #ifdef RPT_AB_KERNELS                 // measured-slower kernel forms kept for A/B runs only; not in the shipped library
 #include "ab/dev_sdf_pool.h"
-#include "ab/dev_grid_path.h"
 #endif
 #include "launch.h"
 
@@ -106,14 +105,9 @@ __global__ __launch_bounds__(256) void RPT_K(render_large_nested_kernel)(const S
 __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(sc, rp); }
 
 // The production megakernel.  Same arithmetic per sample, different schedule:
-//  * PIXELS FROM A WORKGROUP QUEUE.  A workgroup owns a strip of `chunks_per_block` consecutive 8x8-pixel chunks; its four
-//    waves pull chunks from a counter in LDS and hand their pixels to their lanes.  A lane runs its pixel's samples as a
-//    state machine (dev_integrator.h, PathRegs): when a path ends it blends the sample into the pixel's running mean and
-//    starts the next camera path at once, and when the PIXEL is finished it stores the mean and takes the next pixel of
-//    the wave's chunk in the same pass (path regeneration across samples AND pixels).  The strip is one chunk per wave
-//    by default (a wave then stays on one 8x8 tile, whose paths hit the same materials: measured, mixing tiles in a wave
-//    costs 12 % at 256 spp); longer strips (RPT_CHUNKS_PER_BLOCK) pay only on frames with far more chunks than the chip
-//    has wave slots, and then little (+2 % at one sample per pixel: DESIGN.md 4);
+//  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
+//    PathRegs); when its path ends it blends the sample into its running mean and starts
+//    the next camera path at once (path regeneration);
 //  * a bounce is split into TRACE (the geometry pass of closest_hit + the miss / emitter exits:
 //    what every ray needs) and SHADE (normal, material layering, State::finalize, next-event
 //    estimation, Disney BSDF sampling: what only a surface hit needs, ~5x the instructions).  A lane
@@ -132,7 +126,7 @@ constexpr uint32_t kMaxSppPerLaunch = 512;
 #define RPT_SDF_WAVES_PER_SIMD 5
 #endif
 
-// What the state-machine kernels below share: per-launch tables and cold per-lane state in LDS.
+// What the three state-machine kernels below share: per-launch tables and cold per-lane state in LDS.
 // The per-sample frame key and blend weight 1/(frames+1) are per-lane values there (lanes drift apart in sample
 // index), so the workgroup stages them once.  The pixel's running mean and its constants are touched only when a
 // sample ends (once per ~2 bounces); in VGPRs the seven registers they would pin are what separates 4 from 5
@@ -140,11 +134,13 @@ constexpr uint32_t kMaxSppPerLaunch = 512;
 struct LaneTables {
     uint32_t* fkey;            // [kMaxSppPerLaunch] frame_key(seed, frames_done + s)
     float* weight;             // [kMaxSppPerLaunch] 1 / (frames_done + s + 1), tracer.rs:115
-    float4* acc;               // [256] running mean of the lane's current pixel, tracer.rs:105-117
-    float4* pix;               // [256] {coord.x, coord.y, bits(pixel_index), bits(offset of the pixel in the tile buffer)}
+    float4* acc;               // [256] running mean, tracer.rs:105-117
+    float4* pix;               // [256] {coord.x, coord.y, bits(pixel_index), -}
 };
 
-RPT_DEV void fill_sample_tables(const LaneTables& lt, const RenderParams& rp)
+// Fills the tables and this lane's slots.  False: the lane has no pixel, or the scene has max_depth == 0 (no bounce
+// loop at all: every sample's radiance is zero and the lane's pixel is finished here) — the caller returns.
+RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderParams& rp)
 {
     for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
         const uint64_t frames = rp.frames_done + i;
@@ -152,76 +148,21 @@ RPT_DEV void fill_sample_tables(const LaneTables& lt, const RenderParams& rp)
         lt.weight[i] = 1.0f / (float)(frames + 1);                  // tracer.rs:115
     }
     __syncthreads();
-}
-
-// The wave's share of the workgroup's pixel queue (all wave-uniform): the chunk being handed out and how far it is used up.
-struct WaveQueue {
-    uint32_t tile;             // 8x8 tile of the current chunk
-    uint32_t slot;             // next unassigned pixel of it; 64 = used up
-    bool exhausted;            // the workgroup's strip has no chunk left
-};
-
-// The lane's pixel `k` of 8x8 tile `tile`: fills its `lt.pix` slot and starts the load of the stored running mean.
-// False: the pixel is outside the image (edge tile).
-RPT_DEV bool pixel_take(uint32_t tile, uint32_t k, const LaneTables& lt, const RenderParams& rp, float4& pend)
-{
-    const uint32_t tx = tile % rp.chunks_x, ty = tile / rp.chunks_x;
-    const uint32_t col = tx * 8u + (k & 7u);
-    const uint32_t lrow = ty * 8u + (k >> 3);
-    if (col >= rp.width || lrow >= rp.rows_local) return false;
-    const uint32_t grow = tile_global_row(lrow, rp.tile_rows, rp.rank, rp.world);
-    // tracer.rs:34-46; j counts rows from the bottom (par_rchunks, tracer.rs:29-37)
-    const float W = (float)rp.width;
-    const float H = (float)rp.height;
-    const uint32_t j = rp.height - 1u - grow;
-    const float x = (float)col;
-    const float y = H - (float)j;
-    const float xx = x / W;
-    const float yy = y / H;
-    const uint32_t off = lrow * rp.width + col;
-    lt.pix[threadIdx.x] = make_float4(xx, 1.0f - yy, rpt_u2f(grow * rp.width + col), rpt_u2f(off));
-    pend = reinterpret_cast<const float4*>(rp.pixels)[off];
+    const PixelSetup ps = pixel_setup(rp);
+    if (!ps.valid) return false;
+    float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
+    if (max_depth == 0) {
+        float4 acc = *pixel;
+        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), lt.weight[s]);
+        *pixel = acc;
+        return false;
+    }
+    lt.acc[threadIdx.x] = *pixel;
+    lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
     return true;
 }
 
-// Hands pixels to the lanes with `need` set, as far as the wave's current chunk reaches (the others ask again in the
-// next pass, after a new chunk has been pulled).  Returns 1 for a lane that got a pixel (`lt.pix` slot filled, `pend` =
-// the pixel's running mean as stored, still in flight), 2 when there is no work left for it, 0 when it has to ask again.
-// The workgroup owns a strip of rp.chunks_per_block consecutive 8x8 chunks; its waves pull chunks from `next_chunk` (a
-// counter in LDS, one atomic per wave per chunk).
-//
-// Measured and dropped: a PERSISTENT launch (one wave per wave slot of the chip) pulling chunks from a
-// device-wide counter — 0.88x at 256 spp (a wave mixes tiles, whose paths hit different materials) and 0.67x at 1 spp
-// (32 400 pulls in 0.35 ms saturate one atomic word) — and the same launch with a static, atomic-free deal of the
-// pixels (lane gid takes pixels gid, gid + L, ...): 0.37x-0.72x.
-RPT_DEV uint32_t queue_assign(WaveQueue& q, uint32_t* next_chunk, const LaneTables& lt, const RenderParams& rp, bool need, float4& pend)
-{
-    const uint64_t m_need = __ballot(need);
-    if (m_need == 0ull) return 0u;
-    const uint32_t lane = threadIdx.x & 63u;
-    if (q.slot >= 64u && !q.exhausted) {                            // pull the next chunk of the strip
-        uint32_t k = 0u;
-        if (lane == 0u) k = atomicAdd(next_chunk, 1u);
-        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-        const uint32_t c = blockIdx.x * rp.chunks_per_block + k;
-        q.exhausted = (k >= rp.chunks_per_block) || (c >= rp.n_chunks);
-        // bottom rows first: in the usual outdoor framing they are the expensive ones, so the cheap sky chunks fill the tail
-        q.tile = q.exhausted ? 0u : rp.n_chunks - 1u - c;
-        q.slot = q.exhausted ? 64u : 0u;
-    }
-    if (q.exhausted) return need ? 2u : 0u;
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_need, 0u));
-    const uint32_t avail = 64u - q.slot;
-    const uint32_t n = (uint32_t)__popcll(m_need);
-    const bool served = need && rank < avail;
-    const uint32_t k = q.slot + rank;                               // this lane's pixel of the chunk: 8 x 8, row-major
-    const uint32_t tile = q.tile;
-    q.slot += n < avail ? n : avail;
-    if (!served) return 0u;
-    return pixel_take(tile, k, lt, rp, pend) ? 1u : 0u;             // 0: outside the image (edge chunk), ask again
-}
-
-enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u, ST_NEED = 4u };
+enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u };
 
 template <class S>
 RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
@@ -231,63 +172,43 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
-    __shared__ uint32_t s_next_chunk;
     const uint32_t tid = threadIdx.x;
-    const LaneTables lt{s_fkey, s_weight, s_acc, s_pix};
-    if (tid == 0u) s_next_chunk = 0u;
-    fill_sample_tables(lt, rp);                                     // (has the barrier)
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
 
-    WaveQueue q{0u, 64u, false};
     uint32_t s = 0;
-    uint32_t state = ST_NEED;
-    bool fresh = false;                                             // the pixel's stored mean is still in `pend`, not yet in LDS
-    float4 pend = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t state = ST_TRACE;
     PathRegs p;
     GeomHit g;                                                      // what a lane waiting for SHADE parks: one dword
     g.code = 0u;
+    {
+        const float4 c = s_pix[tid];
+        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+    }
 
     for (;;) {
         RPT_PROF(PB_PASS);
         if (state == ST_FINISH) {
-            // blend the finished sample into the running mean and start the next one (or finish the pixel); one site
-            // for the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
+            // blend the finished sample into the running mean and start the next one (or retire); one site for
+            // the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
             RPT_PROF(PB_FINISH);
             float4 acc = s_acc[tid];
             blend(acc, p.radiance, s_weight[s]);
+            s_acc[tid] = acc;
             s += 1;
             if (s >= rp.spp) {
-                reinterpret_cast<float4*>(rp.pixels)[rpt_f2u(s_pix[tid].w)] = acc;
-                state = ST_NEED;
+                state = ST_DONE;
             } else {
-                s_acc[tid] = acc;
                 const float4 c = s_pix[tid];
                 path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
                 state = ST_TRACE;
-            }
-        }
-        {
-            const uint32_t got = queue_assign(q, &s_next_chunk, lt, rp, state == ST_NEED, pend);
-            if (got == 1u) {
-                const float4 c = s_pix[tid];
-                s = 0;
-                fresh = true;
-                path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
-                // max_depth == 0: no bounce loop at all (tracer.rs:61), every sample's radiance is zero
-                state = (sc.max_depth == 0u) ? ST_FINISH : ST_TRACE;
-            } else if (got == 2u) {
-                state = ST_DONE;
             }
         }
         if (state == ST_TRACE) {
             RPT_PROF(PB_TRACE);
             state = path_trace_geom(sc, DirectQuery{}, p, g) ? ST_SHADE : ST_FINISH;
         }
-        if (fresh) {                                                // the new pixel's mean has had the TRACE block to arrive
-            s_acc[tid] = pend;
-            fresh = false;
-        }
         const uint64_t m_shade = __ballot(state == ST_SHADE);
-        const uint64_t m_go = __ballot(state == ST_TRACE || state == ST_FINISH || state == ST_NEED);
+        const uint64_t m_go = __ballot(state == ST_TRACE || state == ST_FINISH);
         if ((m_shade | m_go) == 0ull) break;
         if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_go == 0ull) {
             if (state == ST_SHADE) {
@@ -297,6 +218,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
         }
     }
     RPT_PROF_FLUSH();
+    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
 }
 
 #ifndef RPT_SMALL_WAVES_PER_SIMD
@@ -331,7 +253,7 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_rege
 // Measured on configs[3] (MI355X): min lanes 1: 1.81, 2: 2.11, 4: 2.28, 8: 2.31, 16: 2.01, 32: 1.63
 // Gsamples/s; the bounce-granular kernel: 1.97.  (A policy with RESOLVE/SHADE waiting rooms that fire when
 // 24 lanes wait, as in the regeneration kernel, is slower than bounce-granular: three rooms dilute 64 lanes.)
-enum : uint32_t { SM_MARCH_P = 0u, SM_MARCH_S = 1u, SM_RESOLVE = 2u, SM_SHADE = 3u, SM_DONE = 4u, SM_FINISH = 5u, SM_NEED = 6u };
+enum : uint32_t { SM_MARCH_P = 0u, SM_MARCH_S = 1u, SM_RESOLVE = 2u, SM_SHADE = 3u, SM_DONE = 4u, SM_FINISH = 5u };
 
 RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& rp)
 {
@@ -341,62 +263,43 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
     __shared__ float4 s_hit[256];                                   // parked hit point (the shadow march borrows p.ray.o)
-    __shared__ uint32_t s_next_chunk;
     const uint32_t tid = threadIdx.x;
-    const LaneTables lt{s_fkey, s_weight, s_acc, s_pix};
-    if (tid == 0u) s_next_chunk = 0u;
-    fill_sample_tables(lt, rp);                                     // (has the barrier)
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
 
-    WaveQueue qu{0u, 64u, false};                                   // pixels come from the queue, as in render_regen_body
     uint32_t s = 0;
-    uint32_t state = SM_NEED;
+    uint32_t state = SM_MARCH_P;
     PathRegs p;
     GeomHit g;                                                      // what a lane parks between RESOLVE and SHADE: the accepted
     g.code = 0u;                                                    // mask, the normal (RESOLVE needs it for the shadow ray) and,
     v3 normal = mk3(0.0f, 0.0f, 0.0f);                              // in LDS, the hit point
     MarchRegs m;
-    m.t = 0.0f; m.t_useful = 0.0f; m.steps = 0u; m.accepted = 0u; m.hit = false; m.d = mk3(0.0f, 0.0f, 0.0f);
+    {
+        const float4 c = s_pix[tid];
+        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        march_begin_primary(sc, p, m);
+    }
 
     for (;;) {
         RPT_PROF(PB_PASS);
-        if (state == SM_FINISH) {                                   // blend, next sample of the pixel (or the next pixel)
+        if (state == SM_FINISH) {                                   // blend, next sample of the pixel (or retire)
             RPT_PROF(PB_FINISH);
             float4 acc = s_acc[tid];
             blend(acc, p.radiance, s_weight[s]);
+            s_acc[tid] = acc;
             s += 1;
             if (s >= rp.spp) {
-                reinterpret_cast<float4*>(rp.pixels)[rpt_f2u(s_pix[tid].w)] = acc;
-                state = SM_NEED;
+                state = SM_DONE;
             } else {
-                s_acc[tid] = acc;
                 const float4 c = s_pix[tid];
                 path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
                 march_begin_primary(sc, p, m);
                 state = SM_MARCH_P;
             }
         }
-        {
-            float4 pend;
-            const uint32_t got = queue_assign(qu, &s_next_chunk, lt, rp, state == SM_NEED, pend);
-            if (got == 1u) {
-                s_acc[tid] = pend;                                  // (the march kernels wait for the pixel here: a pixel lasts 64 samples in configs[3])
-                const float4 c = s_pix[tid];
-                s = 0;
-                path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
-                if (sc.max_depth == 0u) state = SM_FINISH;          // no bounce loop at all (tracer.rs:61)
-                else { march_begin_primary(sc, p, m); state = SM_MARCH_P; }
-            } else if (got == 2u) {
-                state = SM_DONE;
-            }
-        }
         const uint64_t w_march = __ballot(state <= SM_MARCH_S);
         const uint32_t n_resolve = (uint32_t)__popcll(__ballot(state == SM_RESOLVE));
         const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == SM_SHADE));
-        const uint64_t w_turn = __ballot(state == SM_FINISH || state == SM_NEED);   // lanes whose next step is the top of the loop
-        if (w_march == 0ull && n_resolve == 0u && n_shade == 0u) {
-            if (w_turn == 0ull) break;
-            continue;
-        }
+        if (w_march == 0ull && n_resolve == 0u && n_shade == 0u) break;
 
         const uint32_t n_march = (uint32_t)__popcll(w_march);
         const bool waiting = (n_resolve | n_shade) != 0u;
@@ -439,31 +342,12 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
         }
     }
     RPT_PROF_FLUSH();
+    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
 }
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
 
 #ifdef RPT_AB_KERNELS
-// The A/B kernels keep the first design's mapping: one lane per pixel of a 16x16 tile, a launch of one workgroup per tile.
-// Fills the tables and this lane's slots.  False: the lane has no pixel, or the scene has max_depth == 0 (no bounce
-// loop at all: every sample's radiance is zero and the lane's pixel is finished here) — the caller returns.
-RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderParams& rp)
-{
-    fill_sample_tables(lt, rp);
-    const PixelSetup ps = pixel_setup(rp);
-    if (!ps.valid) return false;
-    float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
-    if (max_depth == 0) {
-        float4 acc = *pixel;
-        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), lt.weight[s]);
-        *pixel = acc;
-        return false;
-    }
-    lt.acc[threadIdx.x] = *pixel;
-    lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
-    return true;
-}
-
 // SDF scenes, workgroup-wide march pool (dev_sdf_pool.h): the lane states are those of the march kernel above, but a
 // lane in MARCH_P / MARCH_S has SUBMITTED its march and only polls for the answer; the marching itself is done by
 // whichever lanes of the workgroup are serving the queue.  Per pass a wave either runs one of its own blocks — when
@@ -601,87 +485,6 @@ RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& r
 }
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_pool_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_pool_body(sc, rp); }
-
-// Large scenes with the uniform grid, resumable walk (dev_grid_path.h).  Per lane:
-//   WALK_P --(walk over)--> RESOLVE --(miss / emitter)--> FINISH: next sample, WALK_P
-//                                   --(surface)--> WALK_S --(walk over)--> SHADE --> WALK_P / FINISH
-//                                   --(no shadow walk needed)-----------> SHADE
-// Per wave, each pass runs ONE block for the lanes waiting at it: walk steps (one cell per lane per step, primary and
-// shadow walks together) while at least `walk_min_lanes` lanes are walking or nobody waits elsewhere; otherwise the
-// fuller of RESOLVE / SHADE, whose lanes then start new walks next to the stragglers.
-enum : uint32_t { GW_WALK_P = 0u, GW_WALK_S = 1u, GW_RESOLVE = 2u, GW_SHADE = 3u, GW_FINISH = 4u, GW_DONE = 5u };
-
-RPT_DEV void render_large_walk_body(const SceneLarge& sc, const RenderParams& rp)
-{
-    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
-    __shared__ float s_weight[kMaxSppPerLaunch];
-    __shared__ float4 s_acc[256];
-    __shared__ float4 s_pix[256];
-    const uint32_t tid = threadIdx.x;
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
-
-    uint32_t s = 0;
-    uint32_t state;
-    PathRegs p;
-    GeomHit g;
-    g.code = 0u;
-    WalkRegs w;
-    {
-        const float4 c = s_pix[tid];
-        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
-        state = walk_begin_closest(sc, p.ray, w) ? GW_RESOLVE : GW_WALK_P;
-    }
-
-    for (;;) {
-        if (state == GW_FINISH) {                                   // blend, next sample of the pixel (or retire)
-            float4 acc = s_acc[tid];
-            blend(acc, p.radiance, s_weight[s]);
-            s_acc[tid] = acc;
-            s += 1;
-            if (s >= rp.spp) {
-                state = GW_DONE;
-            } else {
-                const float4 c = s_pix[tid];
-                path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
-                state = walk_begin_closest(sc, p.ray, w) ? GW_RESOLVE : GW_WALK_P;
-            }
-        }
-        const uint32_t n_walk = (uint32_t)__popcll(__ballot(state <= GW_WALK_S));
-        const uint32_t n_resolve = (uint32_t)__popcll(__ballot(state == GW_RESOLVE));
-        const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == GW_SHADE));
-        if (n_walk == 0u && n_resolve == 0u && n_shade == 0u) break;
-
-        const bool waiting = (n_resolve | n_shade) != 0u;
-        if (n_walk >= rp.walk_min_lanes || !waiting) {
-            // walk until too few lanes are left walking (and somebody waits) or nobody walks
-            for (;;) {
-                if (state <= GW_WALK_S) {
-                    if (walk_step(sc, w, state == GW_WALK_S)) state = (state == GW_WALK_P) ? GW_RESOLVE : GW_SHADE;
-                }
-                const uint32_t left = (uint32_t)__popcll(__ballot(state <= GW_WALK_S));
-                if (left == 0u || left < rp.walk_min_lanes) break;
-            }
-        } else if (n_shade >= n_resolve) {
-            if (state == GW_SHADE) {
-                const GridInjectedQuery q{0.0f, 0u, false, w.hit};
-                if (path_shade_full(sc, q, p, g)) state = GW_FINISH;
-                else state = walk_begin_closest(sc, p.ray, w) ? GW_RESOLVE : GW_WALK_P;
-            }
-        } else {
-            if (state == GW_RESOLVE) {
-                const GridInjectedQuery q{w.dist, w.best, w.hit, false};
-                if (path_trace_geom(sc, q, p, g)) state = walk_begin_shadow(sc, p, g, w) ? GW_WALK_S : GW_SHADE;
-                else state = GW_FINISH;
-            }
-        }
-    }
-    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
-}
-
-#ifndef RPT_WALK_WAVES_PER_SIMD
-#define RPT_WALK_WAVES_PER_SIMD 5
-#endif
-__global__ __launch_bounds__(256, RPT_WALK_WAVES_PER_SIMD) void RPT_K(render_large_walk_kernel)(const SceneLarge sc, const RenderParams rp) { render_large_walk_body(sc, rp); }
 
 #endif  // RPT_AB_KERNELS
 
@@ -885,42 +688,28 @@ namespace RPT_LAUNCH_NS {
 
 uint32_t max_spp_per_launch() { return kMaxSppPerLaunch; }
 
-hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, bool nested, const RenderParams& rp, uint32_t nblocks_tiles,
-                  uint32_t nblocks_queue, hipStream_t st)
+hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, bool nested, const RenderParams& rp, uint32_t nblocks, hipStream_t st)
 {
     const bool has_sdf = !large && scs.sdf.n_prims > 0;
     const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
-    const dim3 tiles(nblocks_tiles), persistent(nblocks_queue), wg(256);
+    const dim3 tiles(nblocks), wg(256);
     (void)hipGetLastError();                                         // the thread's sticky error may be somebody else's (a host process's own HIP calls)
     if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), tiles, wg, 0, st, scl, rp);
-#ifdef RPT_AB_KERNELS
-    else if (large && scl.use_accel && rp.grid_resumable_walk) hipLaunchKernelGGL(RPT_K(render_large_walk_kernel), tiles, wg, 0, st, scl, rp);
-    else if (has_sdf && !nested && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), tiles, wg, 0, st, scs, rp);
-#endif
-    else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), persistent, wg, 0, st, scl, rp);
+    else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), tiles, wg, 0, st, scl, rp);
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), tiles, wg, 0, st, scs, rp);
-    else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), persistent, wg, 0, st, scs, rp);
-    else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), persistent, wg, 0, st, scs, rp);
+#ifdef RPT_AB_KERNELS
+    else if (has_sdf && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), tiles, wg, 0, st, scs, rp);
+#endif
+    else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), tiles, wg, 0, st, scs, rp);
+    else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), tiles, wg, 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
     else {
         // RPT_DEBUG_EXTRA_LDS (bytes, experiments only): pads the workgroup's LDS so that fewer waves fit a CU — how the
         // kernel's throughput depends on resident waves per SIMD (occupancy sensitivity)
         static const unsigned extra_lds = getenv("RPT_DEBUG_EXTRA_LDS") ? (unsigned)atoi(getenv("RPT_DEBUG_EXTRA_LDS")) : 0u;
-        hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), persistent, wg, extra_lds, st, sc, rp);
+        hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, extra_lds, st, sc, rp);
     }
     return hipGetLastError();
-}
-
-// true: the kernel this (scene, flags) selects pulls its pixels from workgroup queues (a launch of nblocks_queue workgroups)
-bool uses_queue(bool large, bool has_sdf, bool nested, const RenderParams& rp)
-{
-    if (nested) return false;
-#ifdef RPT_AB_KERNELS
-    if (large && rp.grid_resumable_walk) return false;
-    if (has_sdf && rp.sdf_resumable_march == 2u) return false;
-#endif
-    (void)large; (void)has_sdf; (void)rp;
-    return true;
 }
 
 hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,

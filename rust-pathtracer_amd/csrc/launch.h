@@ -35,12 +35,10 @@ namespace rptlaunch {
 
 uint32_t max_spp_per_launch();      // samples one launch of the regenerating kernel can hold in its LDS tables
 
-// One launch of the megakernel: picks the instantiation (small / SDF / large, regenerating or nested) from the scene.
-// The regenerating kernels run `nblocks_queue` workgroups, each pulling the 8x8-pixel chunks of its strip (rp.chunks_per_block)
-// from a counter in LDS; the nested-loop A/B kernels run one workgroup per 16x16 tile (`nblocks_tiles`).
+// One launch of the megakernel on `nblocks` 16x16 tiles: picks the instantiation (small / SDF / large,
+// regenerating or nested) from the scene.
 hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks_tiles, uint32_t nblocks_queue, hipStream_t st);
-bool uses_queue(bool large, bool has_sdf, bool nested, const rptdev::RenderParams& rp);
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st);
 hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
                   uint32_t rows_padded, hipStream_t st);
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st);
@@ -55,5 +53,5 @@ hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t*
 // the relaxed-arithmetic build of the same kernels (kernels_fast.hip)
 namespace rptlaunch_fast {
 hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks_tiles, uint32_t nblocks_queue, hipStream_t st);
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st);
 }  // namespace rptlaunch_fast

@@ -215,4 +215,4 @@ def test_probe_disney_sample(rpt, oracle, torch_cuda, tracer):
     assert_bit_identical(got, want, "disney_sample")
     assert set(np.unique(want[:, 7])) <= {2.0, 3.0} and (want[:, 7] == 3.0).mean() > 0.1   # 2 draws, 3 in the specular arm
     dead = eta_one & (rec[:, 13] == 0.0)                                 # ... when there is no clearcoat lobe either
-    assert dead.sum() > 100 and np.isnan(want[dead][:, 6]).all()
+    assert dead.sum() > 100 and np.isnan(want[dead][:, 6]).mean() > 0.3    # the unguarded 0/0 cases are there (and bit-identical above)

@@ -12,7 +12,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 PKG = os.path.join(ROOT, "rust-pathtracer_amd")
 PROF_LIB = os.path.join(PKG, "librpt_hip_prof.so")
 BLOCKS = ["TRACE", "  closest_hit", "  background", "  finalize", "  finish+camera", "SHADE", "  make_frame", "  nee_sample", "  any_hit",
-          "  disney_eval", "  disney_sample", "    lobe diffuse", "    lobe clearcoat", "    lobe spec", "  tail", "PASS"]
+          "  disney_eval", "  disney_sample", "    lobe diffuse", "    lobe clearcoat", "    lobe spec", "  tail", "PASS", "    grid begin", "    grid cell"]
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     spec = importlib.util.spec_from_file_location("_rpt_build", os.path.join(PKG, "build.py"))
@@ -50,7 +50,7 @@ e0.record(); t.render_n(buf, spp); e1.record(); torch.cuda.synchronize()
 assert lib.rpt_prof_read(out) == 0
 n_samples = w * h * spp
 print("profiled build, %s: %dx%d x %d spp in %.2f ms (%.0f Msamples/s with the counters on)" % (which, w, h, spp, e0.elapsed_time(e1), n_samples / e0.elapsed_time(e1) / 1e3))
-pass_cycles = out[(len(BLOCKS) - 1) * 3 + 2]
+pass_cycles = out[BLOCKS.index("PASS") * 3 + 2]
 print("%-20s %12s %9s %8s %10s %12s" % ("block", "wave execs", "lanes/64", "share", "execs/smp", "lane-exec/smp"))
 for i, name in enumerate(BLOCKS):
     ex, ln, cy = out[i * 3], out[i * 3 + 1], out[i * 3 + 2]

@@ -1,0 +1,25 @@
+"""Build experiment variants of librpt_hip.so side by side (rust-pathtracer_amd/variants/<name>.so), for A/B timing in ONE
+gpurun call (tools/run_variants.sh selects each through RPT_LIB).  Each entry: name -> extra hipcc flags."""
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("b", os.path.join(ROOT, "rust-pathtracer_amd", "build.py"))
+b = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(b)
+
+VARIANTS = {
+    "base": [],
+    "w4": ["-DRPT_SMALL_WAVES_PER_SIMD=4"],
+    "w6": ["-DRPT_SMALL_WAVES_PER_SIMD=6"],
+    "w8": ["-DRPT_SMALL_WAVES_PER_SIMD=8"],
+}
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(VARIANTS)
+    for n in names:
+        flags = VARIANTS[n] if n in VARIANTS else []
+        lib = os.path.join(ROOT, "rust-pathtracer_amd", "variants", n + ".so")
+        b.build(force=True, extra_flags=flags, lib=lib, objdir_name="build_" + n)
+        print("built", lib)

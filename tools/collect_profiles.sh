@@ -1,34 +1,39 @@
 #!/bin/bash
-# Collect the rocprofv3 evidence for bench.py's N=1 line on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh <variant>     -> gpurun_out/prof_<variant>/*.csv  (copy into profiles/<round>/<variant>/)
-# One --kernel-trace --stats pass of the default bench command, then separate --pmc passes (FETCH_SIZE and WRITE_SIZE
-# never together; SQ counters in two groups), as MI355X_MICROARCH.md prescribes.
+# Collect the rocprofv3 evidence for one command on the GPU box (run through gpurun from the repo root):
+#   bash tools/collect_profiles.sh <variant> [program args...]     -> gpurun_out/prof_<variant>/*.csv
+# Default program: bench.py's N=1 line (the command whose summaries go to profiles/<round>/c2_bench/).  Another
+# program (e.g. `tools/c4_run.py c5`) is given after the variant; it is run as `python3 <program args>` so that the
+# profiler's child is the interpreter itself (no shell or env hop after `--`).
+# One --kernel-trace --stats pass, then separate --pmc passes (FETCH_SIZE and WRITE_SIZE never together; SQ counters
+# in groups of 8), as MI355X_MICROARCH.md prescribes.  Copy what is to be judged into profiles/.
 set -e
-V=${1:-current}
+V=${1:-current}; shift || true
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$V
 mkdir -p $OUT
+if [ $# -gt 0 ]; then PROG=("$@"); STATS_PROG=("$@"); KPAT=${RPT_PROFILE_KERNEL:-render_};
+else PROG=(bench.py --steps 2 --warmup 1 --no-cpu-baseline); STATS_PROG=(bench.py --steps 10 --warmup 2 --no-cpu-baseline); KPAT=render_small; fi
 cd /tmp && export TMPDIR=/tmp
 run() {   # name, rocprof args...
     local name=$1; shift
     rm -rf /tmp/rp_$name
-    rocprofv3 "$@" --output-format csv -d /tmp/rp_$name -o out -- python3 $REPO/bench.py $BENCH_ARGS --no-cpu-baseline > $OUT/$name.log 2>&1
+    if [ $name = stats ]; then rocprofv3 "$@" --output-format csv -d /tmp/rp_$name -o out -- python3 $REPO/${STATS_PROG[0]} "${STATS_PROG[@]:1}" > $OUT/$name.log 2>&1
+    else rocprofv3 "$@" --output-format csv -d /tmp/rp_$name -o out -- python3 $REPO/${PROG[0]} "${PROG[@]:1}" > $OUT/$name.log 2>&1; fi
     echo "pass $name done"
 }
-BENCH_ARGS="--steps 10 --warmup 2" run stats --kernel-trace --stats
-cp $(find /tmp/rp_stats -name '*kernel_stats.csv' | head -1) $OUT/bench_n1_kernel_stats.csv
-cp $(find /tmp/rp_stats -name '*domain_stats.csv' | head -1) $OUT/bench_n1_domain_stats.csv || true
-BENCH_ARGS="--steps 2 --warmup 1"
+run stats --kernel-trace --stats
+cp $(find /tmp/rp_stats -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
 run fetch --kernel-trace --pmc FETCH_SIZE
-cp $(find /tmp/rp_fetch -name '*counter_collection.csv' | head -1) $OUT/bench_n1_pmc_FETCH_SIZE.csv
+cp $(find /tmp/rp_fetch -name '*counter_collection.csv' | head -1) $OUT/pmc_FETCH_SIZE.csv
 run write --kernel-trace --pmc WRITE_SIZE
-cp $(find /tmp/rp_write -name '*counter_collection.csv' | head -1) $OUT/bench_n1_pmc_WRITE_SIZE.csv
+cp $(find /tmp/rp_write -name '*counter_collection.csv' | head -1) $OUT/pmc_WRITE_SIZE.csv
 run sq1 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VMEM SQ_WAIT_ANY
-cp $(find /tmp/rp_sq1 -name '*counter_collection.csv' | head -1) $OUT/bench_n1_pmc_SQ_ACTIVE_.csv
+cp $(find /tmp/rp_sq1 -name '*counter_collection.csv' | head -1) $OUT/pmc_sq1.csv
 run sq2 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAVES SQ_WAVE_CYCLES
-cp $(find /tmp/rp_sq2 -name '*counter_collection.csv' | head -1) $OUT/bench_n1_pmc_SQ_WAVESS.csv
+cp $(find /tmp/rp_sq2 -name '*counter_collection.csv' | head -1) $OUT/pmc_sq2.csv
+run sq3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64
+cp $(find /tmp/rp_sq3 -name '*counter_collection.csv' | head -1) $OUT/pmc_sq3.csv
+run sq4 --kernel-trace --pmc SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAIT_INST_LDS SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE
+cp $(find /tmp/rp_sq4 -name '*counter_collection.csv' | head -1) $OUT/pmc_sq4.csv
 cd $REPO
-python3 tools/make_traffic_json.py $OUT
-for f in $OUT/bench_n1_pmc_SQ_*.csv; do python3 tools/pmc_summary.py $f render_small; done
-head -3 $OUT/bench_n1_kernel_stats.csv
-tail -1 $OUT/stats.log
+python3 tools/pmc_summary.py $OUT $KPAT | tee $OUT/summary.txt

@@ -1,12 +1,53 @@
-"""Summarise rocprofv3 counter_collection.csv for kernels matching a substring."""
+"""Summarise a tools/collect_profiles.sh output directory for the kernels matching a substring: the last dispatch's
+counters, the derived figures DESIGN.md quotes (lane utilisation, waves per SIMD, HBM bytes per launch with the gfx950
+FETCH_SIZE correction of MI355X_MICROARCH.md, instruction mix), and traffic.json."""
 import collections
 import csv
+import glob
+import json
+import os
 import sys
 
-f, pat = sys.argv[1], sys.argv[2]
-d = collections.defaultdict(list)
-for r in csv.DictReader(open(f)):
-    if pat in r["Kernel_Name"]:
-        d[r["Counter_Name"]].append(float(r["Counter_Value"]))
-for k, v in sorted(d.items()):
-    print("%-28s n=%d last=%.4g" % (k, len(v), v[-1]))
+d, pat = sys.argv[1], sys.argv[2]
+vals, kernels = {}, collections.Counter()
+for f in sorted(glob.glob(os.path.join(d, "pmc_*.csv"))):
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if pat in r["Kernel_Name"]:
+            per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kernels[r["Kernel_Name"].split("(")[0]] += 1
+    for k, v in per.items():
+        vals[k] = v[-1]
+print("kernels matched:", ", ".join(sorted(kernels)))
+for k in sorted(vals):
+    print("%-28s %.5g" % (k, vals[k]))
+g = vals.get
+if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"):
+    print("VALU lane utilisation        %.1f %%" % (100.0 * g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))))
+if g("SQ_WAVE_CYCLES") and g("GRBM_GUI_ACTIVE"):
+    print("waves resident per SIMD      %.2f" % (4.0 * g("SQ_WAVE_CYCLES") / (g("GRBM_GUI_ACTIVE") / 8.0 * 1024.0)))
+if g("SQ_WAVE_CYCLES"):
+    for name, key in (("issuing", "SQ_ACTIVE_INST_ANY"), ("issue-stalled", "SQ_WAIT_INST_ANY"), ("waiting (s_waitcnt)", "SQ_WAIT_ANY")):
+        if g(key):
+            print("wave time %-18s %.1f %%" % (name, 100.0 * g(key) / g("SQ_WAVE_CYCLES")))
+if g("SQ_INSTS_VALU"):
+    tot = g("SQ_INSTS_VALU")
+    known = 0.0
+    for key in ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT",
+                "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"):
+        if g(key) is not None:
+            known += g(key)
+            print("  %-26s %5.1f %% of VALU instructions" % (key[14:], 100.0 * g(key) / tot))
+    print("  %-26s %5.1f %% (moves, selects, compares, ...)" % ("other", 100.0 * (tot - known) / tot))
+if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+    out = {"kernels": sorted(kernels), "FETCH_SIZE_KiB": g("FETCH_SIZE"), "WRITE_SIZE_KiB": g("WRITE_SIZE"),
+           "hbm_bytes_per_launch": g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE") * 1024,
+           "correction": "FETCH_SIZE x2 (gfx950 half-count of 16 B/lane reads; uncalibrated for this kernel's 128-B row segments), WRITE_SIZE x1",
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh)"}
+    json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
+    print("HBM bytes per launch         %.4g (2 x FETCH + WRITE)" % out["hbm_bytes_per_launch"])
+ks = os.path.join(d, "kernel_stats.csv")
+if os.path.exists(ks):
+    for r in csv.DictReader(open(ks)):
+        if pat in r["Name"]:
+            print("kernel_stats: %s calls=%s avg=%.3f ms" % (r["Name"].split("(")[0], r["Calls"], float(r["AverageNs"]) / 1e6))
