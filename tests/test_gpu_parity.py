@@ -559,6 +559,37 @@ def test_full_size_config5_frame(rpt, torch_cuda, oracle):
     t.close()
 
 
+def test_full_config5_all_512_spp_pixels_match_oracle(rpt, torch_cuda, oracle):
+    """BASELINE.json configs[4] in FULL: 10 000 spheres + 16 lights, 4096x4096, all 512 spp (8.6 G samples, one launch
+    sequence).  The oracle cannot brute-force whole rows of that in test time, so it recomputes 512 pixels spread over the
+    frame: the radiance of each of their 512 samples (sample_pixels), folded into the running mean with the reference's
+    expression in f32 (tracer.rs:105-117) — bit-identical to the GPU's pixels."""
+    from rust_pathtracer_amd import scenes
+    torch = torch_cuda
+    s = scenes.random_spheres_scene(10000, 16)
+    w, h, spp = 4096, 4096, 512
+    t = rpt.Tracer(s, device=0, seed=1)
+    buf = rpt.DeviceColorBuffer(w, h)
+    t.render_n(buf, spp)
+    torch.cuda.synchronize()
+    assert buf.frames == spp
+    rng = np.random.default_rng(5)
+    cols = rng.integers(0, w, size=512).astype(np.uint32)
+    rows = np.concatenate([rng.integers(h // 2, h, size=448), rng.integers(0, h // 2, size=64)]).astype(np.uint32)   # mostly below the horizon
+    got = buf.pixels[torch.from_numpy(rows.astype(np.int64)).cuda(), torch.from_numpy(cols.astype(np.int64)).cuda()].cpu().numpy()
+    desc = s.describe()
+    rad = oracle.sample_pixels(desc, np.repeat(cols, spp), np.repeat(rows, spp), np.tile(np.arange(spp, dtype=np.uint64), len(cols)), w, h, seed=1)
+    rad = rad.reshape(len(cols), spp, 3)
+    acc = np.zeros((len(cols), 4), dtype=np.float32)
+    one = np.float32(1.0)
+    for k in range(spp):
+        v = one / np.float32(k + 1)                                                        # tracer.rs:115
+        colour = np.concatenate([rad[:, k, :], np.ones((len(cols), 1), dtype=np.float32)], axis=1)
+        acc = (one - v) * acc + colour * v                                                 # mix_color, tracer.rs:108-113
+    assert_bit_identical(got, acc, "c5, 512 spp, 512 pixels")
+    t.close()
+
+
 def test_ab_kernels_are_not_in_the_shipped_library(rpt, torch_cuda):
     """The measured-slower kernel forms (csrc/ab/) are only built with -DRPT_AB_KERNELS: the shipped library refuses
     their flags loudly instead of silently running something else."""
