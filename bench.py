@@ -188,6 +188,9 @@ def main():
             if job:
                 job.gather_end()
 
+        if job:                             # set the communicator's connections up outside the timed region, whatever --warmup is
+            job.render_n(1)
+            job.gather()
         for _ in range(args.warmup):
             step()
         drain()
