@@ -122,10 +122,8 @@ RPT_HD float rpt_exp2_core(double t)
 {
     t = (t > 200.0) ? 200.0 : t;
     t = (t < -200.0) ? -200.0 : t;
-    const double SHIFT = 0x1.8p52;                     /* round-to-nearest-int trick */
-    double kd = t + SHIFT;
-    int32_t n = (int32_t)(uint32_t)rpt_d2u(kd);        /* low word of the biased sum = n (two's complement) */
-    kd = kd - SHIFT;
+    double kd = __builtin_rint(t);                     /* round to nearest, ties to even (default rounding mode): one instruction on both sides */
+    int32_t n = (int32_t)kd;                            /* |kd| <= 200: exact */
     double r = t - kd;                                  /* r in [-0.5, 0.5] */
     double p = 0x1.b6571de2f2351p-24;
     p = __builtin_fma(p, r, 0x1.63ef969a64d3cp-20);

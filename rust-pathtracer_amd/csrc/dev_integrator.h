@@ -11,6 +11,20 @@ struct RayD {
     v3 o, d;
 };
 
+// A wave-uniform scene constant (an SGPR) passed through an empty asm: what is computed from it — radius * radius, the
+// f64 image of the background's exponent — is then recomputed where it is used (one instruction) instead of being hoisted
+// out of the path loop into a VGPR that lives, and spills, for the whole kernel.
+RPT_DEV float uniform_here(float x)
+{
+    asm volatile("" : "+s"(x));
+    return x;
+}
+RPT_DEV uint32_t uniform_here(uint32_t x)
+{
+    asm volatile("" : "+s"(x));
+    return x;
+}
+
 // analytical.rs:166-190 == scene.rs:39-63
 RPT_DEV bool hit_sphere(const RayD& ray, v3 center, float radius, float& t)
 {
@@ -164,7 +178,7 @@ RPT_DEV void analytic_closest(const SceneSmall& sc, const RayD& ray, AnalyticHit
     for (uint32_t i = 0; i < sc.n_spheres; ++i) {
         const DevSphere& s = sc.spheres[i];
         float t;
-        bool h = hit_sphere(ray, mk3(s.cx, s.cy, s.cz), s.radius, t);
+        bool h = hit_sphere(ray, mk3(s.cx, s.cy, s.cz), uniform_here(s.radius), t);
         bool acc = h && (i == 0 || t < a.dist);                     // analytical.rs:43 has no distance test for the first one
         if (acc) {
             a.dist = t;
@@ -390,7 +404,7 @@ RPT_DEV bool any_hit_analytic(const SceneSmall& sc, const RayD& ray, float max_d
     for (uint32_t i = 0; i < sc.n_spheres; ++i) {
         const DevSphere& s = sc.spheres[i];
         float t;
-        bool h = hit_sphere(ray, mk3(s.cx, s.cy, s.cz), s.radius, t);
+        bool h = hit_sphere(ray, mk3(s.cx, s.cy, s.cz), uniform_here(s.radius), t);
         occluded = occluded || (h && (!use_max || t < max_dist));
     }
     for (uint32_t k = 0; k < sc.n_planes; ++k) {
@@ -434,7 +448,8 @@ RPT_DEV v3 background(const S& sc, const RayD& ray)
     v3 cb = mk3(b.bx, b.by, b.bz);
     float t = 0.5f * (ray.d.y + 1.0f);
     v3 c = (1.0f - t) * ca + t * cb;
-    v3 lin = mk3(rpt_powf(c.x, b.gamma), rpt_powf(c.y, b.gamma), rpt_powf(c.z, b.gamma));
+    const float gamma = uniform_here(b.gamma);
+    v3 lin = mk3(rpt_powf(c.x, gamma), rpt_powf(c.y, gamma), rpt_powf(c.z, gamma));
     return lin * splat3(b.scale);
 }
 
@@ -503,7 +518,8 @@ RPT_DEV void sample_light(const S& sc, const DevLight& L, v3 scatter_pos, LightS
 RPT_DEV DevLight light_at(const SceneSmall& sc, uint32_t index)
 {
     DevLight L = sc.lights[0];
-    for (uint32_t i = 1; i < sc.n_lights; ++i) {
+    const uint32_t n_lights = uniform_here(sc.n_lights);
+    for (uint32_t i = 1; i < n_lights; ++i) {
         const DevLight& Li = sc.lights[i];
         bool pick = (index == i);
         L.type = pick ? Li.type : L.type;
@@ -531,7 +547,8 @@ RPT_DEV bool nee_sample(const S& sc, v3 fhp, v3 ffnormal, Rng& rng, v3& scatter_
     float random = rng.gen();
     random = random * sc.n_lights_f;
     uint32_t index = (uint32_t)random;                              // `as usize`
-    index = (index >= sc.n_lights) ? sc.n_lights - 1u : index;      // the reference would panic; unreachable for n < 2^24
+    const uint32_t n_lights = uniform_here(sc.n_lights);
+    index = (index >= n_lights) ? n_lights - 1u : index;            // the reference would panic; unreachable for n < 2^24
 
     const DevLight L = light_at(sc, index);                         // Scene::light_at for a per-lane index
     light_area = L.area;
@@ -617,11 +634,13 @@ struct PathRegs {
     Rng rng;
 };
 
-// tracer.rs:44-57
-template <class S>
-RPT_DEV void path_begin(const S& sc, PathRegs& p, float px, float py, uint32_t fkey, uint32_t pixel_index)
+// tracer.rs:44-57.  HASHED: `pixel` is already pcg_hash(pixel index) (the state-machine kernels keep that in LDS: left to
+// itself the compiler hoists the hash out of the sample loop into a register that then spills).
+template <bool HASHED = false, class S>
+RPT_DEV void path_begin(const S& sc, PathRegs& p, float px, float py, uint32_t fkey, uint32_t pixel)
 {
-    p.rng.init(fkey, pixel_index);
+    if (HASHED) p.rng.init_hashed(fkey, pixel);
+    else p.rng.init(fkey, pixel);
     float offx = p.rng.gen();
     float offy = p.rng.gen();
     p.ray = camera_ray(sc.cam, px, py, offx, offy);

@@ -107,6 +107,12 @@ struct Rng {
         key = pcg_hash(pcg_hash(pixel_index) ^ fkey);
         counter = 0;
     }
+    // the same with pcg_hash(pixel_index) computed once per pixel by the caller
+    RPT_DEV void init_hashed(uint32_t fkey, uint32_t pixel_hash)
+    {
+        key = pcg_hash(pixel_hash ^ fkey);
+        counter = 0;
+    }
     RPT_DEV uint32_t next_u32() { return pcg_hash(key + counter++); }
     RPT_DEV float gen() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
 };

@@ -37,7 +37,7 @@ struct PixelSetup {
     size_t pix_offset;                // index of this pixel's float4 in the tile buffer
 };
 
-RPT_DEV PixelSetup pixel_setup(const RenderParams& rp)
+RPT_DEV PixelSetup pixel_setup(const RenderParams& rp, uint32_t tid)
 {
     // A wave covers an 8x8 pixel block (coherent paths), a 256-thread workgroup 16x16.
     PixelSetup ps;
@@ -46,8 +46,8 @@ RPT_DEV PixelSetup pixel_setup(const RenderParams& rp)
     const uint32_t tile = gridDim.x - 1u - blockIdx.x;
     const uint32_t tx = tile % rp.tiles_x;
     const uint32_t ty = tile / rp.tiles_x;
-    const uint32_t wave = threadIdx.x >> 6;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t lane = tid & 63u;
     const uint32_t col = tx * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t lrow = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
     ps.valid = (col < rp.width) && (lrow < rp.rows_local);
@@ -65,6 +65,16 @@ RPT_DEV PixelSetup pixel_setup(const RenderParams& rp)
     ps.pixel_index = grow * rp.width + col;
     ps.pix_offset = (size_t)lrow * rp.width + col;
     return ps;
+}
+RPT_DEV PixelSetup pixel_setup(const RenderParams& rp) { return pixel_setup(rp, threadIdx.x); }
+
+// Where this lane's pixel lives, recomputed at the end of a state-machine kernel from a thread index the compiler cannot
+// identify with the prologue's: otherwise the 64-bit address stays live across the whole kernel and spills.
+RPT_DEV float4* pixel_address_again(const RenderParams& rp)
+{
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    return reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp, tid).pix_offset;
 }
 
 // mix_color, tracer.rs:108-113, with color = [r, g, b, 1.0] (tracer.rs:59,105)
@@ -135,7 +145,7 @@ struct LaneTables {
     uint32_t* fkey;            // [kMaxSppPerLaunch] frame_key(seed, frames_done + s)
     float* weight;             // [kMaxSppPerLaunch] 1 / (frames_done + s + 1), tracer.rs:115
     float4* acc;               // [256] running mean, tracer.rs:105-117
-    float4* pix;               // [256] {coord.x, coord.y, bits(pixel_index), -}
+    float4* pix;               // [256] {coord.x, coord.y, bits(pcg_hash(pixel_index)), -}
 };
 
 // Fills the tables and this lane's slots.  False: the lane has no pixel, or the scene has max_depth == 0 (no bounce
@@ -148,17 +158,21 @@ RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderPa
         lt.weight[i] = 1.0f / (float)(frames + 1);                  // tracer.rs:115
     }
     __syncthreads();
+    if (max_depth == 0) {                                           // (its own address computation: sharing the one below keeps the
+        const PixelSetup ps0 = pixel_setup(rp);                     //  64-bit address live, and spilled, across the whole kernel)
+        if (ps0.valid) {
+            float4* pixel0 = reinterpret_cast<float4*>(rp.pixels) + ps0.pix_offset;
+            float4 acc = *pixel0;
+            for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), lt.weight[s]);
+            *pixel0 = acc;
+        }
+        return false;
+    }
     const PixelSetup ps = pixel_setup(rp);
     if (!ps.valid) return false;
     float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
-    if (max_depth == 0) {
-        float4 acc = *pixel;
-        for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), lt.weight[s]);
-        *pixel = acc;
-        return false;
-    }
     lt.acc[threadIdx.x] = *pixel;
-    lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(ps.pixel_index), 0.0f);
+    lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(pcg_hash(ps.pixel_index)), 0.0f);
     return true;
 }
 
@@ -182,7 +196,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     g.code = 0u;
     {
         const float4 c = s_pix[tid];
-        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
     }
 
     for (;;) {
@@ -199,7 +213,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
                 state = ST_DONE;
             } else {
                 const float4 c = s_pix[tid];
-                path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
                 state = ST_TRACE;
             }
         }
@@ -218,7 +232,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
         }
     }
     RPT_PROF_FLUSH();
-    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
+    *pixel_address_again(rp) = s_acc[tid];
 }
 
 #ifndef RPT_SMALL_WAVES_PER_SIMD
@@ -275,7 +289,7 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
     MarchRegs m;
     {
         const float4 c = s_pix[tid];
-        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
         march_begin_primary(sc, p, m);
     }
 
@@ -291,7 +305,7 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
                 state = SM_DONE;
             } else {
                 const float4 c = s_pix[tid];
-                path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
                 march_begin_primary(sc, p, m);
                 state = SM_MARCH_P;
             }
@@ -342,7 +356,7 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
         }
     }
     RPT_PROF_FLUSH();
-    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
+    *pixel_address_again(rp) = s_acc[tid];
 }
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
@@ -376,7 +390,7 @@ RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& r
     uint32_t patience = 0;
     {
         const float4 c = s_pix[tid];
-        path_begin(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
         pool_begin_primary(pool, sc, p, m);
     }
 
@@ -394,7 +408,7 @@ RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& r
                 state = SM_DONE;
             } else {
                 const float4 c = s_pix[tid];
-                path_begin(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
                 pool_begin_primary(pool, sc, p, m);
                 state = SM_MARCH_P;
             }
@@ -481,7 +495,7 @@ RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& r
         }
     }
     RPT_PROF_FLUSH();
-    *(reinterpret_cast<float4*>(rp.pixels) + pixel_setup(rp).pix_offset) = s_acc[tid];
+    *pixel_address_again(rp) = s_acc[tid];
 }
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_pool_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_pool_body(sc, rp); }
