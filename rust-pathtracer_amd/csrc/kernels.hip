@@ -252,8 +252,13 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 #else
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
 #endif
-// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
+// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).  6 waves per SIMD: the grid walk
+// waits on dependent loads 43 % of its time (profiles/r2/c5), and one more wave hides more of that than the extra spills cost
+// (10 k spheres, 2048^2 x 8 spp: 4 waves 1 165, 5: 1 387, 6: 1 454, 7: 1 372, 8: 1 200 Msamples/s).
+#ifndef RPT_LARGE_WAVES_PER_SIMD
+#define RPT_LARGE_WAVES_PER_SIMD 6
+#endif
+__global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
 
