@@ -95,6 +95,41 @@ def test_argument_validation_without_gpu(rpt):
     lib.rpt_destroy(None)                                     # harmless
 
 
+def test_multi_gpu_entry_points_validate_without_gpu(rpt):
+    """The multi-GPU constructors and helpers reject bad arguments before touching a device (and, on this GPU-less box,
+    fail loudly with RPT_ERR_NO_DEVICE for good ones: no CPU fallback)."""
+    import torch
+    lib, A = rpt.lib(), rpt._abi
+    h = C.c_void_p()
+    ids = (C.c_int * 2)(0, 1)
+    assert lib.rpt_create_multi(None, ids, 2) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_create_multi(C.byref(h), None, 2) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_create_multi(C.byref(h), ids, 0) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_create_multi(C.byref(h), ids, 65) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_comm_unique_id(None) == A.RPT_ERR_INVALID_ARG
+    uid = A.rpt_unique_id()
+    assert lib.rpt_create_rank(C.byref(h), 0, 2, 2, C.byref(uid)) == A.RPT_ERR_INVALID_ARG      # rank >= world
+    assert lib.rpt_create_rank(C.byref(h), 0, 0, 0, C.byref(uid)) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_create_rank(C.byref(h), 0, 0, 1, None) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_set_tile_rows(None, 2) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_world(None, None, None, None) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_resident_gather_device(None, None) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_resident_sync(None) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_resident_upload(None, None, 1, 1, 0) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_resident_kernel_ms(None, None) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_probe_fn(None, 0, None, None, 0, None, None) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_tile_rows_padded(1080, 2, 8) == 136 and lib.rpt_tile_rows_padded(2160, 2, 8) == 270
+    assert lib.rpt_tile_rows_padded(7, 2, 4) == 2 and lib.rpt_tile_rows_padded(10, 0, 4) == 0
+    if not torch.cuda.is_available():
+        assert lib.rpt_create_multi(C.byref(h), ids, 2) == A.RPT_ERR_NO_DEVICE
+        assert b"no CPU fallback" in lib.rpt_last_error(None)
+        try:
+            rpt.Tracer(rpt.AnalyticalScene(), devices=[0, 1])
+            raise AssertionError("a multi-device Tracer must raise without a GPU")
+        except rpt.RptError as e:
+            assert e.status == A.RPT_ERR_NO_DEVICE
+
+
 def test_tile_row_maps(rpt):
     """Cyclic row-block tiling: every row belongs to exactly one rank, in order within a rank."""
     from rust_pathtracer_amd import tiling
