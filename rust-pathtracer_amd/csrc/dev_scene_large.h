@@ -45,6 +45,8 @@ struct SceneLarge {
     const uint32_t* cell_start;
     const uint32_t* cell_items;
     const float4* cell_spheres;       // spheres[cell_items[k]] stored at k: a cell's spheres are one dependent load away, not two
+    uint32_t n_oversize;              // spheres kept out of the grid (far larger than the rest: host_scene.h), tested by every walk
+    const uint32_t* oversize;
 };
 
 // Wave-uniform table reads: plain dwords through the constant address space, which the
@@ -230,6 +232,12 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
         float t;
         if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; hit = true; }
     }
+    for (uint32_t j = 0; j < sc.n_oversize; ++j) {                  // the spheres that are not in the grid (wave-uniform loop)
+        const uint32_t i = ((cuint_p)sc.oversize)[j];
+        const float4 s = sphere_uniform(sc, i);
+        float t;
+        if (i != 0u && hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (t < dist || (t == dist && i < best))) { dist = t; best = i; hit = true; }
+    }
     GridWalk g;
     { RPT_PROF(PB_GRID_BEGIN); g = grid_begin(sc, ray); }
     // The walk is bound by the latency of its dependent loads (cell -> list bounds -> spheres), not by
@@ -260,6 +268,11 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
 RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max, float max_dist)
 {
     if (!grid_usable(sc, ray)) return brute_any_sphere(sc, ray, use_max, max_dist);
+    for (uint32_t j = 0; j < sc.n_oversize; ++j) {
+        const float4 s = sphere_uniform(sc, ((cuint_p)sc.oversize)[j]);
+        float t;
+        if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (!use_max || t < max_dist)) return true;
+    }
     GridWalk g;
     { RPT_PROF(PB_GRID_BEGIN); g = grid_begin(sc, ray); }
     uint32_t k0 = 0, k1 = 0;

@@ -65,18 +65,42 @@ struct HostGrid {
     float gmin[3], gmax[3], cs[3], inv_cs[3];
     float center[3], safe_r2;
     std::vector<uint32_t> cell_start, items;
+    // Spheres far larger than the rest (the classic r = 1000 "ground sphere") would stretch the grid's box and be listed
+    // in every cell: they stay out of the grid and every walk tests them up front, like sphere 0.  Ascending indices.
+    std::vector<uint32_t> oversize;
 };
+
+// Which spheres stay out of the grid: radius beyond 8 x the median radius, at most kMaxOversize of them (more than that
+// is a scene of generally mixed sizes, which the grid takes as it is).
+constexpr size_t kMaxOversize = 32;
+inline std::vector<uint32_t> pick_oversize(const rpt_sphere* sph, uint32_t count)
+{
+    std::vector<float> radii(count);
+    for (uint32_t i = 0; i < count; ++i) radii[i] = sph[i].radius;
+    std::nth_element(radii.begin(), radii.begin() + count / 2, radii.end());
+    const double limit = 8.0 * (double)radii[count / 2];
+    std::vector<uint32_t> big;
+    for (uint32_t i = 0; i < count; ++i)
+        if ((double)sph[i].radius > limit) big.push_back(i);
+    if (big.size() > kMaxOversize || big.size() == count) big.clear();
+    return big;
+}
 
 // false (with `why`): the cell lists would not fit 32-bit offsets (e.g. tens of thousands of large overlapping
 // spheres, each listed in most cells).
 inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per_cell, HostGrid& g, std::string& why)
 {
+    g.oversize = pick_oversize(sph, count);
+    std::vector<bool> skip(count, false);
+    for (uint32_t i : g.oversize) skip[i] = true;
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (uint32_t i = 0; i < count; ++i)
+    for (uint32_t i = 0; i < count; ++i) {
+        if (skip[i]) continue;
         for (int a = 0; a < 3; ++a) {
             lo[a] = std::min(lo[a], (double)sph[i].center[a] - sph[i].radius);
             hi[a] = std::max(hi[a], (double)sph[i].center[a] + sph[i].radius);
         }
+    }
     double ext[3], vol = 1.0;
     for (int a = 0; a < 3; ++a) {
         double pad = 1e-3 * (hi[a] - lo[a]) + 1e-3;
@@ -84,7 +108,7 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
         ext[a] = hi[a] - lo[a];
         vol *= ext[a];
     }
-    const double target = std::cbrt(vol / (count / spheres_per_cell + 1.0));   // cell edge for ~spheres_per_cell spheres per cell
+    const double target = std::cbrt(vol / ((count - g.oversize.size()) / spheres_per_cell + 1.0));   // cell edge for ~spheres_per_cell spheres per cell
     for (int a = 0; a < 3; ++a) {
         double n = std::ceil(ext[a] / target);
         n = n < 1 ? 1 : (n > 128 ? 128 : n);
@@ -115,6 +139,7 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
     };
     std::vector<size_t> counts(ncell + 1, 0);                       // size_t: the total is checked before it becomes an offset
     for (uint32_t i = 0; i < count; ++i) {
+        if (skip[i]) continue;
         int x0, x1, y0, y1, z0, z1;
         range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
         for (int z = z0; z <= z1; ++z)
@@ -130,6 +155,7 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
     std::vector<uint32_t> cursor(g.cell_start.begin(), g.cell_start.end() - 1);
     g.items.assign(g.cell_start[ncell], 0);
     for (uint32_t i = 0; i < count; ++i) {                          // ascending sphere index within a cell
+        if (skip[i]) continue;
         int x0, x1, y0, y1, z0, z1;
         range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
         for (int z = z0; z <= z1; ++z)
@@ -144,14 +170,15 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
 struct HostAccel {
     HostGrid grid;
     std::vector<float> cell_spheres;          // {cx, cy, cz, r} of items[k] at k: a cell's spheres are one load away from its bounds
-    size_t sz_cstart = 0, sz_items = 0, sz_cell_sph = 0;
+    size_t sz_cstart = 0, sz_items = 0, sz_cell_sph = 0, sz_oversize = 0;
 
-    size_t bytes() const { return sz_cstart + sz_items + sz_cell_sph; }
+    size_t bytes() const { return sz_cstart + sz_items + sz_cell_sph + sz_oversize; }
     void write(unsigned char* dst) const
     {
         std::memcpy(dst, grid.cell_start.data(), sizeof(uint32_t) * grid.cell_start.size());
         std::memcpy(dst + sz_cstart, grid.items.data(), sizeof(uint32_t) * grid.items.size());
         std::memcpy(dst + sz_cstart + sz_items, cell_spheres.data(), sizeof(float) * cell_spheres.size());
+        std::memcpy(dst + sz_cstart + sz_items + sz_cell_sph, grid.oversize.data(), sizeof(uint32_t) * grid.oversize.size());
     }
     void bind(rptdev::SceneLarge& L, const unsigned char* base) const
     {
@@ -164,6 +191,8 @@ struct HostAccel {
         L.cell_start = reinterpret_cast<const uint32_t*>(base);
         L.cell_items = reinterpret_cast<const uint32_t*>(base + sz_cstart);
         L.cell_spheres = reinterpret_cast<const float4*>(base + sz_cstart + sz_items);
+        L.n_oversize = (uint32_t)grid.oversize.size();
+        L.oversize = reinterpret_cast<const uint32_t*>(base + sz_cstart + sz_items + sz_cell_sph);
     }
 };
 
@@ -180,6 +209,7 @@ inline bool build_accel(const rpt_sphere* sph, uint32_t count, HostAccel& a, std
     a.sz_cstart = (sizeof(uint32_t) * a.grid.cell_start.size() + 15) & ~(size_t)15;
     a.sz_items = (sizeof(uint32_t) * a.grid.items.size() + 15) & ~(size_t)15;
     a.sz_cell_sph = sizeof(float) * a.cell_spheres.size();
+    a.sz_oversize = (sizeof(uint32_t) * a.grid.oversize.size() + 15) & ~(size_t)15;
     return true;
 }
 

@@ -331,8 +331,22 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
         t.close()
 
 
-@pytest.mark.parametrize("n_spheres", [64, 3000])
-def test_grid_queries_equal_brute_force(rpt, torch_cuda, n_spheres):
+def _with_ground_sphere(s, where):
+    """The classic r = 1000 ground sphere in a field of small ones: far beyond 8 x the median radius, so the grid keeps it out
+    and every walk tests it up front (host_scene.h, pick_oversize) — as sphere 0 (the unconditional first test of
+    analytical.rs:43) or as the last one."""
+    from rust_pathtracer_amd import scenes
+    s.materials.append(scenes.full_material(rgb=(0.4, 0.5, 0.3), roughness=0.9))
+    ground = ((0.0, -1001.5, -60.0), 1000.0, len(s.materials) - 1)
+    if where == "first":
+        s.spheres.insert(0, ground)
+    else:
+        s.spheres.append(ground)
+    return s
+
+
+@pytest.mark.parametrize("n_spheres,ground", [(64, None), (3000, None), (1500, "first"), (1500, "last")])
+def test_grid_queries_equal_brute_force(rpt, torch_cuda, n_spheres, ground):
     """The uniform grid must answer exactly like the reference's ordered loop over all spheres: nearest t
     (bitwise), winning index, and any-hit, for rays from everywhere — floor points, sphere surfaces at
     grazing angles, the camera, and origins tens of thousands of units away, where the f32 sphere test is
@@ -340,6 +354,9 @@ def test_grid_queries_equal_brute_force(rpt, torch_cuda, n_spheres):
     from rust_pathtracer_amd import scenes
     torch = torch_cuda
     s = scenes.random_spheres_scene(n_spheres=n_spheres, n_lights=16, seed=0x5EED0005)
+    if ground:
+        _with_ground_sphere(s, ground)
+        n_spheres += 1
     t = rpt.Tracer(s, device=0, seed=5)
     rng = np.random.default_rng(n_spheres)
     N = 1_000_000
@@ -366,6 +383,20 @@ def test_grid_queries_equal_brute_force(rpt, torch_cuda, n_spheres):
         res.append(out.cpu().numpy())
     assert (res[1][:, 1] != -1).sum() > N // 20 and res[1][:, 2].sum() > N // 20      # the sample does hit things
     assert np.array_equal(res[0], res[1])
+    t.close()
+
+
+@pytest.mark.parametrize("where", ["first", "last"])
+def test_scene_with_a_giant_ground_sphere_matches_oracle(rpt, torch_cuda, oracle, where):
+    from rust_pathtracer_amd import scenes
+    s = _with_ground_sphere(scenes.random_spheres_scene(n_spheres=600, n_lights=4), where)
+    s.planes = []                                           # the ground sphere is the floor
+    w, h, spp = 96, 64, 3
+    t = rpt.Tracer(s, device=0, seed=9)
+    buf = rpt.DeviceColorBuffer(w, h)
+    t.render_n(buf, spp)
+    torch_cuda.cuda.synchronize()
+    assert_bit_identical(buf.pixels.cpu().numpy(), oracle.render(s.describe(), w, h, spp, seed=9), "ground sphere %s" % where)
     t.close()
 
 
