@@ -104,6 +104,51 @@ def cpu_baseline(width, height, budget_s=12.0):
     }
 
 
+class TorchGatherRender:
+    """Insurance only (see main): the interface of tiling.TiledRender over a plain per-rank Tracer, with the tiles
+    gathered to rank 0 by torch.distributed's RCCL backend and scattered by the library's untile kernel."""
+
+    def __init__(self, tracer, tiling, width, height, tile_rows, rank, world, local_rank):
+        import torch
+        import torch.distributed as dist
+        self.tracer, self.tiling, self.dist = tracer, tiling, dist
+        self.width, self.height, self.tile_rows, self.rank, self.world = width, height, tile_rows, rank, world
+        dev = torch.device("cuda", local_rank)
+        if not hasattr(TorchGatherRender, "group"):
+            TorchGatherRender.group = dist.new_group(backend="nccl")
+        self.tile = torch.zeros(tiling.padded_rows(height, tile_rows, world), width, 4, dtype=torch.float32, device=dev)
+        self.parts = [torch.empty_like(self.tile) for _ in range(world)] if rank == 0 else None
+        self.frames, self.image, self._ms = 0, None, 0.0
+
+    def render_n(self, spp):
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.tracer.render_tile(self.tile, self.width, self.height, self.frames, spp, self.tile_rows, self.rank, self.world)
+        e1.record()
+        self._ev = (e0, e1)
+        self.frames += spp
+
+    def kernel_ms(self):
+        self._ev[1].synchronize()
+        return self._ev[0].elapsed_time(self._ev[1])
+
+    def gather_begin(self):
+        import torch
+        self.dist.gather(self.tile, self.parts, dst=0, group=TorchGatherRender.group)
+        if self.rank == 0:
+            self.image = self.tiling.untile(torch.stack(self.parts), self.width, self.height, self.tile_rows, self.world, tracer=self.tracer)
+
+    def gather_end(self):
+        import torch
+        torch.cuda.synchronize()
+        return self.image
+
+    def gather(self):
+        self.gather_begin()
+        return self.gather_end()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,7 +178,18 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo")           # control plane only: the data path's RCCL lives in the library
+        # control plane only (the data path's RCCL lives in the library).  Gloo announces its connections on stdout from
+        # C++: send fd 1 to stderr while it does, so that stdout carries the one JSON line and nothing else.
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
 
     def shrink(cfg):
         return (cfg[0] // 8, cfg[1] // 8, max(1, cfg[2] // 16)) if args.small else cfg
@@ -170,14 +226,33 @@ def main():
     else:
         # ---- N GPUs: configs[2], strong scaling, gather to rank 0 inside the timed region
         width, height, spp = shrink(C3)
+        gather_mode = "library RCCL send/recv to rank 0"
         if args.smoke_shared_gpu:
             os.environ["RPT_GATHER"] = "p2p"
             tracer = None
             if rank == 0:                   # one process drives all "ranks" of cuda:0; the others only keep the barriers company
                 tracer = rpt.Tracer(scene, devices=[0] * world, seed=1)
         else:
-            tracer = tiling.rank_tracer(scene, local_rank, seed=1)
-        job = tiling.TiledRender(tracer, width, height, tile_rows=2) if tracer else None
+            # The library's own communicator (rpt_create_rank).  If it cannot be set up on this node, every rank falls
+            # back TOGETHER to per-rank tiles + a torch.distributed (RCCL) gather, and the JSON line says so.
+            why = ""
+            try:
+                tracer = tiling.rank_tracer(scene, local_rank, seed=1)
+            except Exception as e:          # noqa: BLE001 - any failure of the collective set-up takes the fallback
+                tracer, why = None, "%s: %s" % (type(e).__name__, e)
+            ok = torch.tensor([1 if tracer else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if tracer:
+                    tracer.close()
+                tracer = rpt.Tracer(scene, device=local_rank, seed=1)
+                gather_mode = "torch.distributed RCCL gather (fallback: the library communicator failed to initialise%s)" % (
+                    ": " + why if why else " on another rank")
+        if gather_mode.startswith("torch"):
+            job_of = lambda w, h: TorchGatherRender(tracer, tiling, w, h, 2, rank, world, local_rank)     # noqa: E731
+        else:
+            job_of = lambda w, h: tiling.TiledRender(tracer, w, h, tile_rows=2) if tracer else None      # noqa: E731
+        job = job_of(width, height)
 
         def step():
             if job:
@@ -199,7 +274,9 @@ def main():
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
-            if tracer:
+            if isinstance(job, TorchGatherRender):
+                kernel_ms.append(job.kernel_ms())
+            elif tracer:
                 kernel_ms.append(tracer.resident_kernel_ms())     # HIP events around this step's launches, on their stream
         drain()
         host_fence()
@@ -212,7 +289,7 @@ def main():
         # secondary: fixed work per GPU (weak scaling), a few steps
         ww, wh = weak_frame(world)
         ww, wh, wspp = shrink((ww, wh, C2[2]))
-        wjob = tiling.TiledRender(tracer, ww, wh, tile_rows=2) if tracer else None
+        wjob = job_of(ww, wh)
         wsteps = max(1, min(args.steps, 5))
         if wjob:
             wjob.render_n(wspp)
@@ -288,7 +365,8 @@ def main():
             "config": {"workload": ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[1])" % (width, height, spp)) if world == 1 else
                                    ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[2]): cyclic 2-row tiles over %d GPUs, "
                                     "RCCL gather to rank 0 + scatter per step inside the timed region" % (width, height, spp, world)),
-                       "spp_per_step": spp, "width": width, "height": height, "parallelism": "rows%d" % world},
+                       "spp_per_step": spp, "width": width, "height": height, "parallelism": "rows%d" % world,
+                       **({"gather": gather_mode} if world > 1 else {})},
             "roofline": roofline,
             "roofline_hbm": {"bound": "hbm", "achieved": round(hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 6),
                              "algorithmic_bytes_per_step": algo_bytes,

@@ -86,6 +86,7 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="buil
     failed = [" ".join(cmd) for cmd, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("build.py: compilation failed:\n" + "\n".join(failed))
+    os.makedirs(os.path.dirname(os.path.abspath(lib)), exist_ok=True)
     link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-ldl", "-o", lib]
     if verbose:
         print(" ".join(link))

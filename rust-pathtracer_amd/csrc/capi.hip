@@ -38,6 +38,8 @@ struct DevState {
     float* fb = nullptr;              // staging for the host-pointer API (this device's rows, or a whole image)
     size_t fb_bytes = 0;
     float* tile = nullptr;            // resident ColorBuffer rows of this rank: rows_padded x width RGBA f32
+    void* wf = nullptr;               // wavefront state of large scenes (dev_wavefront.h), grown on demand
+    size_t wf_bytes = 0;
     ncclComm_t comm = nullptr;
 };
 
@@ -175,6 +177,14 @@ static uint32_t sdf_pool_shade_lanes() { static const uint32_t v = env_lanes("RP
 static uint32_t sdf_pool_resolve_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_RESOLVE_LANES", 16); return v; }
 static uint32_t sdf_pool_min_batch() { static const uint32_t v = env_lanes("RPT_SDF_POOL_MIN_BATCH", 32); return v; }
 static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_POOL_PATIENCE") ? (uint32_t)atoi(getenv("RPT_SDF_POOL_PATIENCE")) : 8u; return v; }
+// RPT_LARGE_FORM=wavefront|megakernel overrides the render flag (A/B runs of unmodified callers).
+static bool wavefront_wanted(uint32_t flags)
+{
+    static const char* form = getenv("RPT_LARGE_FORM");
+    if (form && form[0] == 'w') return true;
+    if (form && form[0] == 'm') return false;
+    return (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
+}
 // ---- descriptor -> device tables ---------------------------------------------------------------------------
 static DevPlane dev_plane(const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; }
 static DevLight dev_light(const rpt_light& a)
@@ -204,6 +214,7 @@ static void free_dev(DevState& d)
     if (d.fb) (void)hipFree(d.fb);
     if (d.tile) (void)hipFree(d.tile);
     if (d.tables) (void)hipFree(d.tables);
+    if (d.wf) (void)hipFree(d.wf);
     if (d.ev_begin) (void)hipEventDestroy(d.ev_begin);
     if (d.ev_end) (void)hipEventDestroy(d.ev_end);
     if (d.ev_ready) (void)hipEventDestroy(d.ev_ready);
@@ -293,6 +304,38 @@ static hipError_t copy_rank_rows(bool to_device, float* host_image, float* tile,
 }
 
 // One render launch sequence on one device.
+// The wavefront's per-slot state and lists: one allocation, carved up here.
+static int wavefront_buffers(rpt_ctx* ctx, DevState& d, size_t n_slots, WfBuffers& wb)
+{
+    const size_t n_seg = (n_slots + 63) / 64, padded = n_seg * 64;
+    const size_t head = (kWalkGroups * kWalkCounterStride + 64) * sizeof(uint32_t);
+    const size_t bytes = head + padded * (7 * sizeof(float4) + sizeof(uint4) + 2 * sizeof(uint32_t)) + n_seg * 2 * sizeof(uint32_t);
+    if (bytes > d.wf_bytes) {
+        if (d.wf) { RPT_HIP_CHECK(ctx, hipFree(d.wf)); d.wf = nullptr; d.wf_bytes = 0; }
+        RPT_HIP_CHECK(ctx, hipMalloc(&d.wf, bytes));
+        d.wf_bytes = bytes;
+    }
+    char* p = (char*)d.wf;
+    auto take = [&](size_t n) { char* q = p; p += n; return q; };
+    wb.group_next = (uint32_t*)take(kWalkGroups * kWalkCounterStride * sizeof(uint32_t));
+    wb.any_active = (uint32_t*)take(64 * sizeof(uint32_t));
+    wb.ray_o = (float4*)take(padded * sizeof(float4));
+    wb.ray_d = (float4*)take(padded * sizeof(float4));
+    wb.thr = (float4*)take(padded * sizeof(float4));
+    wb.rad = (float4*)take(padded * sizeof(float4));
+    wb.sh_o = (float4*)take(padded * sizeof(float4));
+    wb.sh_d = (float4*)take(padded * sizeof(float4));
+    wb.c_lit = (float4*)take(padded * sizeof(float4));
+    wb.ctl = (uint4*)take(padded * sizeof(uint4));
+    wb.closest = (uint32_t*)take(padded * sizeof(uint32_t));
+    wb.shadow = (uint32_t*)take(padded * sizeof(uint32_t));
+    wb.cnt_closest = (uint32_t*)take(n_seg * sizeof(uint32_t));
+    wb.cnt_shadow = (uint32_t*)take(n_seg * sizeof(uint32_t));
+    wb.n_slots = (uint32_t)n_slots;
+    wb.n_seg = (uint32_t)n_seg;
+    return RPT_OK;
+}
+
 static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp,
                          uint64_t seed, uint32_t flags, uint32_t tile_rows, uint32_t rank, uint32_t world, hipStream_t stream)
 {
@@ -329,6 +372,15 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     }
 #endif
     const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
+    // wavefront form of large scenes with a grid (max_depth == 0 has no bounce loop: the megakernel's prologue does that)
+    const bool wavefront = wavefront_wanted(flags) && ctx->large && scl.use_accel && !nested && scl.max_depth != 0u;
+    WfBuffers wb;
+    if (wavefront) {
+        const uint64_t n_slots = (uint64_t)rp.rows_local * width;
+        if (n_slots >= (1ull << 31)) { set_err(ctx, "render: tile too large for the wavefront form"); return RPT_ERR_INVALID_ARG; }
+        int rc = wavefront_buffers(ctx, d, (size_t)n_slots, wb);
+        if (rc != RPT_OK) return rc;
+    }
 
     // The LDS tables of the regenerating kernel hold a bounded number of samples: larger batches are
     // split into consecutive launches (the running mean carries over in the framebuffer).
@@ -337,7 +389,9 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         const uint32_t chunk = (spp - done > max_chunk) ? max_chunk : (spp - done);
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
-        if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
+        if (wavefront && (flags & RPT_RENDER_FAST_MATH)) RPT_HIP_CHECK(ctx, rptlaunch_fast::render_wavefront(scl, rp, wb, stream));
+        else if (wavefront) RPT_HIP_CHECK(ctx, rptlaunch::render_wavefront(scl, rp, wb, stream));
+        else if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
         else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
         done += chunk;
     }

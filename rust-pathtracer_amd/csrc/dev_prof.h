@@ -32,6 +32,10 @@ enum ProfBlock : uint32_t {
     PB_PASS,           // one pass of the scheduling loop (votes included)
     PB_GRID_BEGIN,     // large scenes: DDA set-up of one grid walk
     PB_GRID_CELL,      // large scenes: one cell of a grid walk (record tests + step + prefetch)
+    PB_WF_WAVE,        // wavefront walk kernel: a wave's whole life
+    PB_WF_FETCH,       //   taking segments / entries for the idle lanes
+    PB_WF_SETUP,       //   ray load, slab test, DDA set-up, first cell's bounds
+    PB_WF_CELL,        //   one cell iteration of the wave
     PB_COUNT
 };
 
@@ -44,7 +48,7 @@ __shared__ uint32_t s_prof[4 * PB_COUNT * 3];
 __device__ __forceinline__ void prof_init()
 {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    if (lane < PB_COUNT * 3) s_prof[wave * PB_COUNT * 3 + lane] = 0u;
+    for (uint32_t i = lane; i < PB_COUNT * 3; i += 64u) s_prof[wave * PB_COUNT * 3 + i] = 0u;
 }
 __device__ __forceinline__ void prof_flush()
 {

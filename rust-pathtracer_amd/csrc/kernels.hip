@@ -10,6 +10,7 @@
 #include "dev_integrator.h"
 #include "dev_sdf_path.h"
 #include "dev_scene_large.h"
+#include "dev_wavefront.h"
 #ifdef RPT_AB_KERNELS                 // measured-slower kernel forms kept for A/B runs only; not in the shipped library
 #include "ab/dev_sdf_pool.h"
 #endif
@@ -37,6 +38,23 @@ struct PixelSetup {
     size_t pix_offset;                // index of this pixel's float4 in the tile buffer
 };
 
+// coord of tracer.rs:46 and the global pixel index of column `col`, local row `lrow` of this rank's tile
+RPT_DEV void pixel_coords(const RenderParams& rp, uint32_t col, uint32_t lrow, float& px, float& py, uint32_t& pixel_index)
+{
+    const uint32_t grow = tile_global_row(lrow, rp.tile_rows, rp.rank, rp.world);
+    // j counts rows from the bottom (par_rchunks, tracer.rs:29-37)
+    const float W = (float)rp.width;
+    const float H = (float)rp.height;
+    const uint32_t j = rp.height - 1u - grow;
+    const float x = (float)col;
+    const float y = H - (float)j;
+    const float xx = x / W;
+    const float yy = y / H;
+    px = xx;
+    py = 1.0f - yy;
+    pixel_index = grow * rp.width + col;
+}
+
 RPT_DEV PixelSetup pixel_setup(const RenderParams& rp, uint32_t tid)
 {
     // A wave covers an 8x8 pixel block (coherent paths), a 256-thread workgroup 16x16.
@@ -51,18 +69,7 @@ RPT_DEV PixelSetup pixel_setup(const RenderParams& rp, uint32_t tid)
     const uint32_t col = tx * 16u + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t lrow = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
     ps.valid = (col < rp.width) && (lrow < rp.rows_local);
-    const uint32_t grow = tile_global_row(lrow, rp.tile_rows, rp.rank, rp.world);
-    // j counts rows from the bottom (par_rchunks, tracer.rs:29-37)
-    const float W = (float)rp.width;
-    const float H = (float)rp.height;
-    const uint32_t j = rp.height - 1u - grow;
-    const float x = (float)col;
-    const float y = H - (float)j;
-    const float xx = x / W;
-    const float yy = y / H;
-    ps.px = xx;
-    ps.py = 1.0f - yy;
-    ps.pixel_index = grow * rp.width + col;
+    pixel_coords(rp, col, lrow, ps.px, ps.py, ps.pixel_index);
     ps.pix_offset = (size_t)lrow * rp.width + col;
     return ps;
 }
@@ -261,6 +268,124 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
+
+// Large scenes as a wavefront (dev_wavefront.h): WALK(k) walks the rays SHADE(k-1) listed, SHADE(k) does the rest of the bounce
+// for every slot that still has work and lists the next rays.
+#ifndef RPT_WF_WALK_WAVES_PER_SIMD
+#define RPT_WF_WALK_WAVES_PER_SIMD 6
+#endif
+#ifndef RPT_WF_SHADE_WAVES_PER_SIMD
+#define RPT_WF_SHADE_WAVES_PER_SIMD 4
+#endif
+__global__ __launch_bounds__(256, RPT_WF_WALK_WAVES_PER_SIMD) void RPT_K(wf_walk_kernel)(const SceneLarge sc, const WfBuffers wb, uint32_t parity, uint32_t refill_at)
+{
+    RPT_PROF_INIT();
+#ifdef RPT_PROFILE_BLOCKS
+    __syncthreads();
+#endif
+    if (blockIdx.x == 0 && threadIdx.x == 0) wb.any_active[parity] = 0u;       // SHADE(k) raises it again if anything is left
+    wf_walk_body(sc, wb, refill_at);
+    RPT_PROF_FLUSH();
+}
+
+// One thread per slot (= pixel of the tile).  `first`: every slot starts sample 0 of its pixel (no state to read).
+__global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_shade_kernel)(const SceneLarge sc, const RenderParams rp, const WfBuffers wb, uint32_t parity, uint32_t first)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    if (slot < kWalkGroups) wb.group_next[slot * kWalkCounterStride] = 0u;     // the next WALK's segment counters (the previous WALK is over)
+    const bool in_tile = slot < wb.n_slots;
+    uint4 c = make_uint4(0u, 0u, 0u, WF_DONE);
+    if (in_tile && !first) c = wb.ctl[slot];
+    const bool live = in_tile && (first || (c.w & 3u) != WF_DONE);
+
+    PathRegs p;
+    GeomHit g;
+    g.code = 0u;
+    uint32_t s = 0u, status = WF_WALKING;
+    bool want_shade = false, want_finish = false, want_begin = live && first, new_ray = false, walk_closest = false;
+    ShadowReq sr;
+    sr.pending = false;
+    float dist = 0.0f;
+    uint32_t best = 0xFFFFFFFFu;
+    if (live && !first) {
+        const float4 a = wb.ray_o[slot], b = wb.ray_d[slot], t = wb.thr[slot], r = wb.rad[slot];
+        p.ray.o = mk3(a.x, a.y, a.z); p.ray.d = mk3(b.x, b.y, b.z);
+        p.throughput = mk3(t.x, t.y, t.z); p.ps.hit_dist = t.w;
+        p.radiance = mk3(r.x, r.y, r.z); p.ps.scatter_pdf = r.w;
+        p.rng.key = c.x; p.rng.counter = c.y; p.bounce = c.z;
+        s = c.w >> 3; status = c.w & 3u;
+        if (c.w & 4u) {                                             // last bounce's light sample: visible unless its walk found an occluder
+            if (rpt_f2u(wb.sh_d[slot].w) == 0u) {
+                const float4 cl = wb.c_lit[slot];
+                p.radiance = p.radiance + mk3(cl.x, cl.y, cl.z);
+            }
+        }
+        if (status == WF_ENDING) {
+            want_finish = true;
+        } else {
+            const WaveQuery q{a.w, rpt_f2u(b.w)};
+            if (path_trace_geom(sc, q, p, g)) want_shade = true;
+            else want_finish = true;
+        }
+    }
+    if (want_shade) {
+        if (path_shade_deferred(sc, p, g, sr)) {
+            if (sr.pending) status = WF_ENDING;                     // the sample is over once its last shadow ray is answered
+            else want_finish = true;
+        } else {
+            new_ray = true;
+        }
+    }
+    if (want_finish) {                                              // tracer.rs:105-117 on this pixel's running mean, then its next sample
+        const uint64_t frames = rp.frames_done + s;
+        float4* pixel = reinterpret_cast<float4*>(rp.pixels) + slot;
+        float4 acc = *pixel;
+        blend(acc, p.radiance, 1.0f / (float)(frames + 1));
+        *pixel = acc;
+        s += 1u;
+        if (s >= rp.spp) status = WF_DONE;
+        else want_begin = true;
+    }
+    if (want_begin) {
+        float px, py;
+        uint32_t pixel_index;
+        pixel_coords(rp, slot % rp.width, slot / rp.width, px, py, pixel_index);
+        path_begin(sc, p, px, py, frame_key_hd(rp.seed, rp.frames_done + s), pixel_index);
+        status = WF_WALKING;
+        new_ray = true;
+    }
+    if (new_ray) walk_closest = closest_before_walk(sc, p.ray, dist, best);
+
+    const bool keep = live && status != WF_DONE;
+    if (live) {
+        wb.ctl[slot] = make_uint4(p.rng.key, p.rng.counter, p.bounce, (s << 3) | (sr.pending ? 4u : 0u) | status);
+        if (keep) {
+            wb.ray_o[slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, dist);
+            wb.ray_d[slot] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, rpt_u2f(best));
+            wb.thr[slot] = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, p.ps.hit_dist);
+            wb.rad[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, p.ps.scatter_pdf);
+            if (sr.pending) {
+                wb.sh_o[slot] = make_float4(sr.ray.o.x, sr.ray.o.y, sr.ray.o.z, sr.max_dist);
+                wb.sh_d[slot] = make_float4(sr.ray.d.x, sr.ray.d.y, sr.ray.d.z, rpt_u2f(0u));
+                wb.c_lit[slot] = make_float4(sr.c_lit.x, sr.c_lit.y, sr.c_lit.z, 0.0f);
+            }
+        }
+    }
+    // this wave's segment of the two ray lists (dev_wavefront.h)
+    const uint32_t seg = slot >> 6, lane = threadIdx.x & 63u;
+    const uint64_t below = (1ull << lane) - 1ull;
+    const bool qc = keep && new_ray && walk_closest;
+    const uint64_t mc = __ballot(qc);
+    if (qc) wb.closest[seg * 64u + (uint32_t)__popcll(mc & below)] = slot;
+    const bool qs = keep && sr.pending;
+    const uint64_t ms = __ballot(qs);
+    if (qs) wb.shadow[seg * 64u + (uint32_t)__popcll(ms & below)] = slot;
+    if (lane == 0u && seg < wb.n_seg) {
+        wb.cnt_closest[seg] = (uint32_t)__popcll(mc);
+        wb.cnt_shadow[seg] = (uint32_t)__popcll(ms);
+        if (__ballot(keep) != 0ull) wb.any_active[parity] = 1u;
+    }
+}
 
 // SDF scenes, resumable march (dev_sdf_path.h).  Per lane:
 //   MARCH_P --(march over)--> RESOLVE --(miss / emitter)--> next sample: MARCH_P
@@ -727,6 +852,31 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
         // kernel's throughput depends on resident waves per SIMD (occupancy sensitivity)
         static const unsigned extra_lds = getenv("RPT_DEBUG_EXTRA_LDS") ? (unsigned)atoi(getenv("RPT_DEBUG_EXTRA_LDS")) : 0u;
         hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, extra_lds, st, sc, rp);
+    }
+    return hipGetLastError();
+}
+
+hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, hipStream_t st)
+{
+    static const uint32_t refill_at = getenv("RPT_WF_REFILL_AT") ? (uint32_t)atoi(getenv("RPT_WF_REFILL_AT")) : 40u;
+    static const uint32_t blocks_per_group = getenv("RPT_WF_BLOCKS_PER_GROUP") ? (uint32_t)atoi(getenv("RPT_WF_BLOCKS_PER_GROUP")) : 6u;
+    (void)hipGetLastError();
+    const dim3 wg(256), all((wb.n_seg * 64u + 255u) / 256u), walkers(kWalkGroups * (blocks_per_group ? blocks_per_group : 1u));
+    hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, 0u, 1u);
+    // a sample takes at most max_depth walks of its path ray plus one for its last shadow ray
+    const uint64_t bound = (uint64_t)rp.spp * (sc.max_depth + 1u);
+    uint32_t host_active = 1u;
+    for (uint64_t k = 1; k <= bound; ++k) {
+        const uint32_t parity = (uint32_t)(k & 1u);
+        hipLaunchKernelGGL(RPT_K(wf_walk_kernel), walkers, wg, 0, st, sc, wb, parity, refill_at);
+        hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, parity, 0u);
+        if ((k & 63u) == 0u && bound - k > 64u) {
+            // long bounds (deep paths) are mostly empty iterations: look at the flag SHADE(k) just wrote
+            hipError_t e = hipMemcpyAsync(&host_active, &wb.any_active[parity], sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            if (host_active == 0u) break;
+        }
     }
     return hipGetLastError();
 }

@@ -121,3 +121,28 @@ def test_multi_context_large_scene_and_progressive_gathers(rpt, oracle, torch_cu
     t.render_resident(w, h, 2)
     assert_bit_identical(t.resident_to_host(w, h).image(), oracle.render(desc, w, h, 3, seed=3), "large scene, step 2")
     t.close()
+
+
+def test_bench_fallback_gather_gives_the_same_image(rpt, oracle, torch_cuda):
+    """bench.py's insurance path (per-rank tile + torch.distributed RCCL gather + the library's scatter), on a one-rank
+    group: the image of the plain render, bit for bit."""
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    from rust_pathtracer_amd import tiling
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    try:
+        w, h = 70, 37
+        t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
+        job = bench.TorchGatherRender(t, tiling, w, h, 2, 0, 1, 0)
+        job.render_n(2)
+        job.render_n(3)
+        img = job.gather()
+        assert job.kernel_ms() > 0.0
+        assert_bit_identical(img.cpu().numpy(), oracle.render(oracle.scene_analytical(), w, h, 5, seed=1), "fallback gather")
+        t.close()
+    finally:
+        dist.destroy_process_group()

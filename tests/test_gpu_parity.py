@@ -290,8 +290,9 @@ def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
     s = scenes.random_spheres_scene(n_spheres=n_spheres, n_lights=n_lights, seed=0x5EED0005)
     w, h, spp = 96, 54, 3
     t = rpt.Tracer(s, device=0, seed=5)
-    # default: the grid walk inside the bounce (from 64 spheres up); then the resumable walk; then nested loops
-    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+    # default: the grid walk inside the bounce (from 64 spheres up); then nested loops; then the wavefront form (walks in their
+    # own kernel; scenes without a grid ignore the flag)
+    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS, rpt._abi.RPT_RENDER_LARGE_WAVEFRONT):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)

@@ -12,7 +12,8 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 PKG = os.path.join(ROOT, "rust-pathtracer_amd")
 PROF_LIB = os.path.join(PKG, "librpt_hip_prof.so")
 BLOCKS = ["TRACE", "  closest_hit", "  background", "  finalize", "  finish+camera", "SHADE", "  make_frame", "  nee_sample", "  any_hit",
-          "  disney_eval", "  disney_sample", "    lobe diffuse", "    lobe clearcoat", "    lobe spec", "  tail", "PASS", "    grid begin", "    grid cell"]
+          "  disney_eval", "  disney_sample", "    lobe diffuse", "    lobe clearcoat", "    lobe spec", "  tail", "PASS", "    grid begin", "    grid cell",
+          "WALK wave (wavefront)", "  fetch entries", "  ray set-up", "  cell iteration"]
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     spec = importlib.util.spec_from_file_location("_rpt_build", os.path.join(PKG, "build.py"))
@@ -31,9 +32,11 @@ from rust_pathtracer_amd import scenes  # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 which = sys.argv[2] if len(sys.argv) > 2 else "c2"
-w, h = (2048, 2048) if which == "c5" else (1920, 1080)
-scene = {"c2": rpt.AnalyticalScene, "c4": scenes.sdf_scene, "c4i": scenes.sdf_scene, "c4p": scenes.sdf_scene, "c5": lambda: scenes.random_spheres_scene(10000, 16)}[which]()
+w, h = (2048, 2048) if which in ("c5", "c5w") else (1920, 1080)
+scene = {"c5w": lambda: scenes.random_spheres_scene(10000, 16), "c2": rpt.AnalyticalScene, "c4": scenes.sdf_scene, "c4i": scenes.sdf_scene, "c4p": scenes.sdf_scene, "c5": lambda: scenes.random_spheres_scene(10000, 16)}[which]()
 t = rpt.Tracer(scene, device=0, seed=1)
+if which == "c5w":
+    t.flags = rpt._abi.RPT_RENDER_LARGE_WAVEFRONT          # walk kernel scopes: shares are of the WALK waves' time
 if which == "c4p":
     t.flags = rpt._abi.RPT_RENDER_SDF_POOL_MARCH           # the workgroup march pool
 if which == "c4i":
@@ -50,7 +53,7 @@ e0.record(); t.render_n(buf, spp); e1.record(); torch.cuda.synchronize()
 assert lib.rpt_prof_read(out) == 0
 n_samples = w * h * spp
 print("profiled build, %s: %dx%d x %d spp in %.2f ms (%.0f Msamples/s with the counters on)" % (which, w, h, spp, e0.elapsed_time(e1), n_samples / e0.elapsed_time(e1) / 1e3))
-pass_cycles = out[BLOCKS.index("PASS") * 3 + 2]
+pass_cycles = out[BLOCKS.index("WALK wave (wavefront)" if which == "c5w" else "PASS") * 3 + 2]
 print("%-20s %12s %9s %8s %10s %12s" % ("block", "wave execs", "lanes/64", "share", "execs/smp", "lane-exec/smp"))
 for i, name in enumerate(BLOCKS):
     ex, ln, cy = out[i * 3], out[i * 3 + 1], out[i * 3 + 2]

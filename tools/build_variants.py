@@ -14,6 +14,13 @@ VARIANTS = {
     "w4": ["-DRPT_SMALL_WAVES_PER_SIMD=4"],
     "w6": ["-DRPT_SMALL_WAVES_PER_SIMD=6"],
     "w8": ["-DRPT_SMALL_WAVES_PER_SIMD=8"],
+    # wavefront form of large scenes: occupancy of the two kernels
+    "walk6": ["-DRPT_WF_WALK_WAVES_PER_SIMD=6"],
+    "walk7": ["-DRPT_WF_WALK_WAVES_PER_SIMD=7"],
+    "walk8": ["-DRPT_WF_WALK_WAVES_PER_SIMD=8"],
+    "shade3": ["-DRPT_WF_SHADE_WAVES_PER_SIMD=3"],
+    "shade5": ["-DRPT_WF_SHADE_WAVES_PER_SIMD=5"],
+    "shade6": ["-DRPT_WF_SHADE_WAVES_PER_SIMD=6"],
 }
 
 if __name__ == "__main__":

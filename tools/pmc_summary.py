@@ -17,7 +17,7 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*.csv"))):
             per[r["Counter_Name"]].append(float(r["Counter_Value"]))
             kernels[r["Kernel_Name"].split("(")[0]] += 1
     for k, v in per.items():
-        vals[k] = v[-1]
+        vals[k] = sum(v) if os.environ.get("PMC_AGG") == "sum" else v[-1]      # PMC_AGG=sum: all dispatches (multi-launch forms)
 print("kernels matched:", ", ".join(sorted(kernels)))
 for k in sorted(vals):
     print("%-28s %.5g" % (k, vals[k]))
