@@ -232,7 +232,7 @@ enum {
     RPT_RENDER_RUSSIAN_ROULETTE = 1u << 5,
     /* Large scenes with a grid (more than 64 spheres): render as a WAVEFRONT — the grid walks in a kernel of their own over
      * ray lists in HBM, the rest of a bounce in a shading kernel — instead of inside the megakernel.  Same
-     * image bit for bit.  Needs 152 B of device memory per pixel of the tile while it runs (kept by the context).  Ignored
+     * image bit for bit.  Needs 168 B of device memory per pixel of the tile while it runs (kept by the context).  Ignored
      * for scenes that have no grid. */
     RPT_RENDER_LARGE_WAVEFRONT = 1u << 6
 };

@@ -309,7 +309,7 @@ static int wavefront_buffers(rpt_ctx* ctx, DevState& d, size_t n_slots, WfBuffer
 {
     const size_t n_seg = (n_slots + 63) / 64, padded = n_seg * 64;
     const size_t head = (kWalkGroups * kWalkCounterStride + 64) * sizeof(uint32_t);
-    const size_t bytes = head + padded * (7 * sizeof(float4) + sizeof(uint4) + 2 * sizeof(uint32_t)) + n_seg * 2 * sizeof(uint32_t);
+    const size_t bytes = head + padded * (8 * sizeof(float4) + sizeof(uint4) + 2 * sizeof(uint32_t)) + n_seg * 2 * sizeof(uint32_t);
     if (bytes > d.wf_bytes) {
         if (d.wf) { RPT_HIP_CHECK(ctx, hipFree(d.wf)); d.wf = nullptr; d.wf_bytes = 0; }
         RPT_HIP_CHECK(ctx, hipMalloc(&d.wf, bytes));
@@ -326,6 +326,7 @@ static int wavefront_buffers(rpt_ctx* ctx, DevState& d, size_t n_slots, WfBuffer
     wb.sh_o = (float4*)take(padded * sizeof(float4));
     wb.sh_d = (float4*)take(padded * sizeof(float4));
     wb.c_lit = (float4*)take(padded * sizeof(float4));
+    wb.prev = (float4*)take(padded * sizeof(float4));
     wb.ctl = (uint4*)take(padded * sizeof(uint4));
     wb.closest = (uint32_t*)take(padded * sizeof(uint32_t));
     wb.shadow = (uint32_t*)take(padded * sizeof(uint32_t));

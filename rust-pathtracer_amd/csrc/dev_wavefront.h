@@ -20,7 +20,7 @@
 
 namespace rptdev {
 
-enum : uint32_t { WF_WALKING = 0u, WF_ENDING = 1u, WF_DONE = 2u };      // slot status (ctl.w bits 0-1); bit 2: a shadow ray is pending
+enum : uint32_t { WF_WALKING = 0u, WF_ENDING = 1u, WF_DONE = 2u };      // slot status (ctl.w bits 0-1)
 
 // Ray lists without a shared counter: every wave of SHADE (64 consecutive slots) owns a 64-entry SEGMENT of each list and
 // compacts its rays into it with a ballot — no atomics.  (A first version appended to one global list with one atomicAdd per
@@ -39,7 +39,8 @@ struct WfBuffers {
     float4* sh_o;              //           shadow ray origin; w: max_dist
     float4* sh_d;              //           direction; w: bits of "occluded" (written by WALK)
     float4* c_lit;             //           the parked next-event contribution
-    uint4* ctl;                //           rng key, rng counter, bounce, sample << 3 | pending << 2 | status
+    float4* prev;              //           radiance of the pixel's previous sample while its last shadow ray is out (ctl.w bit 3)
+    uint4* ctl;                //           rng key, rng counter, bounce, sample << 4 | previous parked << 3 | shadow pending << 2 | status
     uint32_t* closest;         // [n_seg * 64] slots whose path ray needs a grid walk, per segment
     uint32_t* shadow;          // [n_seg * 64] slots whose shadow ray needs a grid walk
     uint32_t* cnt_closest;     // [n_seg] entries in each segment

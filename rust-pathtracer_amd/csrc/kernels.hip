@@ -291,6 +291,10 @@ __global__ __launch_bounds__(256, RPT_WF_WALK_WAVES_PER_SIMD) void RPT_K(wf_walk
 // One thread per slot (= pixel of the tile).  `first`: every slot starts sample 0 of its pixel (no state to read).
 __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_shade_kernel)(const SceneLarge sc, const RenderParams rp, const WfBuffers wb, uint32_t parity, uint32_t first)
 {
+    RPT_PROF_INIT();
+#ifdef RPT_PROFILE_BLOCKS
+    __syncthreads();
+#endif
     const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
     if (slot < kWalkGroups) wb.group_next[slot * kWalkCounterStride] = 0u;     // the next WALK's segment counters (the previous WALK is over)
     const bool in_tile = slot < wb.n_slots;
@@ -307,18 +311,37 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
     sr.pending = false;
     float dist = 0.0f;
     uint32_t best = 0xFFFFFFFFu;
+    bool park = false;
+    v3 prev_rad = mk3(0.0f, 0.0f, 0.0f);
+#ifdef RPT_PROFILE_BLOCKS
+    {
+#endif
+    RPT_PROF(PB_PASS);
     if (live && !first) {
+        RPT_PROF(PB_TRACE);
         const float4 a = wb.ray_o[slot], b = wb.ray_d[slot], t = wb.thr[slot], r = wb.rad[slot];
         p.ray.o = mk3(a.x, a.y, a.z); p.ray.d = mk3(b.x, b.y, b.z);
         p.throughput = mk3(t.x, t.y, t.z); p.ps.hit_dist = t.w;
         p.radiance = mk3(r.x, r.y, r.z); p.ps.scatter_pdf = r.w;
         p.rng.key = c.x; p.rng.counter = c.y; p.bounce = c.z;
-        s = c.w >> 3; status = c.w & 3u;
-        if (c.w & 4u) {                                             // last bounce's light sample: visible unless its walk found an occluder
-            if (rpt_f2u(wb.sh_d[slot].w) == 0u) {
-                const float4 cl = wb.c_lit[slot];
-                p.radiance = p.radiance + mk3(cl.x, cl.y, cl.z);
-            }
+        s = c.w >> 4; status = c.w & 3u;
+        // last bounce's light sample: visible unless its walk found an occluder
+        const bool lit = (c.w & 4u) && rpt_f2u(wb.sh_d[slot].w) == 0u;
+        v3 gain = mk3(0.0f, 0.0f, 0.0f);
+        if (lit) { const float4 cl = wb.c_lit[slot]; gain = mk3(cl.x, cl.y, cl.z); }
+        if (c.w & 8u) {
+            // that light sample belonged to the PREVIOUS sample of the pixel, which ended there: it is blended now (the
+            // current sample was started at once, in its place: tracer.rs:105-117 still sees the samples in order)
+            const float4 pr = wb.prev[slot];
+            v3 r = mk3(pr.x, pr.y, pr.z);
+            if (lit) r = r + gain;
+            const uint64_t frames = rp.frames_done + (s - 1u);
+            float4* pixel = reinterpret_cast<float4*>(rp.pixels) + slot;
+            float4 acc = *pixel;
+            blend(acc, r, 1.0f / (float)(frames + 1));
+            *pixel = acc;
+        } else if (lit) {
+            p.radiance = p.radiance + gain;
         }
         if (status == WF_ENDING) {
             want_finish = true;
@@ -329,14 +352,24 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
         }
     }
     if (want_shade) {
+        RPT_PROF(PB_SHADE);
         if (path_shade_deferred(sc, p, g, sr)) {
-            if (sr.pending) status = WF_ENDING;                     // the sample is over once its last shadow ray is answered
-            else want_finish = true;
+            if (!sr.pending) {
+                want_finish = true;
+            } else if (s + 1u < rp.spp) {                           // over once its last shadow ray is answered: park it, start the next sample
+                prev_rad = p.radiance;
+                park = true;
+                s += 1u;
+                want_begin = true;
+            } else {
+                status = WF_ENDING;                                 // the launch's last sample waits for the answer
+            }
         } else {
             new_ray = true;
         }
     }
     if (want_finish) {                                              // tracer.rs:105-117 on this pixel's running mean, then its next sample
+        RPT_PROF(PB_FINISH);
         const uint64_t frames = rp.frames_done + s;
         float4* pixel = reinterpret_cast<float4*>(rp.pixels) + slot;
         float4 acc = *pixel;
@@ -347,6 +380,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
         else want_begin = true;
     }
     if (want_begin) {
+        RPT_PROF(PB_FRAME);
         float px, py;
         uint32_t pixel_index;
         pixel_coords(rp, slot % rp.width, slot / rp.width, px, py, pixel_index);
@@ -354,16 +388,20 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
         status = WF_WALKING;
         new_ray = true;
     }
-    if (new_ray) walk_closest = closest_before_walk(sc, p.ray, dist, best);
+    if (new_ray) {
+        RPT_PROF(PB_GRID_BEGIN);
+        walk_closest = closest_before_walk(sc, p.ray, dist, best);
+    }
 
     const bool keep = live && status != WF_DONE;
     if (live) {
-        wb.ctl[slot] = make_uint4(p.rng.key, p.rng.counter, p.bounce, (s << 3) | (sr.pending ? 4u : 0u) | status);
+        wb.ctl[slot] = make_uint4(p.rng.key, p.rng.counter, p.bounce, (s << 4) | (park ? 8u : 0u) | (sr.pending ? 4u : 0u) | status);
         if (keep) {
             wb.ray_o[slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, dist);
             wb.ray_d[slot] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, rpt_u2f(best));
             wb.thr[slot] = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, p.ps.hit_dist);
             wb.rad[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, p.ps.scatter_pdf);
+            if (park) wb.prev[slot] = make_float4(prev_rad.x, prev_rad.y, prev_rad.z, 0.0f);
             if (sr.pending) {
                 wb.sh_o[slot] = make_float4(sr.ray.o.x, sr.ray.o.y, sr.ray.o.z, sr.max_dist);
                 wb.sh_d[slot] = make_float4(sr.ray.d.x, sr.ray.d.y, sr.ray.d.z, rpt_u2f(0u));
@@ -380,11 +418,16 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
     const bool qs = keep && sr.pending;
     const uint64_t ms = __ballot(qs);
     if (qs) wb.shadow[seg * 64u + (uint32_t)__popcll(ms & below)] = slot;
+    const uint64_t mk = __ballot(keep);
     if (lane == 0u && seg < wb.n_seg) {
         wb.cnt_closest[seg] = (uint32_t)__popcll(mc);
         wb.cnt_shadow[seg] = (uint32_t)__popcll(ms);
-        if (__ballot(keep) != 0ull) wb.any_active[parity] = 1u;
+        if (mk != 0ull) wb.any_active[parity] = 1u;
     }
+#ifdef RPT_PROFILE_BLOCKS
+    }                                                               // (closes the PB_PASS scope before the flush)
+    RPT_PROF_FLUSH();
+#endif
 }
 
 // SDF scenes, resumable march (dev_sdf_path.h).  Per lane:
@@ -863,8 +906,9 @@ hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const 
     (void)hipGetLastError();
     const dim3 wg(256), all((wb.n_seg * 64u + 255u) / 256u), walkers(kWalkGroups * (blocks_per_group ? blocks_per_group : 1u));
     hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, 0u, 1u);
-    // a sample takes at most max_depth walks of its path ray plus one for its last shadow ray
-    const uint64_t bound = (uint64_t)rp.spp * (sc.max_depth + 1u);
+    // a sample takes at most max_depth walks of its path ray; its last shadow ray is walked beside the next sample's first
+    // ray, except the launch's last sample's
+    const uint64_t bound = (uint64_t)rp.spp * sc.max_depth + 1u;
     uint32_t host_active = 1u;
     for (uint64_t k = 1; k <= bound; ++k) {
         const uint32_t parity = (uint32_t)(k & 1u);

@@ -53,10 +53,15 @@ e0.record(); t.render_n(buf, spp); e1.record(); torch.cuda.synchronize()
 assert lib.rpt_prof_read(out) == 0
 n_samples = w * h * spp
 print("profiled build, %s: %dx%d x %d spp in %.2f ms (%.0f Msamples/s with the counters on)" % (which, w, h, spp, e0.elapsed_time(e1), n_samples / e0.elapsed_time(e1) / 1e3))
-pass_cycles = out[BLOCKS.index("WALK wave (wavefront)" if which == "c5w" else "PASS") * 3 + 2]
+pass_cycles = out[BLOCKS.index("PASS") * 3 + 2]
+if which == "c5w":
+    print("wavefront form: TRACE = load + geometry finish, SHADE = shading, finish+camera = blend, make_frame = next camera path, grid begin = "
+          "tests before the walk; PASS = the shade kernel's waves (shares below are of THAT, the WALK rows are of the WALK waves' time)")
+walk_cycles = out[BLOCKS.index("WALK wave (wavefront)") * 3 + 2]
 print("%-20s %12s %9s %8s %10s %12s" % ("block", "wave execs", "lanes/64", "share", "execs/smp", "lane-exec/smp"))
 for i, name in enumerate(BLOCKS):
     ex, ln, cy = out[i * 3], out[i * 3 + 1], out[i * 3 + 2]
     if ex == 0:
         continue
-    print("%-20s %12d %8.1f%% %7.1f%% %10.3f %12.3f" % (name, ex, 100.0 * ln / (64.0 * ex), 100.0 * cy / pass_cycles, 64.0 * ex / n_samples, ln / n_samples))
+    denom = walk_cycles if (i >= BLOCKS.index("WALK wave (wavefront)") and walk_cycles) else pass_cycles
+    print("%-20s %12d %8.1f%% %7.1f%% %10.3f %12.3f" % (name, ex, 100.0 * ln / (64.0 * ex), 100.0 * cy / denom, 64.0 * ex / n_samples, ln / n_samples))
