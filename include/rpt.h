@@ -230,11 +230,15 @@ enum {
      * the path, otherwise throughput = throughput / q.  Same expectation, different samples: OFF (the default) is
      * the reference.  Worth it for deep paths (max_depth > 4). */
     RPT_RENDER_RUSSIAN_ROULETTE = 1u << 5,
-    /* Large scenes with a grid (more than 64 spheres): render as a WAVEFRONT — the grid walks in a kernel of their own over
-     * ray lists in HBM, the rest of a bounce in a shading kernel — instead of inside the megakernel.  Same
-     * image bit for bit.  Needs 168 B of device memory per pixel of the tile while it runs (kept by the context).  Ignored
-     * for scenes that have no grid. */
-    RPT_RENDER_LARGE_WAVEFRONT = 1u << 6
+    /* Large scenes with a grid (64 spheres or more) have two forms, same image bit for bit:
+     *   megakernel — the grid walks inside the path-regenerating kernel, like everything else;
+     *   wavefront  — the grid walks in a kernel of their own over ray lists in HBM, the rest of a bounce in a shading
+     *                kernel; needs 168 B of device memory per pixel of the tile while it runs (kept by the context) and
+     *                1 + 2 * (spp * max_depth + 1) launches, so it pays from about 1.5 M pixels per device up.
+     * Default: wavefront for tiles of at least 1.5 M pixels, megakernel below.  These two flags force one form (both set:
+     * RPT_ERR_INVALID_ARG); scenes without a grid ignore them. */
+    RPT_RENDER_LARGE_WAVEFRONT = 1u << 6,
+    RPT_RENDER_LARGE_MEGAKERNEL = 1u << 7
 };
 
 /* ---- context --------------------------------------------------------------- */

@@ -177,13 +177,17 @@ static uint32_t sdf_pool_shade_lanes() { static const uint32_t v = env_lanes("RP
 static uint32_t sdf_pool_resolve_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_RESOLVE_LANES", 16); return v; }
 static uint32_t sdf_pool_min_batch() { static const uint32_t v = env_lanes("RPT_SDF_POOL_MIN_BATCH", 32); return v; }
 static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_POOL_PATIENCE") ? (uint32_t)atoi(getenv("RPT_SDF_POOL_PATIENCE")) : 8u; return v; }
-// RPT_LARGE_FORM=wavefront|megakernel overrides the render flag (A/B runs of unmodified callers).
-static bool wavefront_wanted(uint32_t flags)
+// Which form a large scene with a grid takes (include/rpt.h).  RPT_LARGE_FORM=wavefront|megakernel overrides flags and
+// default (A/B runs of unmodified callers).
+constexpr uint64_t kWavefrontMinPixels = 3ull << 19;                // 1.5 M
+static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels)
 {
     static const char* form = getenv("RPT_LARGE_FORM");
     if (form && form[0] == 'w') return true;
     if (form && form[0] == 'm') return false;
-    return (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
+    if (flags & RPT_RENDER_LARGE_WAVEFRONT) return true;
+    if (flags & RPT_RENDER_LARGE_MEGAKERNEL) return false;
+    return tile_pixels >= kWavefrontMinPixels;
 }
 // ---- descriptor -> device tables ---------------------------------------------------------------------------
 static DevPlane dev_plane(const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; }
@@ -374,7 +378,11 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
 #endif
     const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
     // wavefront form of large scenes with a grid (max_depth == 0 has no bounce loop: the megakernel's prologue does that)
-    const bool wavefront = wavefront_wanted(flags) && ctx->large && scl.use_accel && !nested && scl.max_depth != 0u;
+    if ((flags & RPT_RENDER_LARGE_WAVEFRONT) && (flags & RPT_RENDER_LARGE_MEGAKERNEL)) {
+        set_err(ctx, "render: RPT_RENDER_LARGE_WAVEFRONT and RPT_RENDER_LARGE_MEGAKERNEL exclude each other");
+        return RPT_ERR_INVALID_ARG;
+    }
+    const bool wavefront = ctx->large && scl.use_accel && !nested && scl.max_depth != 0u && wavefront_wanted(flags, (uint64_t)rp.rows_local * width);
     WfBuffers wb;
     if (wavefront) {
         const uint64_t n_slots = (uint64_t)rp.rows_local * width;

@@ -40,7 +40,7 @@ struct WfBuffers {
     float4* sh_d;              //           direction; w: bits of "occluded" (written by WALK)
     float4* c_lit;             //           the parked next-event contribution
     float4* prev;              //           radiance of the pixel's previous sample while its last shadow ray is out (ctl.w bit 3)
-    uint4* ctl;                //           rng key, rng counter, bounce, sample << 4 | previous parked << 3 | shadow pending << 2 | status
+    uint4* ctl;                //           rng key, rng counter, bounce, sample << 8 | previous parked << 3 | shadow pending << 2 | status
     uint32_t* closest;         // [n_seg * 64] slots whose path ray needs a grid walk, per segment
     uint32_t* shadow;          // [n_seg * 64] slots whose shadow ray needs a grid walk
     uint32_t* cnt_closest;     // [n_seg] entries in each segment
@@ -88,6 +88,24 @@ RPT_DEV bool closest_before_walk(const SceneLarge& sc, const RayD& ray, float& d
         if (i != 0u && hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (t < dist || (t == dist && i < best))) { dist = t; best = i; }
     }
     return true;
+}
+
+// path_trace_geom (dev_integrator.h) with the miss left to the caller: 0 the ray left the scene (the background is still to
+// be added), 1 it ended on an emitter (radiance updated), 2 a surface was hit.
+RPT_DEV uint32_t path_trace_geom_split(const SceneLarge& sc, const WaveQuery& q, PathRegs& p, GeomHit& g)
+{
+    EmitterHit e;
+    e.is_emitter = false;
+    e.light_pdf = 0.0f;
+    e.light_emission = mk3(0.0f, 0.0f, 0.0f);
+    if (!q.geom(sc, p.ray, p.ps, g, e)) return 0u;
+    if (e.is_emitter) {
+        p.radiance = p.radiance + hit_emission(sc, g) * p.throughput;                      // tracer.rs:74
+        const float mis_weight = power_heuristic(p.ps.scatter_pdf, e.light_pdf);
+        p.radiance = p.radiance + (mis_weight * e.light_emission) * p.throughput;
+        return 1u;
+    }
+    return 2u;
 }
 
 struct ShadowReq {

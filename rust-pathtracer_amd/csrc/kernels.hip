@@ -288,134 +288,227 @@ __global__ __launch_bounds__(256, RPT_WF_WALK_WAVES_PER_SIMD) void RPT_K(wf_walk
     RPT_PROF_FLUSH();
 }
 
-// One thread per slot (= pixel of the tile).  `first`: every slot starts sample 0 of its pixel (no state to read).
+// One workgroup per 256 slots (= pixels of the tile), in four stages with the workgroup's slots RE-DEALT to its threads in
+// between, so that each expensive block runs on full waves whatever the mix of outcomes:
+//   G  every thread, its own slot: load the path, add the parked light sample, finish closest_hit (planes, lights);
+//      outcome: surface hit -> list S, path over (miss / emitter / waiting sample) -> list F
+//   S  thread t < |S|: entry t of list S: material, next-event estimation, BSDF sample; path over -> list F
+//   F  thread t < |F|: entry t of list F: background, blend into the pixel's running mean, next camera path
+//   P  every thread, its own slot: tests before the grid walk, store the path, this wave's ray segments
+// Paths travel between stages through LDS (19 dwords each).  `first`: every slot starts sample 0 (nothing to read).
+enum : uint32_t { WFF_PENDING = 4u, WFF_PARK = 8u, WFF_NEWRAY = 16u, WFF_MISS = 32u, WFF_BLEND = 64u };   // record flags above the status bits
+
+struct WfRecords {
+    float f[14][256];          // ray o, d; throughput; radiance; hit_dist; scatter pdf
+    uint32_t u[5][256];        // rng key, counter; bounce; GeomHit; sample << 8 | flags | status
+};
+
+RPT_DEV void wf_rec_put(WfRecords& r, uint32_t i, const PathRegs& p, uint32_t gcode, uint32_t ctl)
+{
+    r.f[0][i] = p.ray.o.x; r.f[1][i] = p.ray.o.y; r.f[2][i] = p.ray.o.z;
+    r.f[3][i] = p.ray.d.x; r.f[4][i] = p.ray.d.y; r.f[5][i] = p.ray.d.z;
+    r.f[6][i] = p.throughput.x; r.f[7][i] = p.throughput.y; r.f[8][i] = p.throughput.z;
+    r.f[9][i] = p.radiance.x; r.f[10][i] = p.radiance.y; r.f[11][i] = p.radiance.z;
+    r.f[12][i] = p.ps.hit_dist; r.f[13][i] = p.ps.scatter_pdf;
+    r.u[0][i] = p.rng.key; r.u[1][i] = p.rng.counter; r.u[2][i] = p.bounce; r.u[3][i] = gcode; r.u[4][i] = ctl;
+}
+
+RPT_DEV void wf_rec_get(const WfRecords& r, uint32_t i, PathRegs& p, uint32_t& gcode, uint32_t& ctl)
+{
+    p.ray.o = mk3(r.f[0][i], r.f[1][i], r.f[2][i]);
+    p.ray.d = mk3(r.f[3][i], r.f[4][i], r.f[5][i]);
+    p.throughput = mk3(r.f[6][i], r.f[7][i], r.f[8][i]);
+    p.radiance = mk3(r.f[9][i], r.f[10][i], r.f[11][i]);
+    p.ps.hit_dist = r.f[12][i]; p.ps.scatter_pdf = r.f[13][i];
+    p.rng.key = r.u[0][i]; p.rng.counter = r.u[1][i]; p.bounce = r.u[2][i]; gcode = r.u[3][i]; ctl = r.u[4][i];
+}
+
+// append `value` to a workgroup list in LDS for the lanes that `want` (one LDS atomic per wave)
+RPT_DEV void wf_list_add(uint32_t* list, uint32_t* count, bool want, uint32_t value)
+{
+    const uint64_t m = __ballot(want);
+    if (m == 0ull) return;
+    const uint32_t lane = __lane_id();
+    const uint32_t leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+    uint32_t base = 0u;
+    if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, (int)leader);
+    if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+}
+
 __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_shade_kernel)(const SceneLarge sc, const RenderParams rp, const WfBuffers wb, uint32_t parity, uint32_t first)
 {
-    RPT_PROF_INIT();
-#ifdef RPT_PROFILE_BLOCKS
-    __syncthreads();
-#endif
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    __shared__ WfRecords rec;
+    __shared__ uint32_t l_shade[256], l_fin[256];
+    __shared__ uint32_t n_lists[2];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t slot0 = blockIdx.x * 256u;
+    const uint32_t slot = slot0 + tid;
     if (slot < kWalkGroups) wb.group_next[slot * kWalkCounterStride] = 0u;     // the next WALK's segment counters (the previous WALK is over)
+    if (tid < 2u) n_lists[tid] = 0u;
+    __syncthreads();
+
+    // ---- G
     const bool in_tile = slot < wb.n_slots;
-    uint4 c = make_uint4(0u, 0u, 0u, WF_DONE);
-    if (in_tile && !first) c = wb.ctl[slot];
-    const bool live = in_tile && (first || (c.w & 3u) != WF_DONE);
-
-    PathRegs p;
-    GeomHit g;
-    g.code = 0u;
-    uint32_t s = 0u, status = WF_WALKING;
-    bool want_shade = false, want_finish = false, want_begin = live && first, new_ray = false, walk_closest = false;
-    ShadowReq sr;
-    sr.pending = false;
-    float dist = 0.0f;
-    uint32_t best = 0xFFFFFFFFu;
-    bool park = false;
-    v3 prev_rad = mk3(0.0f, 0.0f, 0.0f);
-#ifdef RPT_PROFILE_BLOCKS
+    bool live = in_tile;
     {
-#endif
-    RPT_PROF(PB_PASS);
-    if (live && !first) {
-        RPT_PROF(PB_TRACE);
-        const float4 a = wb.ray_o[slot], b = wb.ray_d[slot], t = wb.thr[slot], r = wb.rad[slot];
-        p.ray.o = mk3(a.x, a.y, a.z); p.ray.d = mk3(b.x, b.y, b.z);
-        p.throughput = mk3(t.x, t.y, t.z); p.ps.hit_dist = t.w;
-        p.radiance = mk3(r.x, r.y, r.z); p.ps.scatter_pdf = r.w;
-        p.rng.key = c.x; p.rng.counter = c.y; p.bounce = c.z;
-        s = c.w >> 4; status = c.w & 3u;
-        // last bounce's light sample: visible unless its walk found an occluder
-        const bool lit = (c.w & 4u) && rpt_f2u(wb.sh_d[slot].w) == 0u;
-        v3 gain = mk3(0.0f, 0.0f, 0.0f);
-        if (lit) { const float4 cl = wb.c_lit[slot]; gain = mk3(cl.x, cl.y, cl.z); }
-        if (c.w & 8u) {
-            // that light sample belonged to the PREVIOUS sample of the pixel, which ended there: it is blended now (the
-            // current sample was started at once, in its place: tracer.rs:105-117 still sees the samples in order)
-            const float4 pr = wb.prev[slot];
-            v3 r = mk3(pr.x, pr.y, pr.z);
-            if (lit) r = r + gain;
-            const uint64_t frames = rp.frames_done + (s - 1u);
-            float4* pixel = reinterpret_cast<float4*>(rp.pixels) + slot;
-            float4 acc = *pixel;
-            blend(acc, r, 1.0f / (float)(frames + 1));
-            *pixel = acc;
-        } else if (lit) {
-            p.radiance = p.radiance + gain;
-        }
-        if (status == WF_ENDING) {
-            want_finish = true;
-        } else {
-            const WaveQuery q{a.w, rpt_f2u(b.w)};
-            if (path_trace_geom(sc, q, p, g)) want_shade = true;
-            else want_finish = true;
-        }
-    }
-    if (want_shade) {
-        RPT_PROF(PB_SHADE);
-        if (path_shade_deferred(sc, p, g, sr)) {
-            if (!sr.pending) {
-                want_finish = true;
-            } else if (s + 1u < rp.spp) {                           // over once its last shadow ray is answered: park it, start the next sample
-                prev_rad = p.radiance;
-                park = true;
-                s += 1u;
-                want_begin = true;
+        uint4 c = make_uint4(0u, 0u, 0u, WF_DONE);
+        if (in_tile && !first) c = wb.ctl[slot];
+        live = in_tile && (first || (c.w & 3u) != WF_DONE);
+        bool to_shade = false, to_fin = false;
+        if (live) {
+            PathRegs p;
+            GeomHit g;
+            g.code = 0u;
+            uint32_t ctl;
+            if (first) {
+                p.ray.o = p.ray.d = p.throughput = p.radiance = mk3(0.0f, 0.0f, 0.0f);
+                p.ps.hit_dist = 0.0f; p.ps.scatter_pdf = 0.0f;
+                p.rng.key = 0u; p.rng.counter = 0u; p.bounce = 0u;
+                ctl = WF_WALKING;                                   // sample 0, nothing to blend: F starts its camera path
+                to_fin = true;
             } else {
-                status = WF_ENDING;                                 // the launch's last sample waits for the answer
+                const float4 a = wb.ray_o[slot], b = wb.ray_d[slot], t = wb.thr[slot], r = wb.rad[slot];
+                p.ray.o = mk3(a.x, a.y, a.z); p.ray.d = mk3(b.x, b.y, b.z);
+                p.throughput = mk3(t.x, t.y, t.z); p.ps.hit_dist = t.w;
+                p.radiance = mk3(r.x, r.y, r.z); p.ps.scatter_pdf = r.w;
+                p.rng.key = c.x; p.rng.counter = c.y; p.bounce = c.z;
+                const uint32_t s = c.w >> 8;
+                const uint32_t status = c.w & 3u;
+                // last bounce's light sample: visible unless its walk found an occluder
+                const bool lit = (c.w & WFF_PENDING) && rpt_f2u(wb.sh_d[slot].w) == 0u;
+                v3 gain = mk3(0.0f, 0.0f, 0.0f);
+                if (lit) { const float4 cl = wb.c_lit[slot]; gain = mk3(cl.x, cl.y, cl.z); }
+                if (c.w & WFF_PARK) {
+                    // that light sample belonged to the PREVIOUS sample of the pixel, which ended there: it is blended now (the
+                    // current sample was started at once, in its place: tracer.rs:105-117 still sees the samples in order)
+                    const float4 pr = wb.prev[slot];
+                    v3 r2 = mk3(pr.x, pr.y, pr.z);
+                    if (lit) r2 = r2 + gain;
+                    const uint64_t frames = rp.frames_done + (s - 1u);
+                    float4* pixel = reinterpret_cast<float4*>(rp.pixels) + slot;
+                    float4 acc = *pixel;
+                    blend(acc, r2, 1.0f / (float)(frames + 1));
+                    *pixel = acc;
+                } else if (lit) {
+                    p.radiance = p.radiance + gain;
+                }
+                ctl = (s << 8) | status;
+                if (status == WF_ENDING) {
+                    ctl |= WFF_BLEND;
+                    to_fin = true;
+                } else {
+                    const WaveQuery q{a.w, rpt_f2u(b.w)};
+                    const uint32_t what = path_trace_geom_split(sc, q, p, g);
+                    if (what == 2u) to_shade = true;
+                    else { to_fin = true; ctl |= WFF_BLEND | (what == 0u ? WFF_MISS : 0u); }
+                }
             }
-        } else {
-            new_ray = true;
+            wf_rec_put(rec, tid, p, g.code, ctl);
         }
+        wf_list_add(l_shade, &n_lists[0], to_shade, tid);
+        wf_list_add(l_fin, &n_lists[1], to_fin, tid);
     }
-    if (want_finish) {                                              // tracer.rs:105-117 on this pixel's running mean, then its next sample
-        RPT_PROF(PB_FINISH);
-        const uint64_t frames = rp.frames_done + s;
-        float4* pixel = reinterpret_cast<float4*>(rp.pixels) + slot;
-        float4 acc = *pixel;
-        blend(acc, p.radiance, 1.0f / (float)(frames + 1));
-        *pixel = acc;
-        s += 1u;
-        if (s >= rp.spp) status = WF_DONE;
-        else want_begin = true;
-    }
-    if (want_begin) {
-        RPT_PROF(PB_FRAME);
-        float px, py;
-        uint32_t pixel_index;
-        pixel_coords(rp, slot % rp.width, slot / rp.width, px, py, pixel_index);
-        path_begin(sc, p, px, py, frame_key_hd(rp.seed, rp.frames_done + s), pixel_index);
-        status = WF_WALKING;
-        new_ray = true;
-    }
-    if (new_ray) {
-        RPT_PROF(PB_GRID_BEGIN);
-        walk_closest = closest_before_walk(sc, p.ray, dist, best);
-    }
+    __syncthreads();
 
-    const bool keep = live && status != WF_DONE;
+    // ---- S
+    {
+        const bool mine = tid < n_lists[0];
+        bool to_fin = false;
+        uint32_t i = 0u;
+        if (mine) {
+            i = l_shade[tid];
+            PathRegs p;
+            uint32_t gcode, ctl;
+            wf_rec_get(rec, i, p, gcode, ctl);
+            GeomHit g;
+            g.code = gcode;
+            ShadowReq sr;
+            const bool over = path_shade_deferred(sc, p, g, sr);
+            const uint32_t si = slot0 + i;
+            if (sr.pending) {
+                wb.sh_o[si] = make_float4(sr.ray.o.x, sr.ray.o.y, sr.ray.o.z, sr.max_dist);
+                wb.sh_d[si] = make_float4(sr.ray.d.x, sr.ray.d.y, sr.ray.d.z, rpt_u2f(0u));
+                wb.c_lit[si] = make_float4(sr.c_lit.x, sr.c_lit.y, sr.c_lit.z, 0.0f);
+                ctl |= WFF_PENDING;
+            }
+            if (!over) {
+                ctl |= WFF_NEWRAY;
+            } else if (!sr.pending) {
+                ctl |= WFF_BLEND;
+                to_fin = true;
+            } else if ((ctl >> 8) + 1u < rp.spp) {                  // over once its last shadow ray is answered: park it, start the next sample
+                wb.prev[si] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, 0.0f);
+                ctl = (((ctl >> 8) + 1u) << 8) | (ctl & 0xFFu) | WFF_PARK;
+                to_fin = true;                                      // (no WFF_BLEND: F only starts the next camera path)
+            } else {
+                ctl = (ctl & ~3u) | WF_ENDING;                      // the launch's last sample waits for the answer
+            }
+            wf_rec_put(rec, i, p, gcode, ctl);
+        }
+        wf_list_add(l_fin, &n_lists[1], to_fin, i);
+    }
+    __syncthreads();
+
+    // ---- F
+    if (tid < n_lists[1]) {
+        const uint32_t i = l_fin[tid];
+        PathRegs p;
+        uint32_t gcode, ctl;
+        wf_rec_get(rec, i, p, gcode, ctl);
+        uint32_t s = ctl >> 8;
+        bool begin = true;
+        if (ctl & WFF_MISS) p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
+        if (ctl & WFF_BLEND) {                                      // tracer.rs:105-117 on this pixel's running mean, then its next sample
+            const uint64_t frames = rp.frames_done + s;
+            float4* pixel = reinterpret_cast<float4*>(rp.pixels) + (slot0 + i);
+            float4 acc = *pixel;
+            blend(acc, p.radiance, 1.0f / (float)(frames + 1));
+            *pixel = acc;
+            s += 1u;
+            begin = s < rp.spp;
+        }
+        ctl = (s << 8) | (ctl & (WFF_PENDING | WFF_PARK));
+        if (begin) {
+            float px, py;
+            uint32_t pixel_index;
+            const uint32_t pix = slot0 + i;
+            pixel_coords(rp, pix % rp.width, pix / rp.width, px, py, pixel_index);
+            path_begin(sc, p, px, py, frame_key_hd(rp.seed, rp.frames_done + s), pixel_index);
+            ctl |= WF_WALKING | WFF_NEWRAY;
+        } else {
+            ctl |= WF_DONE;
+        }
+        wf_rec_put(rec, i, p, gcode, ctl);
+    }
+    __syncthreads();
+
+    // ---- P
+    bool keep = false, qc = false, qs = false;
     if (live) {
-        wb.ctl[slot] = make_uint4(p.rng.key, p.rng.counter, p.bounce, (s << 4) | (park ? 8u : 0u) | (sr.pending ? 4u : 0u) | status);
+        PathRegs p;
+        uint32_t gcode, ctl;
+        wf_rec_get(rec, tid, p, gcode, ctl);
+        float dist = 0.0f;
+        uint32_t best = 0xFFFFFFFFu;
+        bool walk_closest = false;
+        if (ctl & WFF_NEWRAY) walk_closest = closest_before_walk(sc, p.ray, dist, best);
+        keep = (ctl & 3u) != WF_DONE;
+        wb.ctl[slot] = make_uint4(p.rng.key, p.rng.counter, p.bounce, ctl & ~(WFF_NEWRAY | WFF_MISS | WFF_BLEND));
         if (keep) {
             wb.ray_o[slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, dist);
             wb.ray_d[slot] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, rpt_u2f(best));
             wb.thr[slot] = make_float4(p.throughput.x, p.throughput.y, p.throughput.z, p.ps.hit_dist);
             wb.rad[slot] = make_float4(p.radiance.x, p.radiance.y, p.radiance.z, p.ps.scatter_pdf);
-            if (park) wb.prev[slot] = make_float4(prev_rad.x, prev_rad.y, prev_rad.z, 0.0f);
-            if (sr.pending) {
-                wb.sh_o[slot] = make_float4(sr.ray.o.x, sr.ray.o.y, sr.ray.o.z, sr.max_dist);
-                wb.sh_d[slot] = make_float4(sr.ray.d.x, sr.ray.d.y, sr.ray.d.z, rpt_u2f(0u));
-                wb.c_lit[slot] = make_float4(sr.c_lit.x, sr.c_lit.y, sr.c_lit.z, 0.0f);
-            }
         }
+        qc = keep && (ctl & WFF_NEWRAY) && walk_closest;
+        qs = keep && (ctl & WFF_PENDING);
     }
     // this wave's segment of the two ray lists (dev_wavefront.h)
-    const uint32_t seg = slot >> 6, lane = threadIdx.x & 63u;
+    const uint32_t seg = slot >> 6, lane = tid & 63u;
     const uint64_t below = (1ull << lane) - 1ull;
-    const bool qc = keep && new_ray && walk_closest;
     const uint64_t mc = __ballot(qc);
     if (qc) wb.closest[seg * 64u + (uint32_t)__popcll(mc & below)] = slot;
-    const bool qs = keep && sr.pending;
     const uint64_t ms = __ballot(qs);
     if (qs) wb.shadow[seg * 64u + (uint32_t)__popcll(ms & below)] = slot;
     const uint64_t mk = __ballot(keep);
@@ -424,10 +517,6 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
         wb.cnt_shadow[seg] = (uint32_t)__popcll(ms);
         if (mk != 0ull) wb.any_active[parity] = 1u;
     }
-#ifdef RPT_PROFILE_BLOCKS
-    }                                                               // (closes the PB_PASS scope before the flush)
-    RPT_PROF_FLUSH();
-#endif
 }
 
 // SDF scenes, resumable march (dev_sdf_path.h).  Per lane:

@@ -290,14 +290,36 @@ def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
     s = scenes.random_spheres_scene(n_spheres=n_spheres, n_lights=n_lights, seed=0x5EED0005)
     w, h, spp = 96, 54, 3
     t = rpt.Tracer(s, device=0, seed=5)
-    # default: the grid walk inside the bounce (from 64 spheres up); then nested loops; then the wavefront form (walks in their
-    # own kernel; scenes without a grid ignore the flag)
-    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS, rpt._abi.RPT_RENDER_LARGE_WAVEFRONT):
+    # the default form (at this size: the grid walk inside the megakernel, from 64 spheres up); nested loops; then both forms
+    # forced: the wavefront (walks in their own kernel) and the megakernel (scenes without a grid ignore the two flags)
+    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS, rpt._abi.RPT_RENDER_LARGE_WAVEFRONT, rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
         want = oracle.render(s.describe(), w, h, spp, seed=5)
         assert_bit_identical(buf.image(), want, "large scene %d spheres flags=%d" % (n_spheres, flags))
+    t.close()
+
+
+@pytest.mark.parametrize("w,h,spp,depth,rr", [(70, 37, 5, 4, False), (33, 65, 3, 9, True), (200, 120, 2, 1, False), (64, 64, 40, 30, True)])
+def test_large_scene_wavefront_form_matches_oracle(rpt, oracle, w, h, spp, depth, rr):
+    """The wavefront form of large scenes (include/rpt.h RPT_RENDER_LARGE_WAVEFRONT) over ragged tiles (sizes that are not
+    multiples of the 64-slot segments), depth 1, deep paths with Russian roulette (the launch bound gets long enough for the
+    early-out read-back), and a resumed accumulation: bit-identical to the oracle."""
+    from rust_pathtracer_amd import scenes
+    s = scenes.random_spheres_scene(n_spheres=400, n_lights=5, seed=0x5EED0007)
+    s.max_depth = depth
+    rflags = rpt._abi.RPT_RENDER_RUSSIAN_ROULETTE if rr else 0
+    t = rpt.Tracer(s, device=0, seed=9)
+    t.flags = rpt._abi.RPT_RENDER_LARGE_WAVEFRONT | rflags
+    buf = rpt.ColorBuffer(w, h)
+    t.render_n(buf, spp)
+    t.render_n(buf, 2)                                                # resumes at frames_done = spp
+    want = oracle.render(s.describe(), w, h, spp + 2, seed=9, render_flags=rflags)
+    assert_bit_identical(buf.image(), want, "wavefront %dx%d spp %d depth %d" % (w, h, spp, depth))
+    t.flags |= rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL
+    with pytest.raises(rpt.RptError):
+        t.render_n(rpt.ColorBuffer(w, h), 1)
     t.close()
 
 

@@ -9,7 +9,7 @@ w, h, spp = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])) if len(sys.ar
 s = scenes.random_spheres_scene(10000, 16)
 t = rpt.Tracer(s, device=0, seed=1)
 imgs = {}
-for name, flags in (("megakernel", 0), ("wavefront", rpt._abi.RPT_RENDER_LARGE_WAVEFRONT)):
+for name, flags in (("megakernel", rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL), ("wavefront", rpt._abi.RPT_RENDER_LARGE_WAVEFRONT)):
     t.flags = flags
     buf = rpt.DeviceColorBuffer(w, h)
     t.render_n(buf, spp); torch.cuda.synchronize()          # warm (allocations)
