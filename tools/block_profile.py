@@ -55,8 +55,7 @@ n_samples = w * h * spp
 print("profiled build, %s: %dx%d x %d spp in %.2f ms (%.0f Msamples/s with the counters on)" % (which, w, h, spp, e0.elapsed_time(e1), n_samples / e0.elapsed_time(e1) / 1e3))
 pass_cycles = out[BLOCKS.index("PASS") * 3 + 2]
 if which == "c5w":
-    print("wavefront form: TRACE = load + geometry finish, SHADE = shading, finish+camera = blend, make_frame = next camera path, grid begin = "
-          "tests before the walk; PASS = the shade kernel's waves (shares below are of THAT, the WALK rows are of the WALK waves' time)")
+    print("wavefront form: the WALK rows are shares of the walk kernel's wave time (the shading kernel carries no scopes of its own)")
 walk_cycles = out[BLOCKS.index("WALK wave (wavefront)") * 3 + 2]
 print("%-20s %12s %9s %8s %10s %12s" % ("block", "wave execs", "lanes/64", "share", "execs/smp", "lane-exec/smp"))
 for i, name in enumerate(BLOCKS):
