@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
+GPU_CLOCK_HZ = 2.4e9           # the same table's engine clock (the PMC passes measured 2.37e9 under this kernel)
 C2 = (1920, 1080, 256)         # BASELINE.json configs[1]
 C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
 TRAFFIC_JSON = os.path.join("profiles", "r2", "c2_bench", "traffic.json")
@@ -356,6 +357,18 @@ def main():
             roofline["traffic"] = t["hbm_bytes_per_launch"]
             roofline["traffic_source"] = "%s: rocprofv3 PMC passes of this command, committed (%s); bench.py cannot collect counters itself" % (
                 TRAFFIC_JSON, t["correction"])
+            if "valu_insts_per_launch" in t:
+                # How busy the vector ALUs are, from the same committed PMC passes and THIS run's kernel time: a SIMD issues one
+                # wave64 VALU instruction per quad-cycle, two when two waves have one ready (SQ_ACTIVE_INST_VALU2), which is
+                # what the 157 TFLOP/s peak assumes.  SIMD cycles = 1 024 SIMDs x kernel time x the clock.
+                simd_quads = 1024.0 * avg_kernel_s * GPU_CLOCK_HZ / 4.0
+                roofline["valu_issue"] = {
+                    "insts_per_launch": t["valu_insts_per_launch"], "lane_utilisation": round(t.get("valu_lane_utilisation", 0.0), 3),
+                    "insts_per_simd_quad_cycle": round(t["valu_insts_per_launch"] / simd_quads, 3),
+                    "frac_of_dual_issue_peak": round(t["valu_insts_per_launch"] / simd_quads / 2.0, 3),
+                    "note": "VALU wave-instructions per SIMD per 4 cycles (rocprofv3's VALUBusy / 100); 2.0 is the issue peak, "
+                            "reached only with every instruction dual-issued and no dependency or memory stall; x lane_utilisation "
+                            "= the share of the ALU lanes doing path work"}
         out = {
             "metric": "Msamples/s (pixels x spp) on AnalyticalScene 1920x1080 f32; 1/2/4/8-GPU scaling",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -283,7 +283,11 @@ __global__ __launch_bounds__(256, RPT_WF_WALK_WAVES_PER_SIMD) void RPT_K(wf_walk
 #ifdef RPT_PROFILE_BLOCKS
     __syncthreads();
 #endif
-    if (blockIdx.x == 0 && threadIdx.x == 0) wb.any_active[parity] = 0u;       // SHADE(k) raises it again if anything is left
+    // any_active[p]: raised by SHADE(k), k & 1 == p, when a slot still has work.  Once a SHADE leaves it down, every later launch of
+    // the sequence returns at once (the host enqueues the worst-case number of iterations without looking).
+    const bool idle = wb.any_active[parity ^ 1u] == 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) wb.any_active[parity] = 0u;
+    if (idle) return;
     wf_walk_body(sc, wb, refill_at);
     RPT_PROF_FLUSH();
 }
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
     const uint32_t tid = threadIdx.x;
     const uint32_t slot0 = blockIdx.x * 256u;
     const uint32_t slot = slot0 + tid;
+    if (!first && wb.any_active[parity ^ 1u] == 0u) return;         // nothing was left after the previous SHADE (see wf_walk_kernel)
     if (slot < kWalkGroups) wb.group_next[slot * kWalkCounterStride] = 0u;     // the next WALK's segment counters (the previous WALK is over)
     if (tid < 2u) n_lists[tid] = 0u;
     __syncthreads();
@@ -988,7 +993,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     return hipGetLastError();
 }
 
-hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, hipStream_t st)
+hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, bool host_checks, hipStream_t st)
 {
     static const uint32_t refill_at = getenv("RPT_WF_REFILL_AT") ? (uint32_t)atoi(getenv("RPT_WF_REFILL_AT")) : 40u;
     static const uint32_t blocks_per_group = getenv("RPT_WF_BLOCKS_PER_GROUP") ? (uint32_t)atoi(getenv("RPT_WF_BLOCKS_PER_GROUP")) : 6u;
@@ -996,15 +1001,15 @@ hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const 
     const dim3 wg(256), all((wb.n_seg * 64u + 255u) / 256u), walkers(kWalkGroups * (blocks_per_group ? blocks_per_group : 1u));
     hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, 0u, 1u);
     // a sample takes at most max_depth walks of its path ray; its last shadow ray is walked beside the next sample's first
-    // ray, except the launch's last sample's
+    // ray, except the launch's last sample's.  Launches after the last useful iteration return at once (any_active); when the
+    // bound is long (deep paths that mostly end early) and the caller allows it, the host also looks every 256 iterations.
     const uint64_t bound = (uint64_t)rp.spp * sc.max_depth + 1u;
     uint32_t host_active = 1u;
     for (uint64_t k = 1; k <= bound; ++k) {
         const uint32_t parity = (uint32_t)(k & 1u);
         hipLaunchKernelGGL(RPT_K(wf_walk_kernel), walkers, wg, 0, st, sc, wb, parity, refill_at);
         hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, parity, 0u);
-        if ((k & 63u) == 0u && bound - k > 64u) {
-            // long bounds (deep paths) are mostly empty iterations: look at the flag SHADE(k) just wrote
+        if (host_checks && (k & 255u) == 0u && bound - k > 256u) {
             hipError_t e = hipMemcpyAsync(&host_active, &wb.any_active[parity], sizeof(uint32_t), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;

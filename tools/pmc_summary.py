@@ -44,6 +44,12 @@ if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
            "hbm_bytes_per_launch": g("FETCH_SIZE") * 1024 * 2 + g("WRITE_SIZE") * 1024,
            "correction": "FETCH_SIZE x2 (gfx950 half-count of 16 B/lane reads; uncalibrated for this kernel's 128-B row segments), WRITE_SIZE x1",
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh)"}
+    if g("SQ_INSTS_VALU"):
+        out["valu_insts_per_launch"] = g("SQ_INSTS_VALU")
+    if g("SQ_ACTIVE_INST_VALU"):
+        out["valu_active_quad_cycles_per_launch"] = g("SQ_ACTIVE_INST_VALU")
+    if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"):
+        out["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
     print("HBM bytes per launch         %.4g (2 x FETCH + WRITE)" % out["hbm_bytes_per_launch"])
 ks = os.path.join(d, "kernel_stats.csv")
