@@ -189,6 +189,8 @@ static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels)
     if (flags & RPT_RENDER_LARGE_MEGAKERNEL) return false;
     return tile_pixels >= kWavefrontMinPixels;
 }
+// Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel)
+static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 1u; return v; }
 // ---- descriptor -> device tables ---------------------------------------------------------------------------
 static DevPlane dev_plane(const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; }
 static DevLight dev_light(const rpt_light& a)
@@ -363,6 +365,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     rp.pool_min_batch = sdf_pool_min_batch();
     rp.pool_patience = sdf_pool_patience();
     rp.shade_threshold = shade_threshold();
+    rp.compact = ((flags & RPT_RENDER_SMALL_COMPACT) || spp <= compact_max_spp()) ? 1u : 0u;
     rp.march_min_lanes = sdf_march_min_lanes();
     if (flags & RPT_RENDER_RUSSIAN_ROULETTE) { scs.flags |= kSceneFlagRussianRoulette; scl.flags |= kSceneFlagRussianRoulette; }
     if (rp.rows_local == 0) return RPT_OK;

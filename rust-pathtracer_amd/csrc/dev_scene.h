@@ -123,6 +123,7 @@ struct RenderParams {
     uint32_t pool_resolve_lanes;
     uint32_t pool_min_batch;       // ... serves the queue when it can fill this many lanes with jobs ...
     uint32_t pool_patience;        // ... and after this many idle passes does whatever there is to do
+    uint32_t compact;              // small scenes: the kernel that re-deals its workgroup's paths before every stage (few samples per launch)
 };
 
 }  // namespace rptdev

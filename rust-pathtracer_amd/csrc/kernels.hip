@@ -524,6 +524,104 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
     }
 }
 
+// Small scenes, FEW samples per launch (the reference's own usage: one render() per redraw).  With nothing to regenerate a
+// wave of the megakernel drains: its lanes end one by one and the wave runs on for its longest path.  Here the workgroup's 256
+// paths live in LDS and are re-dealt to the threads before every stage, so TRACE and SHADE always run on full waves (the last one
+// of a list excepted) and waves that get nothing issue nothing:
+//   TRACE  thread t < |T|: entry t of the trace list: closest_hit; miss / emitter -> blend, the pixel's next sample (if any) -> next T
+//                                                                   surface -> S
+//   SHADE  thread t < |S|: entry t of the shade list: material, light sample, BSDF; path over -> blend, next sample -> next T;
+//                                                                   otherwise -> next T
+// Same device functions, same per-pixel order of samples: bit-identical to the other kernels.
+#ifndef RPT_COMPACT_WAVES_PER_SIMD
+#define RPT_COMPACT_WAVES_PER_SIMD 5
+#endif
+template <class S>
+RPT_DEV bool compact_finish(const S& sc, const RenderParams& rp, float4* s_acc, uint32_t i, PathRegs& p, uint32_t& s)
+{
+    float4 acc = s_acc[i];
+    const uint64_t frames = rp.frames_done + s;
+    blend(acc, p.radiance, 1.0f / (float)(frames + 1));             // tracer.rs:105-117
+    s_acc[i] = acc;
+    s += 1u;
+    if (s >= rp.spp) return false;
+    const PixelSetup ps = pixel_setup(rp, i);
+    path_begin(sc, p, ps.px, ps.py, frame_key_hd(rp.seed, rp.frames_done + s), ps.pixel_index);
+    return true;
+}
+
+__global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_kernel)(const SceneSmall sc, const RenderParams rp)
+{
+    __shared__ WfRecords rec;                                       // u[4] = the sample index of the pixel's current path
+    __shared__ float4 s_acc[256];
+    __shared__ uint32_t l_trace[2][256], l_shade[256];
+    __shared__ uint32_t n_trace[2], n_shade[2];
+    const uint32_t tid = threadIdx.x;
+    const PixelSetup ps = pixel_setup(rp);
+    float4* pixel = reinterpret_cast<float4*>(rp.pixels) + (ps.valid ? ps.pix_offset : 0);
+    if (sc.max_depth == 0) {                                        // no bounce loop: every sample's radiance is zero
+        if (ps.valid) {
+            float4 acc = *pixel;
+            for (uint32_t k = 0; k < rp.spp; ++k) blend(acc, mk3(0.0f, 0.0f, 0.0f), 1.0f / (float)(rp.frames_done + k + 1));
+            *pixel = acc;
+        }
+        return;
+    }
+    if (tid < 2u) { n_trace[tid] = 0u; n_shade[tid] = 0u; }
+    __syncthreads();
+    if (ps.valid) {
+        s_acc[tid] = *pixel;
+        PathRegs p;
+        path_begin(sc, p, ps.px, ps.py, frame_key_hd(rp.seed, rp.frames_done), ps.pixel_index);
+        wf_rec_put(rec, tid, p, 0u, 0u);
+    }
+    wf_list_add(l_trace[0], &n_trace[0], ps.valid, tid);
+    __syncthreads();
+
+    for (uint32_t cur = 0u;; cur ^= 1u) {
+        const uint32_t n_t = n_trace[cur];
+        if (n_t == 0u) break;                                       // (the same value in every thread: read behind a barrier)
+        {
+            bool to_shade = false, to_trace = false;
+            uint32_t i = 0u;
+            if (tid < n_t) {
+                i = l_trace[cur][tid];
+                PathRegs p;
+                uint32_t gcode, s;
+                wf_rec_get(rec, i, p, gcode, s);
+                GeomHit g;
+                g.code = 0u;
+                if (path_trace_geom(sc, DirectQuery{}, p, g)) to_shade = true;
+                else to_trace = compact_finish(sc, rp, s_acc, i, p, s);
+                if (to_shade || to_trace) wf_rec_put(rec, i, p, g.code, s);
+            }
+            wf_list_add(l_shade, &n_shade[cur], to_shade, i);
+            wf_list_add(l_trace[cur ^ 1u], &n_trace[cur ^ 1u], to_trace, i);
+        }
+        __syncthreads();
+        if (tid == 0u) { n_trace[cur] = 0u; n_shade[cur ^ 1u] = 0u; }       // both were last read before this barrier, next written after the next
+        {
+            const uint32_t n_s = n_shade[cur];
+            bool to_trace = false;
+            uint32_t i = 0u;
+            if (tid < n_s) {
+                i = l_shade[tid];
+                PathRegs p;
+                uint32_t gcode, s;
+                wf_rec_get(rec, i, p, gcode, s);
+                GeomHit g;
+                g.code = gcode;
+                if (path_shade_full(sc, DirectQuery{}, p, g)) to_trace = compact_finish(sc, rp, s_acc, i, p, s);
+                else to_trace = true;
+                if (to_trace) wf_rec_put(rec, i, p, 0u, s);
+            }
+            wf_list_add(l_trace[cur ^ 1u], &n_trace[cur ^ 1u], to_trace, i);
+        }
+        __syncthreads();
+    }
+    if (ps.valid) *pixel = s_acc[tid];
+}
+
 // SDF scenes, resumable march (dev_sdf_path.h).  Per lane:
 //   MARCH_P --(march over)--> RESOLVE --(miss / emitter)--> next sample: MARCH_P
 //                                     --(surface)--> MARCH_S --(march over)--> SHADE --> MARCH_P
@@ -984,6 +1082,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), tiles, wg, 0, st, scs, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), tiles, wg, 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
+    else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_kernel), tiles, wg, 0, st, sc, rp);
     else {
         // RPT_DEBUG_EXTRA_LDS (bytes, experiments only): pads the workgroup's LDS so that fewer waves fit a CU — how the
         // kernel's throughput depends on resident waves per SIMD (occupancy sensitivity)

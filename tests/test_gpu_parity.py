@@ -120,6 +120,21 @@ def test_render_matches_oracle(rpt, tracer, oracle, w, h, spp):
     assert_bit_identical(buf.image(), want, "render %dx%dx%d" % (w, h, spp))
 
 
+@pytest.mark.parametrize("w,h,spp", [(64, 48, 1), (100, 75, 3), (17, 9, 7), (160, 120, 5)])
+def test_compact_kernel_matches_oracle(rpt, oracle, w, h, spp):
+    """The kernel a one-sample launch of a small scene takes (paths re-dealt through LDS before every stage), forced at other
+    sample counts too so that its regeneration path runs; ragged tiles; resumed accumulation; with and without roulette."""
+    for rflags in (0, rpt._abi.RPT_RENDER_RUSSIAN_ROULETTE):
+        t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=4)
+        t.flags = rpt._abi.RPT_RENDER_SMALL_COMPACT | rflags
+        buf = rpt.ColorBuffer(w, h)
+        t.render_n(buf, spp)
+        t.render_n(buf, 1)
+        want = oracle.render(oracle.scene_analytical(), w, h, spp + 1, seed=4, render_flags=rflags)
+        assert_bit_identical(buf.image(), want, "compact kernel %dx%d spp %d flags %d" % (w, h, spp, rflags))
+        t.close()
+
+
 def test_render_800x600_1spp_config1(rpt, tracer, oracle):
     """BASELINE.json configs[0]: the reference's own window size, one render() call."""
     buf = rpt.ColorBuffer(800, 600)
