@@ -136,9 +136,11 @@ def test_bench_fallback_gather_gives_the_same_image(rpt, oracle, torch_cuda):
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
     import bench
     from rust_pathtracer_amd import tiling
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29631")
-    dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    import socket
+    with socket.socket() as sk:                                       # any free port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group(backend="gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
     try:
         w, h = 70, 37
         t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
