@@ -45,6 +45,32 @@ pub struct RptSceneDesc {
 #[repr(C)] #[derive(Clone, Copy)] pub struct RptUniqueId { pub bytes: [c_char; 128] }
 
 pub const RPT_ABI_VERSION: u32 = 2;
+// Constants of include/rpt.h (tests/test_rust_binding.py compares every one of them with the header).
+pub const RPT_OK: i32 = 0;
+pub const RPT_ERR_INVALID_ARG: i32 = -1;
+pub const RPT_ERR_NO_DEVICE: i32 = -2;
+pub const RPT_ERR_HIP: i32 = -3;
+pub const RPT_ERR_NO_SCENE: i32 = -4;
+pub const RPT_ERR_UNSUPPORTED: i32 = -5;
+pub const RPT_ERR_RCCL: i32 = -6;
+pub const RPT_MAT_ALL: u32 = 0x1FFF;
+pub const RPT_LIGHT_RECTANGULAR: u32 = 0;
+pub const RPT_LIGHT_SPHERICAL: u32 = 1;
+pub const RPT_LIGHT_DISTANT: u32 = 2;
+pub const RPT_BG_CONSTANT: u32 = 0;
+pub const RPT_BG_GRADIENT_Y: u32 = 1;
+pub const RPT_SCENE_ANYHIT_USES_MAX_DIST: u32 = 1;
+pub const RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES: u32 = 2;
+pub const RPT_RENDER_DEFAULT: u32 = 0;
+pub const RPT_RENDER_NESTED_LOOPS: u32 = 1;
+pub const RPT_RENDER_FAST_MATH: u32 = 2;
+pub const RPT_RENDER_SDF_INLINE_MARCH: u32 = 4;
+pub const RPT_RENDER_GRID_RESUMABLE_WALK: u32 = 8;
+pub const RPT_RENDER_SDF_POOL_MARCH: u32 = 0x10;
+pub const RPT_RENDER_RUSSIAN_ROULETTE: u32 = 0x20;
+pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x40;
+pub const RPT_RENDER_LARGE_MEGAKERNEL: u32 = 0x80;
+pub const RPT_RENDER_SMALL_COMPACT: u32 = 0x100;
 
 impl RptSceneDesc {
     /// All zeros (no primitives, no SDF object): the starting point of every `describe()`.

@@ -220,6 +220,27 @@ def check_binding(rust_src, tmp_path):
     for cname in ("rpt_scene_desc", "rpt_material", "rpt_sphere", "rpt_plane", "rpt_light", "rpt_camera", "rpt_background", "rpt_sdf", "rpt_sdf_prim"):
         if camel(cname) not in r_structs:
             problems.append("%s: no Rust mirror" % cname)
+    # constants: every `pub const RPT_*` must have the header's value (gcc evaluates the enumerators), and every render /
+    # scene flag and status code of the header must be there
+    r_consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"pub const (RPT_[A-Z0-9_]+): [iu]32 = (-?(?:0x[0-9A-Fa-f]+|\d+));", rust_src)}
+    hdr_names = sorted(set(re.findall(r"\b(RPT_(?:RENDER|SCENE|ERR|LIGHT|BG)_[A-Z0-9_]+|RPT_OK|RPT_MAT_ALL)\s*=", open(HEADER).read())))
+    prog = os.path.join(str(tmp_path), "consts.c")
+    with open(prog, "w") as f:
+        f.write('#include <stdio.h>\n#include "rpt.h"\nint main(void) {\n')
+        for n in hdr_names:
+            f.write('    printf("%s %%lld\\n", (long long)%s);\n' % (n, n))
+        f.write("    return 0;\n}\n")
+    exe = os.path.join(str(tmp_path), "consts")
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), prog, "-o", exe], check=True)
+    c_consts = {ln.split()[0]: int(ln.split()[1]) for ln in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines()}
+    for n in hdr_names:
+        if n not in r_consts:
+            problems.append("%s: constant not in the Rust binding" % n)
+        elif r_consts[n] != c_consts[n]:
+            problems.append("%s: %d != rpt.h %d" % (n, r_consts[n], c_consts[n]))
+    for n in r_consts:
+        if n != "RPT_ABI_VERSION" and n not in c_consts:
+            problems.append("%s: no such constant in rpt.h" % n)
     m = re.search(r"pub const RPT_ABI_VERSION: u32 = (\d+);", rust_src)
     c_ver = re.search(r"#define RPT_ABI_VERSION (\d+)u", open(HEADER).read())
     if not m or not c_ver or m.group(1) != c_ver.group(1):
@@ -253,3 +274,10 @@ def test_checker_catches_a_wrong_signature_and_field_order(tmp_path):
 def test_scene_desc_size_export_matches_c(rpt):
     import ctypes as C
     assert rpt.lib().rpt_sizeof_scene_desc() == C.sizeof(rpt._abi.rpt_scene_desc)
+
+
+def test_checker_catches_a_wrong_flag_value(tmp_path):
+    src = open(RUST).read()
+    assert "pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x40;" in src
+    broken = src.replace("pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x40;", "pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x80;")
+    assert any("RPT_RENDER_LARGE_WAVEFRONT" in p for p in check_binding(broken, tmp_path))
