@@ -385,13 +385,22 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         set_err(ctx, "render: RPT_RENDER_LARGE_WAVEFRONT and RPT_RENDER_LARGE_MEGAKERNEL exclude each other");
         return RPT_ERR_INVALID_ARG;
     }
-    const bool wavefront = ctx->large && scl.use_accel && !nested && scl.max_depth != 0u && wavefront_wanted(flags, (uint64_t)rp.rows_local * width);
+    bool wavefront = ctx->large && scl.use_accel && !nested && scl.max_depth != 0u && wavefront_wanted(flags, (uint64_t)rp.rows_local * width);
     WfBuffers wb;
     if (wavefront) {
         const uint64_t n_slots = (uint64_t)rp.rows_local * width;
-        if (n_slots >= (1ull << 31)) { set_err(ctx, "render: tile too large for the wavefront form"); return RPT_ERR_INVALID_ARG; }
-        int rc = wavefront_buffers(ctx, d, (size_t)n_slots, wb);
-        if (rc != RPT_OK) return rc;
+        const bool forced = (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
+        if (n_slots >= (1ull << 31)) {
+            if (forced) { set_err(ctx, "render: tile too large for the wavefront form"); return RPT_ERR_INVALID_ARG; }
+            wavefront = false;
+        } else {
+            int rc = wavefront_buffers(ctx, d, (size_t)n_slots, wb);
+            if (rc != RPT_OK) {
+                if (forced) return rc;
+                (void)hipGetLastError();                            // no room for 168 B per pixel: the megakernel needs none
+                wavefront = false;
+            }
+        }
     }
 
     // The LDS tables of the regenerating kernel hold a bounded number of samples: larger batches are
@@ -711,13 +720,13 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         return RPT_OK;
     }
 
-    for (DevState& d : ctx->devs) {                                 // a small scene needs no tables: drop a previous large scene's
-        if (!d.tables) continue;
+    for (DevState& d : ctx->devs) {                                 // a small scene needs no tables: drop a previous large scene's,
+        if (!d.tables && !d.wf) continue;                           // and the path buffers of its wavefront form
         DeviceGuard guard(d.device);
         RPT_HIP_CHECK(ctx, guard.status);
         RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
-        RPT_HIP_CHECK(ctx, hipFree(d.tables));
-        d.tables = nullptr;
+        if (d.tables) { RPT_HIP_CHECK(ctx, hipFree(d.tables)); d.tables = nullptr; }
+        if (d.wf) { RPT_HIP_CHECK(ctx, hipFree(d.wf)); d.wf = nullptr; d.wf_bytes = 0; }
     }
     SceneSmallSdf& d = ctx->scene;
     memset(&d, 0, sizeof(d));
