@@ -190,7 +190,7 @@ static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels)
     return tile_pixels >= kWavefrontMinPixels;
 }
 // Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel)
-static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 1u; return v; }
+static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 2u; return v; }
 // ---- descriptor -> device tables ---------------------------------------------------------------------------
 static DevPlane dev_plane(const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; }
 static DevLight dev_light(const rpt_light& a)

@@ -92,7 +92,8 @@ RPT_DEV bool closest_before_walk(const SceneLarge& sc, const RayD& ray, float& d
 
 // path_trace_geom (dev_integrator.h) with the miss left to the caller: 0 the ray left the scene (the background is still to
 // be added), 1 it ended on an emitter (radiance updated), 2 a surface was hit.
-RPT_DEV uint32_t path_trace_geom_split(const SceneLarge& sc, const WaveQuery& q, PathRegs& p, GeomHit& g)
+template <class S, class Q>
+RPT_DEV uint32_t path_trace_geom_split(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
 {
     EmitterHit e;
     e.is_emitter = false;

@@ -328,7 +328,8 @@ RPT_DEV void wf_rec_get(const WfRecords& r, uint32_t i, PathRegs& p, uint32_t& g
 }
 
 // append `value` to a workgroup list in LDS for the lanes that `want` (one LDS atomic per wave)
-RPT_DEV void wf_list_add(uint32_t* list, uint32_t* count, bool want, uint32_t value)
+template <class T>
+RPT_DEV void wf_list_add(T* list, uint32_t* count, bool want, uint32_t value)
 {
     const uint64_t m = __ballot(want);
     if (m == 0ull) return;
@@ -337,7 +338,7 @@ RPT_DEV void wf_list_add(uint32_t* list, uint32_t* count, bool want, uint32_t va
     uint32_t base = 0u;
     if (lane == leader) base = atomicAdd(count, (uint32_t)__popcll(m));
     base = (uint32_t)__shfl((int)base, (int)leader);
-    if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
+    if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (T)value;
 }
 
 __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_shade_kernel)(const SceneLarge sc, const RenderParams rp, const WfBuffers wb, uint32_t parity, uint32_t first)
@@ -537,40 +538,44 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
 #define RPT_COMPACT_WAVES_PER_SIMD 5
 #endif
 template <class S>
-RPT_DEV bool compact_finish(const S& sc, const RenderParams& rp, float4* s_acc, uint32_t i, PathRegs& p, uint32_t& s)
+RPT_DEV bool compact_finish(const S& sc, const RenderParams& rp, uint32_t i, PathRegs& p, uint32_t& s)
 {
-    float4 acc = s_acc[i];
+    // tracer.rs:105-117 straight on the pixel in HBM (32 B per sample; keeping the 256 running means in LDS would cost the
+    // kernel two of its eight resident workgroups per CU)
+    const PixelSetup ps = pixel_setup(rp, i);
+    float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
+    float4 acc = *pixel;
     const uint64_t frames = rp.frames_done + s;
-    blend(acc, p.radiance, 1.0f / (float)(frames + 1));             // tracer.rs:105-117
-    s_acc[i] = acc;
+    blend(acc, p.radiance, 1.0f / (float)(frames + 1));
+    *pixel = acc;
     s += 1u;
     if (s >= rp.spp) return false;
-    const PixelSetup ps = pixel_setup(rp, i);
     path_begin(sc, p, ps.px, ps.py, frame_key_hd(rp.seed, rp.frames_done + s), ps.pixel_index);
     return true;
 }
 
-__global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_kernel)(const SceneSmall sc, const RenderParams rp)
+// Per pass two barriers:  TRACE for the trace list (closest_hit only: surface -> S, miss / emitter -> F)  |  SHADE for the
+// entries of S from thread 0 up and, at the same time, FINISH (background for a miss, blend, the pixel's next camera path)
+// for the entries of F from thread 255 down — |S| + |F| <= 256, so at most one wave has both kinds.
+RPT_DEV void render_compact_body(const SceneSmall& sc, const RenderParams& rp)
 {
-    __shared__ WfRecords rec;                                       // u[4] = the sample index of the pixel's current path
-    __shared__ float4 s_acc[256];
-    __shared__ uint32_t l_trace[2][256], l_shade[256];
-    __shared__ uint32_t n_trace[2], n_shade[2];
+    __shared__ WfRecords rec;                                       // u[4] = sample index << 1 | "the ray left the scene"
+    __shared__ uint8_t l_trace[2][256], l_shade[256], l_fin[256];   // path = pixel of the tile = thread that started it
+    __shared__ uint32_t n_trace[2], n_shade[2], n_fin[2];
     const uint32_t tid = threadIdx.x;
     const PixelSetup ps = pixel_setup(rp);
-    float4* pixel = reinterpret_cast<float4*>(rp.pixels) + (ps.valid ? ps.pix_offset : 0);
     if (sc.max_depth == 0) {                                        // no bounce loop: every sample's radiance is zero
         if (ps.valid) {
+            float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
             float4 acc = *pixel;
             for (uint32_t k = 0; k < rp.spp; ++k) blend(acc, mk3(0.0f, 0.0f, 0.0f), 1.0f / (float)(rp.frames_done + k + 1));
             *pixel = acc;
         }
         return;
     }
-    if (tid < 2u) { n_trace[tid] = 0u; n_shade[tid] = 0u; }
+    if (tid < 2u) { n_trace[tid] = 0u; n_shade[tid] = 0u; n_fin[tid] = 0u; }
     __syncthreads();
     if (ps.valid) {
-        s_acc[tid] = *pixel;
         PathRegs p;
         path_begin(sc, p, ps.px, ps.py, frame_key_hd(rp.seed, rp.frames_done), ps.pixel_index);
         wf_rec_put(rec, tid, p, 0u, 0u);
@@ -582,45 +587,61 @@ __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_
         const uint32_t n_t = n_trace[cur];
         if (n_t == 0u) break;                                       // (the same value in every thread: read behind a barrier)
         {
-            bool to_shade = false, to_trace = false;
+            bool to_shade = false, to_fin = false;
             uint32_t i = 0u;
             if (tid < n_t) {
                 i = l_trace[cur][tid];
                 PathRegs p;
-                uint32_t gcode, s;
-                wf_rec_get(rec, i, p, gcode, s);
+                uint32_t gcode, ctl;
+                wf_rec_get(rec, i, p, gcode, ctl);
                 GeomHit g;
                 g.code = 0u;
-                if (path_trace_geom(sc, DirectQuery{}, p, g)) to_shade = true;
-                else to_trace = compact_finish(sc, rp, s_acc, i, p, s);
-                if (to_shade || to_trace) wf_rec_put(rec, i, p, g.code, s);
+                const uint32_t what = path_trace_geom_split(sc, DirectQuery{}, p, g);
+                to_shade = what == 2u;
+                to_fin = !to_shade;
+                wf_rec_put(rec, i, p, g.code, (ctl & ~1u) | (what == 0u ? 1u : 0u));
             }
             wf_list_add(l_shade, &n_shade[cur], to_shade, i);
-            wf_list_add(l_trace[cur ^ 1u], &n_trace[cur ^ 1u], to_trace, i);
+            wf_list_add(l_fin, &n_fin[cur], to_fin, i);
         }
         __syncthreads();
-        if (tid == 0u) { n_trace[cur] = 0u; n_shade[cur ^ 1u] = 0u; }       // both were last read before this barrier, next written after the next
+        if (tid == 0u) { n_trace[cur] = 0u; n_shade[cur ^ 1u] = 0u; n_fin[cur ^ 1u] = 0u; }   // last read before this barrier, next written after the next
         {
-            const uint32_t n_s = n_shade[cur];
+            const uint32_t n_s = n_shade[cur], n_f = n_fin[cur];
             bool to_trace = false;
             uint32_t i = 0u;
             if (tid < n_s) {
                 i = l_shade[tid];
                 PathRegs p;
-                uint32_t gcode, s;
-                wf_rec_get(rec, i, p, gcode, s);
+                uint32_t gcode, ctl;
+                wf_rec_get(rec, i, p, gcode, ctl);
                 GeomHit g;
                 g.code = gcode;
-                if (path_shade_full(sc, DirectQuery{}, p, g)) to_trace = compact_finish(sc, rp, s_acc, i, p, s);
+                uint32_t s = ctl >> 1;
+                if (path_shade_full(sc, DirectQuery{}, p, g)) to_trace = compact_finish(sc, rp, i, p, s);
                 else to_trace = true;
-                if (to_trace) wf_rec_put(rec, i, p, 0u, s);
+                if (to_trace) wf_rec_put(rec, i, p, 0u, s << 1);
+            } else if (255u - tid < n_f) {
+                i = l_fin[255u - tid];
+                PathRegs p;
+                uint32_t gcode, ctl;
+                wf_rec_get(rec, i, p, gcode, ctl);
+                uint32_t s = ctl >> 1;
+                if (ctl & 1u) p.radiance = p.radiance + background(sc, p.ray) * p.throughput;     // tracer.rs:64-68
+                to_trace = compact_finish(sc, rp, i, p, s);
+                if (to_trace) wf_rec_put(rec, i, p, 0u, s << 1);
             }
             wf_list_add(l_trace[cur ^ 1u], &n_trace[cur ^ 1u], to_trace, i);
         }
         __syncthreads();
     }
-    if (ps.valid) *pixel = s_acc[tid];
 }
+
+__global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(sc, rp); }
+// Frames of a few thousand workgroups (the reference's 800x600 window: 1 875) are a question of how many ROUNDS of workgroups the
+// chip needs: six resident per CU (80 VGPRs, 112 B of scratch) make that 1.2 instead of 1.5 rounds, 0.096 instead of 0.101 ms;
+// from 1080p up the five-per-CU build is 1 % faster.
+__global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(sc, rp); }
 
 // SDF scenes, resumable march (dev_sdf_path.h).  Per lane:
 //   MARCH_P --(march over)--> RESOLVE --(miss / emitter)--> next sample: MARCH_P
@@ -1082,6 +1103,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), tiles, wg, 0, st, scs, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), tiles, wg, 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
+    else if (rp.compact && nblocks <= 3072u) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
     else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_kernel), tiles, wg, 0, st, sc, rp);
     else {
         // RPT_DEBUG_EXTRA_LDS (bytes, experiments only): pads the workgroup's LDS so that fewer waves fit a CU — how the

@@ -21,6 +21,12 @@ VARIANTS = {
     "shade3": ["-DRPT_WF_SHADE_WAVES_PER_SIMD=3"],
     "shade5": ["-DRPT_WF_SHADE_WAVES_PER_SIMD=5"],
     "shade6": ["-DRPT_WF_SHADE_WAVES_PER_SIMD=6"],
+    # the compacting kernel of one-sample launches
+    "compact4": ["-DRPT_COMPACT_WAVES_PER_SIMD=4"],
+    "compact5": ["-DRPT_COMPACT_WAVES_PER_SIMD=5"],
+    "compact6": ["-DRPT_COMPACT_WAVES_PER_SIMD=6"],
+    "compact7": ["-DRPT_COMPACT_WAVES_PER_SIMD=7"],
+    "compact8": ["-DRPT_COMPACT_WAVES_PER_SIMD=8"],
 }
 
 if __name__ == "__main__":
