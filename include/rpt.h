@@ -244,7 +244,11 @@ enum {
      * reference's own usage, where the megakernel has little to regenerate and its waves drain (+13..23 % at one sample) —
      * and slower than the megakernel from three samples per launch up; the flag forces it at any sample count (A/B, tests).
      * Same image bit for bit. */
-    RPT_RENDER_SMALL_COMPACT = 1u << 8
+    RPT_RENDER_SMALL_COMPACT = 1u << 8,
+    /* Scenes with an SDF object: the same idea with the sphere march as one of the stages (paths in LDS, marching paths
+     * re-dealt every few iterations).  Same image bit for bit; measured SLOWER than the default march kernel (1.7 vs 2.4
+     * Gsamples/s: DESIGN.md 4b); only in builds with -DRPT_AB_KERNELS, otherwise RPT_ERR_UNSUPPORTED. */
+    RPT_RENDER_SDF_COMPACT = 1u << 9
 };
 
 /* ---- context --------------------------------------------------------------- */

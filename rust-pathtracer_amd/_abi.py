@@ -49,6 +49,7 @@ RPT_RENDER_RUSSIAN_ROULETTE = 1 << 5
 RPT_RENDER_LARGE_WAVEFRONT = 1 << 6
 RPT_RENDER_LARGE_MEGAKERNEL = 1 << 7
 RPT_RENDER_SMALL_COMPACT = 1 << 8
+RPT_RENDER_SDF_COMPACT = 1 << 9
 
 RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG = range(7)
 (RPT_PROBE_FN_GEN_RAY, RPT_PROBE_FN_HIT_SPHERE, RPT_PROBE_FN_HIT_PLANE, RPT_PROBE_FN_SAMPLE_LIGHT, RPT_PROBE_FN_DISNEY_EVAL,

@@ -38,6 +38,7 @@ struct DevState {
     float* fb = nullptr;              // staging for the host-pointer API (this device's rows, or a whole image)
     size_t fb_bytes = 0;
     float* tile = nullptr;            // resident ColorBuffer rows of this rank: rows_padded x width RGBA f32
+    SceneSmallSdf* scene_small_dev = nullptr;   // the small scene in device memory, for the one kernel that reads it from there (SDF compact)
     void* wf = nullptr;               // wavefront state of large scenes (dev_wavefront.h), grown on demand
     size_t wf_bytes = 0;
     ncclComm_t comm = nullptr;
@@ -191,6 +192,19 @@ static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels)
 }
 // Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel)
 static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 2u; return v; }
+// SDF scenes: RPT_SDF_FORM=compact|march overrides the flag (A/B runs of unmodified callers)
+static bool sdf_compact_wanted(uint32_t flags)
+{
+#ifndef RPT_AB_KERNELS
+    (void)flags;
+    return false;                                                   // (the flag itself is refused in launch_render)
+#endif
+    static const char* form = getenv("RPT_SDF_FORM");
+    if (form && form[0] == 'c') return true;
+    if (form && form[0] == 'm') return false;
+    return (flags & RPT_RENDER_SDF_COMPACT) != 0;
+}
+static uint32_t sdf_compact_steps() { static const uint32_t v = getenv("RPT_SDF_COMPACT_STEPS") ? (uint32_t)atoi(getenv("RPT_SDF_COMPACT_STEPS")) : 8u; return v; }
 // ---- descriptor -> device tables ---------------------------------------------------------------------------
 static DevPlane dev_plane(const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; }
 static DevLight dev_light(const rpt_light& a)
@@ -221,6 +235,7 @@ static void free_dev(DevState& d)
     if (d.tile) (void)hipFree(d.tile);
     if (d.tables) (void)hipFree(d.tables);
     if (d.wf) (void)hipFree(d.wf);
+    if (d.scene_small_dev) (void)hipFree(d.scene_small_dev);
     if (d.ev_begin) (void)hipEventDestroy(d.ev_begin);
     if (d.ev_end) (void)hipEventDestroy(d.ev_end);
     if (d.ev_ready) (void)hipEventDestroy(d.ev_ready);
@@ -359,7 +374,8 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
     rp.seed = seed;
     rp.tiles_x = (width + 15u) / 16u;
-    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : ((flags & RPT_RENDER_SDF_POOL_MARCH) ? 2u : 1u);
+    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : ((flags & RPT_RENDER_SDF_POOL_MARCH) ? 2u : (sdf_compact_wanted(flags) ? 3u : 1u));
+    rp.sdf_compact_steps = sdf_compact_steps();
     rp.pool_shade_lanes = sdf_pool_shade_lanes();
     rp.pool_resolve_lanes = sdf_pool_resolve_lanes();
     rp.pool_min_batch = sdf_pool_min_batch();
@@ -374,6 +390,10 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     if (nblocks > 0x7FFFFFFFull) { set_err(ctx, "render: grid too large"); return RPT_ERR_INVALID_ARG; }
     if (flags & RPT_RENDER_GRID_RESUMABLE_WALK) { set_err(ctx, "render: RPT_RENDER_GRID_RESUMABLE_WALK was removed (measured slower, DESIGN.md 4b)"); return RPT_ERR_UNSUPPORTED; }
 #ifndef RPT_AB_KERNELS
+    if (flags & RPT_RENDER_SDF_COMPACT) {
+        set_err(ctx, "render: the A/B kernel RPT_RENDER_SDF_COMPACT is not in this build (-DRPT_AB_KERNELS)");
+        return RPT_ERR_UNSUPPORTED;
+    }
     if (flags & RPT_RENDER_SDF_POOL_MARCH) {
         set_err(ctx, "render: the A/B kernel RPT_RENDER_SDF_POOL_MARCH is not in this build (-DRPT_AB_KERNELS)");
         return RPT_ERR_UNSUPPORTED;
@@ -403,6 +423,14 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         }
     }
 
+    const SceneSmallSdf* scs_dev = nullptr;
+    if (!ctx->large && scs.sdf.n_prims > 0 && rp.sdf_resumable_march == 3u && !nested) {
+        // (a copy per launch: the camera in it depends on the frame size; pageable source, so the copy has left `scs` on return)
+        if (!d.scene_small_dev) RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.scene_small_dev, sizeof(SceneSmallSdf)));
+        RPT_HIP_CHECK(ctx, hipMemcpyAsync(d.scene_small_dev, &scs, sizeof(SceneSmallSdf), hipMemcpyHostToDevice, stream));
+        scs_dev = d.scene_small_dev;
+    }
+
     // The LDS tables of the regenerating kernel hold a bounded number of samples: larger batches are
     // split into consecutive launches (the running mean carries over in the framebuffer).
     const uint32_t max_chunk = rptlaunch::max_spp_per_launch();
@@ -412,8 +440,8 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         rp.frames_done = frames_done + done;
         if (wavefront && (flags & RPT_RENDER_FAST_MATH)) RPT_HIP_CHECK(ctx, rptlaunch_fast::render_wavefront(scl, rp, wb, ctx->devs.size() == 1, stream));
         else if (wavefront) RPT_HIP_CHECK(ctx, rptlaunch::render_wavefront(scl, rp, wb, ctx->devs.size() == 1, stream));
-        else if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
-        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream));
+        else if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
+        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
         done += chunk;
     }
     return RPT_OK;

@@ -14,16 +14,15 @@ struct RayD {
 // A wave-uniform scene constant (an SGPR) passed through an empty asm: what is computed from it — radius * radius, the
 // f64 image of the background's exponent — is then recomputed where it is used (one instruction) instead of being hoisted
 // out of the path loop into a VGPR that lives, and spills, for the whole kernel.
-RPT_DEV float uniform_here(float x)
-{
-    asm volatile("" : "+s"(x));
-    return x;
-}
+// (readfirstlane: a no-op where the value already is in an SGPR; where register pressure made the compiler keep the constant
+// in a VGPR it is what lets the constraint be met at all.)
 RPT_DEV uint32_t uniform_here(uint32_t x)
 {
+    x = (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
     asm volatile("" : "+s"(x));
     return x;
 }
+RPT_DEV float uniform_here(float x) { return rpt_u2f(uniform_here(rpt_f2u(x))); }
 
 // analytical.rs:166-190 == scene.rs:39-63
 RPT_DEV bool hit_sphere(const RayD& ray, v3 center, float radius, float& t)

@@ -118,11 +118,12 @@ struct RenderParams {
     uint32_t shade_threshold;  // lanes that must be waiting before a wave runs the shading block
     uint32_t march_min_lanes;      // SDF scenes: a wave keeps marching while at least this many lanes are marching
     uint32_t sdf_resumable_march;  // SDF scenes: 0 march inside closest_hit / any_hit, 1 as a scheduling state of the lane (dev_sdf_path.h),
-                                   // 2 through the workgroup's march pool (dev_sdf_pool.h)
+                                   // 2 through the workgroup's march pool (dev_sdf_pool.h), 3 the compacting kernel (paths in LDS)
     uint32_t pool_shade_lanes;     // march pool: a wave runs SHADE / RESOLVE when this many of its lanes wait at it ...
     uint32_t pool_resolve_lanes;
     uint32_t pool_min_batch;       // ... serves the queue when it can fill this many lanes with jobs ...
     uint32_t pool_patience;        // ... and after this many idle passes does whatever there is to do
+    uint32_t sdf_compact_steps;    // SDF scenes, compacting kernel: march iterations per pass
     uint32_t compact;              // small scenes: the kernel that re-deals its workgroup's paths before every stage (few samples per launch)
 };
 

@@ -643,6 +643,10 @@ __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_
 // from 1080p up the five-per-CU build is 1 % faster.
 __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(sc, rp); }
 
+#ifdef RPT_AB_KERNELS
+#include "ab/kernel_sdf_compact.h"
+#endif
+
 // SDF scenes, resumable march (dev_sdf_path.h).  Per lane:
 //   MARCH_P --(march over)--> RESOLVE --(miss / emitter)--> next sample: MARCH_P
 //                                     --(surface)--> MARCH_S --(march over)--> SHADE --> MARCH_P
@@ -1088,7 +1092,8 @@ namespace RPT_LAUNCH_NS {
 
 uint32_t max_spp_per_launch() { return kMaxSppPerLaunch; }
 
-hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, bool nested, const RenderParams& rp, uint32_t nblocks, hipStream_t st)
+hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, bool nested, const RenderParams& rp, uint32_t nblocks, hipStream_t st,
+                  const SceneSmallSdf* scs_dev)
 {
     const bool has_sdf = !large && scs.sdf.n_prims > 0;
     const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
@@ -1099,6 +1104,9 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), tiles, wg, 0, st, scs, rp);
 #ifdef RPT_AB_KERNELS
     else if (has_sdf && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), tiles, wg, 0, st, scs, rp);
+#endif
+#ifdef RPT_AB_KERNELS
+    else if (has_sdf && rp.sdf_resumable_march == 3u && scs_dev) hipLaunchKernelGGL(RPT_K(render_sdf_compact_kernel), tiles, wg, 0, st, scs_dev, rp);
 #endif
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), tiles, wg, 0, st, scs, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), tiles, wg, 0, st, scs, rp);

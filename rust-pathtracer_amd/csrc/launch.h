@@ -37,9 +37,10 @@ namespace rptlaunch {
 uint32_t max_spp_per_launch();      // samples one launch of the regenerating kernel can hold in its LDS tables
 
 // One launch of the megakernel on `nblocks` 16x16 tiles: picks the instantiation (small / SDF / large,
-// regenerating or nested) from the scene.
+// regenerating or nested) from the scene.  `small_scene_dev`: the same small scene in device memory (only the compacting SDF
+// kernel, rp.sdf_resumable_march == 3, reads it; without it that mode falls back to the march kernel).
 hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st);
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr);
 // Large scenes with a grid, wavefront form (dev_wavefront.h): `spp` samples of every pixel of the tile; the buffers hold
 // rp.rows_local * rp.width slots.  Enqueues 1 + 2 * (spp * max_depth + 1) launches at most; launches after the last useful
 // iteration return at once.  `host_checks`: the host may also wait for the stream every 256 iterations of a long bound and stop
@@ -62,5 +63,5 @@ namespace rptlaunch_fast {
 hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, bool host_checks,
                             hipStream_t st);
 hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st);
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr);
 }  // namespace rptlaunch_fast

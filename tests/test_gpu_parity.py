@@ -698,7 +698,7 @@ def test_ab_kernels_are_not_in_the_shipped_library(rpt, torch_cuda):
     from rust_pathtracer_amd import scenes
     t = rpt.Tracer(scenes.sdf_scene(), device=0, seed=1)
     buf = rpt.DeviceColorBuffer(16, 16)
-    for flag in (rpt._abi.RPT_RENDER_SDF_POOL_MARCH, rpt._abi.RPT_RENDER_GRID_RESUMABLE_WALK):
+    for flag in (rpt._abi.RPT_RENDER_SDF_POOL_MARCH, rpt._abi.RPT_RENDER_SDF_COMPACT, rpt._abi.RPT_RENDER_GRID_RESUMABLE_WALK):
         t.flags = flag
         try:
             t.render_n(buf, 1)
