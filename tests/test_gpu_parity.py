@@ -797,3 +797,29 @@ def test_fast_math_mode_is_statistically_equivalent(rpt, torch_cuda, oracle):
     want = oracle.render(oracle.scene_analytical(), w, h, spp, seed=1)
     assert_bit_identical(exact.pixels.cpu().numpy(), want, "strict kernel next to the fast build")
     t.close()
+
+
+def test_fast_math_mode_in_the_other_kernels(rpt, torch_cuda):
+    """The relaxed-arithmetic build of the kernels added in round 2 — the compacting kernel of one-sample launches and the
+    wavefront form of large scenes — runs, and stays within the same statistical distance of the strict kernels."""
+    from rust_pathtracer_amd import scenes
+    A = rpt._abi
+    cases = [("compact", rpt.AnalyticalScene(), A.RPT_RENDER_SMALL_COMPACT, 256, 144, 32),
+             ("wavefront", scenes.random_spheres_scene(n_spheres=400, n_lights=6), A.RPT_RENDER_LARGE_WAVEFRONT, 192, 108, 24)]
+    for name, scene, form, w, h, spp in cases:
+        t = rpt.Tracer(scene, device=0, seed=2)
+        t.flags = form
+        exact = rpt.DeviceColorBuffer(w, h)
+        t.render_n(exact, spp)
+        t.flags = form | A.RPT_RENDER_FAST_MATH
+        fast = rpt.DeviceColorBuffer(w, h)
+        t.render_n(fast, spp)
+        torch_cuda.cuda.synchronize()
+        a = exact.pixels.cpu().numpy()[..., :3].astype(np.float64)
+        b = fast.pixels.cpu().numpy()[..., :3].astype(np.float64)
+        assert not np.isnan(b).any(), name
+        d = np.abs(a - b)
+        assert np.median(d) < 5e-6, name
+        assert (d.max(axis=2) > 1e-2).mean() < 0.05, name
+        assert abs(a.mean() - b.mean()) < 2e-3, name
+        t.close()
