@@ -4,8 +4,8 @@
 //
 // Why: inside the megakernel a wave leaves a grid walk when its LONGEST walk ends — 19.5 % of the lanes active on the
 // 10 k-sphere scene (profiles/r2/block_profile_c5.txt) — and handing finished lanes new walks inside that kernel lost to
-// the register state it had to keep.  A kernel that ONLY walks keeps ~40 VGPRs per lane: a lane whose walk
-// ends takes the next ray of the list, whatever pixel it belongs to, at 8 waves per SIMD.
+// the register state it had to keep.  A kernel that ONLY walks keeps 80 VGPRs per lane, none of them spilled:
+// a lane whose walk ends takes the next ray of the list, whatever pixel it belongs to, at 6 waves per SIMD.
 //
 // Per pixel the arithmetic and its order are the megakernel's (same device functions), so the image is bit-identical:
 //   * a pixel's samples are still traced one after the other (a slot per pixel, path regeneration in the slot);
@@ -219,7 +219,7 @@ RPT_DEV void wf_walk_body(const SceneLarge& sc, const WfBuffers& wb, uint32_t re
     RPT_PROF(PB_WF_WAVE);
     for (;;) {
         uint32_t n_has = (uint32_t)__popcll(__ballot(has));
-        if (!exhausted && n_has <= (refill_at & 0xFFu)) {
+        if (!exhausted && n_has <= refill_at) {
             uint64_t m_need = __ballot(!has);
             bool got = false;
             RPT_PROF(PB_WF_FETCH);
@@ -263,7 +263,7 @@ RPT_DEV void wf_walk_body(const SceneLarge& sc, const WfBuffers& wb, uint32_t re
                 dist = o.w; max_dist = o.w;                         // (each kind reads its own)
                 best = rpt_f2u(d.w);
                 g = grid_begin(sc, ray);
-                if (g.alive && !(refill_at & 0x100u)) {
+                if (g.alive) {
                     has = true;
                     cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
                     guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u;
@@ -347,7 +347,7 @@ RPT_DEV void wf_walk_body(const SceneLarge& sc, const WfBuffers& wb, uint32_t re
                 k0 = n0; k1 = n1;
             }
             n_has = (uint32_t)__popcll(__ballot(has));
-        } while (n_has != 0u && (exhausted || n_has > (refill_at & 0xFFu)));
+        } while (n_has != 0u && (exhausted || n_has > refill_at));
     }
 }
 

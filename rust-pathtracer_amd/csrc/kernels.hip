@@ -1124,7 +1124,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 
 hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, bool host_checks, hipStream_t st)
 {
-    static const uint32_t refill_at = getenv("RPT_WF_REFILL_AT") ? (uint32_t)atoi(getenv("RPT_WF_REFILL_AT")) : 40u;
+    static const uint32_t refill_at = getenv("RPT_WF_REFILL_AT") ? ((uint32_t)atoi(getenv("RPT_WF_REFILL_AT")) & 63u) : 40u;
     static const uint32_t blocks_per_group = getenv("RPT_WF_BLOCKS_PER_GROUP") ? (uint32_t)atoi(getenv("RPT_WF_BLOCKS_PER_GROUP")) : 6u;
     (void)hipGetLastError();
     const dim3 wg(256), all((wb.n_seg * 64u + 255u) / 256u), walkers(kWalkGroups * (blocks_per_group ? blocks_per_group : 1u));
