@@ -181,14 +181,15 @@ static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_
 // Which form a large scene with a grid takes (include/rpt.h).  RPT_LARGE_FORM=wavefront|megakernel overrides flags and
 // default (A/B runs of unmodified callers).
 constexpr uint64_t kWavefrontMinPixels = 3ull << 19;                // 1.5 M
-static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels)
+constexpr uint32_t kWavefrontMaxSpp = 64;                           // the megakernel regenerates over a launch's samples: from ~128 per launch it catches up
+static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels, uint32_t spp)
 {
     static const char* form = getenv("RPT_LARGE_FORM");
     if (form && form[0] == 'w') return true;
     if (form && form[0] == 'm') return false;
     if (flags & RPT_RENDER_LARGE_WAVEFRONT) return true;
     if (flags & RPT_RENDER_LARGE_MEGAKERNEL) return false;
-    return tile_pixels >= kWavefrontMinPixels;
+    return tile_pixels >= kWavefrontMinPixels && spp <= kWavefrontMaxSpp;
 }
 // Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel)
 static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 2u; return v; }
@@ -405,7 +406,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         set_err(ctx, "render: RPT_RENDER_LARGE_WAVEFRONT and RPT_RENDER_LARGE_MEGAKERNEL exclude each other");
         return RPT_ERR_INVALID_ARG;
     }
-    bool wavefront = ctx->large && scl.use_accel && !nested && scl.max_depth != 0u && wavefront_wanted(flags, (uint64_t)rp.rows_local * width);
+    bool wavefront = ctx->large && scl.use_accel && !nested && scl.max_depth != 0u && wavefront_wanted(flags, (uint64_t)rp.rows_local * width, spp);
     WfBuffers wb;
     if (wavefront) {
         const uint64_t n_slots = (uint64_t)rp.rows_local * width;
