@@ -692,6 +692,29 @@ def test_full_config5_all_512_spp_pixels_match_oracle(rpt, torch_cuda, oracle):
     t.close()
 
 
+def test_wavefront_long_launch_equals_megakernel(rpt, torch_cuda):
+    """A launch long enough for the wavefront form's host early-out (more than 512 iterations: 150 spp x depth 4) on a tile
+    above the default threshold, and the default choice on both sides of the 64-sample limit: whole frames bit-identical to the
+    megakernel's (which the oracle tests pin)."""
+    from rust_pathtracer_amd import scenes
+    torch = torch_cuda
+    A = rpt._abi
+    s = scenes.random_spheres_scene(3000, 8)
+    w, h = 1600, 1000
+    t = rpt.Tracer(s, device=0, seed=6)
+    frames = {}
+    for name, flags, steps in (("mega", A.RPT_RENDER_LARGE_MEGAKERNEL, (150, 8)), ("wave", A.RPT_RENDER_LARGE_WAVEFRONT, (150, 8)), ("default", 0, (150, 8))):
+        t.flags = flags
+        buf = rpt.DeviceColorBuffer(w, h)
+        for spp in steps:
+            t.render_n(buf, spp)
+        torch.cuda.synchronize()
+        frames[name] = buf.pixels.view(torch.int32).clone()
+    assert torch.equal(frames["mega"], frames["wave"])
+    assert torch.equal(frames["mega"], frames["default"])
+    t.close()
+
+
 def test_ab_kernels_are_not_in_the_shipped_library(rpt, torch_cuda):
     """The measured-slower kernel forms (csrc/ab/) are only built with -DRPT_AB_KERNELS: the shipped library refuses
     their flags loudly instead of silently running something else."""
