@@ -181,7 +181,7 @@ static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_
 // Which form a large scene with a grid takes (include/rpt.h).  RPT_LARGE_FORM=wavefront|megakernel overrides flags and
 // default (A/B runs of unmodified callers).
 constexpr uint64_t kWavefrontMinPixels = 3ull << 19;                // 1.5 M
-constexpr uint32_t kWavefrontMaxSpp = 64;                           // the megakernel regenerates over a launch's samples: from ~128 per launch it catches up
+constexpr uint32_t kWavefrontMaxSpp = 8;                            // the megakernel regenerates over a launch's samples: from 16 per launch it is the faster form
 static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels, uint32_t spp)
 {
     static const char* form = getenv("RPT_LARGE_FORM");

@@ -106,6 +106,13 @@ RPT_DEV DevLight light_at(const SceneLarge& sc, uint32_t index)     // per-lane 
 // build_grid); rays that start farther away (grazing floor hits tens of thousands of units out,
 // where the test is pure noise) take the brute-force loop instead.
 // ---------------------------------------------------------------------------
+#ifndef RPT_GRID_BATCH
+#define RPT_GRID_BATCH 2          // list entries per trip in grid_closest_sphere ...
+#endif
+#ifndef RPT_GRID_BATCH_ANY
+#define RPT_GRID_BATCH_ANY 2      // ... and in grid_any_sphere
+#endif
+
 struct GridWalk {
     int ix, iy, iz;
     int sx, sy, sz;
@@ -169,6 +176,18 @@ RPT_DEV GridWalk grid_begin(const SceneLarge& sc, const RayD& ray)
     g.tdx = tdel[0]; g.tdy = tdel[1]; g.tdz = tdel[2];
     g.alive = true;
     return g;
+}
+
+// cell_start[c], cell_start[c + 1] in one 8-byte load (dword-aligned)
+RPT_DEV void cell_bounds(const SceneLarge& sc, uint32_t c, uint32_t& k0, uint32_t& k1)
+{
+#ifdef RPT_CELL_BOUNDS_TWO_LOADS
+    k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1];
+#else
+    struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
+    const Pair r = *reinterpret_cast<const Pair*>(sc.cell_start + c);
+    k0 = r.a; k1 = r.b;
+#endif
 }
 
 RPT_DEV uint32_t grid_cell_index(const SceneLarge& sc, const GridWalk& g)
@@ -244,21 +263,55 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
     // arithmetic, so the next cell's list bounds are requested before this cell's spheres are tested.
     // A DDA crosses at most nx+ny+nz cells; the guard guarantees every wave leaves the loop.
     uint32_t k0 = 0, k1 = 0;
-    if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
+    if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
     for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
         RPT_PROF(PB_GRID_CELL);
         const float t_exit = grid_cell_exit(g);                     // of the cell whose list is [k0, k1)
         grid_step(sc, g);                                           // g is the NEXT cell from here on
         uint32_t n0 = 0, n1 = 0;
-        if (g.alive) { const uint32_t c = grid_cell_index(sc, g); n0 = sc.cell_start[c]; n1 = sc.cell_start[c + 1]; }
-        for (uint32_t k = k0; k < k1; ++k) {
-            const float4 s = sc.cell_spheres[k];
-            float t;
-            if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) {
-                const uint32_t i = sc.cell_items[k];
-                if (i != 0u && (t < dist || (t == dist && i < best))) { dist = t; best = i; hit = true; }
+        if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), n0, n1);
+        // The cell's list, RPT_GRID_BATCH entries per trip: the loads go out together, hit_sphere's discriminant is computed
+        // branch-free for all of them and only candidates (the line meets the sphere: few) take its square-root half.  The
+        // acceptance rule is order-independent, so neither batching nor parking changes the winner.  (Against the plain loop
+        // over hit_sphere, 10 k spheres: two-phase test +4.6 %, 2 per trip +1.8 %, one 8-byte load for the list bounds +1.4 %;
+        // 4 per trip: more live registers than the kernel has, -6 %.)
+        // The first candidate of a cell parks hit_sphere's tca and radius2 - d2 and its square-root half runs once, behind the
+        // list, with the other lanes' (+1.4 %); further candidates of the same cell are resolved at once.
+        float c_tca = 0.0f, c_rd = 0.0f;
+        uint32_t c_k = 0u;
+        bool parked = false;
+        auto resolve = [&](float tca, float rd, uint32_t kk) {
+            const float thc = __builtin_sqrtf(rd);
+            float t0 = tca - thc;
+            float t1 = tca + thc;
+            if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+            bool ok = true;
+            if (t0 < 0.0f) { t0 = t1; if (t0 < 0.0f) ok = false; }
+            if (ok) {
+                const uint32_t i = sc.cell_items[kk];
+                if (i != 0u && (t0 < dist || (t0 == dist && i < best))) { dist = t0; best = i; hit = true; }
+            }
+        };
+        for (uint32_t k = k0; k < k1; k += RPT_GRID_BATCH) {
+            float4 sp[RPT_GRID_BATCH];
+#pragma unroll
+            for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) {
+                sp[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (k + j < k1) sp[j] = sc.cell_spheres[k + j];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) {
+                const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
+                const float tca = dot3(l, ray.d);
+                const float d2 = dot3(l, l) - tca * tca;
+                const float radius2 = sp[j].w * sp[j].w;
+                if ((k + j < k1) && !(d2 > radius2)) {
+                    if (!parked) { c_tca = tca; c_rd = radius2 - d2; c_k = k + j; parked = true; }
+                    else resolve(tca, radius2 - d2, k + j);
+                }
             }
         }
+        if (parked) resolve(c_tca, c_rd, c_k);
         if (hit && dist <= t_exit) break;                           // nothing beyond this cell can be nearer
         if (t_exit > g.t_end) break;
         k0 = n0; k1 = n1;
@@ -276,17 +329,38 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
     GridWalk g;
     { RPT_PROF(PB_GRID_BEGIN); g = grid_begin(sc, ray); }
     uint32_t k0 = 0, k1 = 0;
-    if (g.alive) { const uint32_t c = grid_cell_index(sc, g); k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1]; }
+    if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
     for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
         RPT_PROF(PB_GRID_CELL);
         const float t_exit = grid_cell_exit(g);
         grid_step(sc, g);                                           // as in grid_closest_sphere
         uint32_t n0 = 0, n1 = 0;
-        if (g.alive) { const uint32_t c = grid_cell_index(sc, g); n0 = sc.cell_start[c]; n1 = sc.cell_start[c + 1]; }
-        for (uint32_t k = k0; k < k1; ++k) {
-            const float4 s = sc.cell_spheres[k];
-            float t;
-            if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (!use_max || t < max_dist)) return true;
+        if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), n0, n1);
+        // (as in grid_closest_sphere; parking the candidate as well, or 3 per trip, is slower here: -2 %, -4 %)
+        for (uint32_t k = k0; k < k1; k += RPT_GRID_BATCH_ANY) {
+            float4 sp[RPT_GRID_BATCH_ANY];
+            bool cand[RPT_GRID_BATCH_ANY];
+            bool any_cand = false;
+#pragma unroll
+            for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) {
+                sp[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (k + j < k1) sp[j] = sc.cell_spheres[k + j];
+            }
+#pragma unroll
+            for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) {
+                const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
+                const float tca = dot3(l, ray.d);
+                const float d2 = dot3(l, l) - tca * tca;
+                cand[j] = (k + j < k1) && !(d2 > sp[j].w * sp[j].w);
+                any_cand = any_cand || cand[j];
+            }
+            if (any_cand) {
+#pragma unroll
+                for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) {
+                    float t;
+                    if (cand[j] && hit_sphere(ray, mk3(sp[j].x, sp[j].y, sp[j].z), sp[j].w, t) && (!use_max || t < max_dist)) return true;
+                }
+            }
         }
         if (t_exit > g.t_end) break;
         if (use_max && t_exit > max_dist) {

@@ -50,14 +50,6 @@ struct WfBuffers {
     uint32_t n_slots, n_seg;
 };
 
-// cell_start[c], cell_start[c + 1] in one 8-byte load (dword-aligned)
-RPT_DEV void cell_bounds(const SceneLarge& sc, uint32_t c, uint32_t& k0, uint32_t& k1)
-{
-    struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
-    const Pair r = *reinterpret_cast<const Pair*>(sc.cell_start + c);
-    k0 = r.a; k1 = r.b;
-}
-
 // closest_hit's sphere part arrives from the walk kernel
 struct WaveQuery {
     float dist;

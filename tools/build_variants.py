@@ -26,6 +26,21 @@ VARIANTS = {
     "compact5": ["-DRPT_COMPACT_WAVES_PER_SIMD=5"],
     "compact6": ["-DRPT_COMPACT_WAVES_PER_SIMD=6"],
     "compact7": ["-DRPT_COMPACT_WAVES_PER_SIMD=7"],
+    "gridbatch2": ["-DRPT_GRID_BATCH=2"],
+    "gridbatch4": ["-DRPT_GRID_BATCH=4"],
+    "gridbatch4w5": ["-DRPT_GRID_BATCH=4", "-DRPT_LARGE_WAVES_PER_SIMD=5"],
+    "gridbatch2any2": ["-DRPT_GRID_BATCH=2", "-DRPT_GRID_BATCH_ANY=2"],
+    "gridbatch2any4": ["-DRPT_GRID_BATCH=2", "-DRPT_GRID_BATCH_ANY=4"],
+    "gridany2": ["-DRPT_GRID_BATCH_ANY=2"],
+    "bounds2loads": ["-DRPT_CELL_BOUNDS_TWO_LOADS"],
+    "gridpark": ["-DRPT_GRID_PARK"],
+    "parkany": ["-DRPT_GRID_PARK_ANY"],
+    "batch3": ["-DRPT_GRID_BATCH=3"],
+    "any3": ["-DRPT_GRID_BATCH_ANY=3"],
+    "gridpark_w5": ["-DRPT_GRID_PARK", "-DRPT_LARGE_WAVES_PER_SIMD=5"],
+    "base_w5": ["-DRPT_LARGE_WAVES_PER_SIMD=5"],
+    "base_w7": ["-DRPT_LARGE_WAVES_PER_SIMD=7"],
+    "gridbatch1": ["-DRPT_GRID_BATCH=1", "-DRPT_GRID_BATCH_ANY=1"],
     "compact8": ["-DRPT_COMPACT_WAVES_PER_SIMD=8"],
 }
 
