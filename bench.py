@@ -55,17 +55,91 @@ def _cpu_quota():
     return n
 
 
-def op_counts():
-    """Algorithmic flops per sample of the AnalyticalScene view, measured by the op-counting build of the oracle."""
+def op_counts(desc=None, frame=(240, 136, 4), skip_missed_sphere_tests=False):
+    """Algorithmic flops per sample of a scene's view (default: the AnalyticalScene), measured by the op-counting build of
+    the oracle on a small frame of the same view.  `skip_missed_sphere_tests`: leave out the operations of ray/sphere tests
+    that missed — what a scene with an acceleration structure is priced against (the oracle's loop tests every sphere:
+    0.4 Mflop per sample on 10 000 spheres, of which 99.6 % are misses a grid never executes)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     oc = oracle_lib.Oracle("liboracle_opcount.so")
-    cw, ch, cs = 240, 136, 4
-    c = oc.opcount(oc.scene_analytical(), cw, ch, cs, seed=1)
+    cw, ch, cs = frame
+    c, missed = oc.opcount_split(desc if desc is not None else oc.scene_analytical(), cw, ch, cs, seed=1)
     n = cw * ch * cs
-    return {"flops_per_sample": round((c["add"] + c["mul"] + c["div"] + c["sqrt"]) / n, 1),
-            "transcendentals_per_sample": round(c["transc"] / n, 2),
-            "divides_per_sample": round(c["div"] / n, 2), "sqrts_per_sample": round(c["sqrt"] / n, 2)}
+    out = {}
+    if skip_missed_sphere_tests:
+        out["brute_force_flops_per_sample"] = round((c["add"] + c["mul"] + c["div"] + c["sqrt"]) / n, 1)
+        c = {k: c[k] - missed[k] for k in c}
+    out.update({"flops_per_sample": round((c["add"] + c["mul"] + c["div"] + c["sqrt"]) / n, 1),
+                "transcendentals_per_sample": round(c["transc"] / n, 2),
+                "divides_per_sample": round(c["div"] / n, 2), "sqrts_per_sample": round(c["sqrt"] / n, 2)})
+    return out
+
+
+def roofline_block(ops, launch_samples, kernel_s, kernel, launches, pixels):
+    """FP32-VALU roofline of one config (no dense contraction, HBM is not the limiter): algorithmic flops per
+    step = flops per sample (oracle op counts) x samples per step, over the measured duration of the step's launches."""
+    tfl = ops["flops_per_sample"] * launch_samples / kernel_s / 1e12
+    # the same work with every correctly rounded divide / sqrt counted at the 12 / 15 VALU instructions
+    # (~2 flops each where they are fmas) gfx950 needs for it: what the VALU actually has to issue
+    expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (2 * 12 - 1) + ops["sqrts_per_sample"] * (2 * 15 - 1)
+    hbm = 32.0 * pixels / kernel_s / 1e9
+    return {"bound": "fp32_valu", "achieved": round(tfl, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tfl / FP32_PEAK_TFLOPS, 5), "traffic": None,
+            "kernel": kernel, "kernel_ms": round(kernel_s * 1e3, 3), "launches_per_step": launches,
+            "algorithmic_flops_per_step": ops["flops_per_sample"] * launch_samples, **ops,
+            "ieee_expanded_flops_per_sample": round(expanded, 1),
+            "ieee_expanded_frac": round(expanded * launch_samples / kernel_s / 1e12 / FP32_PEAK_TFLOPS, 5),
+            "hbm_algorithmic_GBs": round(hbm, 3), "hbm_frac": round(hbm / HBM_PEAK_GBS, 6)}
+
+
+def other_configs(rpt, torch, device, small):
+    """BASELINE.json configs[3] and configs[4] on one GPU, after the headline's timed region: a few steps each, HIP events on
+    the launch stream, with their own op-counted flops per sample -> `roofline_c4` / `roofline_c5` (secondary keys)."""
+    from rust_pathtracer_amd import scenes
+
+    def run(scene, w, h, spp, reps):
+        tracer = rpt.Tracer(scene, device=device, seed=1)
+        buf = rpt.DeviceColorBuffer(w, h, device="cuda:%d" % device)
+        tracer.render_n(buf, 1)
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tracer.render_n(buf, spp)
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        tracer.close()
+        del buf
+        return sum(ms) / len(ms) / 1e3
+
+    out = {}
+    div = 8 if small else 1
+    sdf = scenes.sdf_scene()
+    w, h, spp = 1920 // div, 1080 // div, 64 // (4 if small else 1)
+    t = run(sdf, w, h, spp, 3)
+    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march_kernel", 1, w * h)
+    blk.update({"workload": "SDF sphere-march scene %dx%d x %d spp per step (BASELINE.json configs[3])" % (w, h, spp),
+                "value": round(w * h * spp / t / 1e6, 2), "value_unit": "Msamples/s"})
+    out["roofline_c4"] = blk
+    big = scenes.random_spheres_scene(10000, 16)
+    ops = op_counts(big.describe(), (128, 128, 1), skip_missed_sphere_tests=True)
+    w = h = 4096 // div
+    full = 512 // (16 if small else 1)
+    t_full = run(big, w, h, full, 1)
+    blk = roofline_block(ops, w * h * full, t_full, "render_large_regen_kernel", 1, w * h)
+    blk.update({"workload": "10k spheres + 16 lights %dx%d x %d spp in one call (BASELINE.json configs[4], the whole frame on one GPU)" % (w, h, full),
+                "value": round(w * h * full / t_full / 1e6, 2), "value_unit": "Msamples/s",
+                "note": "flops per sample exclude ray/sphere tests that missed (brute_force_flops_per_sample is the oracle's loop); "
+                        "the grid walk's own arithmetic is not algorithmic work and is not counted"})
+    t8 = run(big, w, h, 8, 2)
+    blk["progressive_8spp"] = {"kernel": "wf_walk_kernel + wf_shade_kernel" if w * h >= (3 << 19) else "render_large_regen_kernel",
+                               "kernel_ms": round(t8 * 1e3, 3), "value": round(w * h * 8 / t8 / 1e6, 2),
+                               "frac": round(ops["flops_per_sample"] * w * h * 8 / t8 / 1e12 / FP32_PEAK_TFLOPS, 5)}
+    out["roofline_c5"] = blk
+    return out
 
 
 def cpu_baseline(width, height, budget_s=12.0):
@@ -156,6 +230,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU leg (profiling runs)")
+    ap.add_argument("--headline-only", action="store_true", help="skip the secondary configs[3] / configs[4] legs (profiling runs)")
     ap.add_argument("--smoke-shared-gpu", action="store_true",
                     help="TEST ONLY: every rank drives cuda:0 and the tiles are gathered with peer copies (RCCL rejects "
                          "duplicate devices), to exercise the N>1 control flow on a 1-GPU box; the numbers mean nothing")
@@ -332,25 +407,15 @@ def main():
         value = samples / elapsed / 1e6
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
         ops = op_counts()
-        # FP32-VALU roofline of the megakernel (no dense contraction, HBM is not the limiter):
-        # algorithmic flops per launch = flops per sample (measured by the oracle's op-counting build) x this rank's
-        # pixels x spp, over the launch's measured duration.
+        # FP32-VALU roofline of the megakernel: this rank's pixels x spp per step over the step's measured launch time
         launch_samples = local_pixels * spp
-        tfl = ops["flops_per_sample"] * launch_samples / avg_kernel_s / 1e12
-        # the same work with every correctly rounded divide / sqrt counted at the 12 / 15 VALU instructions
-        # (~2 flops each where they are fmas) gfx950 needs for it: what the VALU actually has to issue
-        expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (2 * 12 - 1) + ops["sqrts_per_sample"] * (2 * 15 - 1)
         algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
         hbm = algo_bytes / avg_kernel_s / 1e9
         launches = -(-spp // 512)                 # the kernel's LDS tables hold 512 samples: longer batches are split
-        roofline = {"bound": "fp32_valu", "achieved": round(tfl, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(tfl / FP32_PEAK_TFLOPS, 5), "traffic": None,
-                    "kernel": "render_small_regen_kernel", "kernel_ms": round(avg_kernel_s * 1e3, 3), "launches_per_step": launches,
-                    "algorithmic_flops_per_step": ops["flops_per_sample"] * launch_samples, **ops,
-                    "ieee_expanded_flops_per_sample": round(expanded, 1),
-                    "ieee_expanded_frac": round(expanded * launch_samples / avg_kernel_s / 1e12 / FP32_PEAK_TFLOPS, 5),
-                    "note": "algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
-                            "rounded f32 divide or sqrt costs 12-15 VALU instructions on gfx950; kernel_ms = HIP events on the launch stream"}
+        kernel = "render_small_regen_kernel" if spp > 2 else "render_small_compact_kernel"     # (capi.hip: RPT_COMPACT_MAX_SPP)
+        roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels)
+        roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
+                            "rounded f32 divide or sqrt costs 12-15 VALU instructions on gfx950; kernel_ms = HIP events on the launch stream")
         tj = os.path.join(ROOT, TRAFFIC_JSON)
         if world == 1 and not args.small and os.path.exists(tj):
             t = json.load(open(tj))
@@ -386,6 +451,8 @@ def main():
                              "note": "32/S bytes per pixel-sample: the honest signature of an ALU-bound path, not the binding roofline"},
         }
         out.update(extra)
+        if world == 1 and not args.headline_only:
+            out.update(other_configs(rpt, torch, local_rank, args.small))
         if world == 1 and not args.no_cpu_baseline and not args.small:
             cpu = cpu_baseline(width, height)
             out["cpu_baseline"] = cpu

@@ -424,6 +424,13 @@ int rpt_probe_fn(rpt_ctx* ctx, uint32_t fn, const float* in_dev, float* out_dev,
  * or 0xFFFFFFFF, any_hit (0/1) with max_dist honoured}.  use_grid = 0 forces the brute-force loops. */
 int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint64_t n, uint32_t use_grid, void* stream);
 
+/* Multi-device contexts, after rpt_render / rpt_resident_render: the time in ms from the moment device index `b` (position in
+ * rpt_create_multi's list) BEGAN its part of the last render to the moment device index `a` ENDED its part (HIP events on their
+ * streams).  Positive for a != b means the two overlapped: what the fan-out inside render() promises (tracer.rs:29-32).  Events
+ * of two different physical devices cannot be compared (RPT_ERR_UNSUPPORTED): the probe is for virtual ranks, i.e. repeated
+ * device ids under RPT_GATHER=p2p.  Waits for both events. */
+int rpt_debug_render_overlap_ms(rpt_ctx* ctx, int a, int b, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -207,6 +207,21 @@ int oracle_opcount(const rpt_scene_desc* desc, uint32_t width, uint32_t height, 
     return 0;
 }
 
+// The same plus, in counts[6..11], the part of it spent in scene-sphere tests that missed (rpt_oracle.hpp, g_ops_missed).
+int oracle_opcount_split(const rpt_scene_desc* desc, uint32_t width, uint32_t height, uint32_t spp, uint64_t seed, uint64_t* counts)
+{
+    for (int i = 0; i < 12; ++i) counts[i] = 0;
+#ifdef RPT_OPCOUNT
+    g_ops_missed = OpCounts();
+    oracle_opcount(desc, width, height, spp, seed, counts);
+    counts[6] = g_ops_missed.add; counts[7] = g_ops_missed.mul; counts[8] = g_ops_missed.div;
+    counts[9] = g_ops_missed.sqrt; counts[10] = g_ops_missed.transc; counts[11] = g_ops_missed.cmp;
+#else
+    (void)desc; (void)width; (void)height; (void)spp; (void)seed;
+#endif
+    return 0;
+}
+
 // ---- leaf probes (known-answer tests) ---------------------------------------
 int oracle_sphere(const float* o, const float* d, const float* c, float radius, float* t)
 {

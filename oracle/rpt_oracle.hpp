@@ -49,6 +49,19 @@ struct OpCounts {
 
 #ifdef RPT_OPCOUNT
 inline thread_local OpCounts g_ops;
+// Operations spent in tests of SCENE spheres that missed (closest_hit / any_hit loops): what an ideal acceleration
+// structure never executes.  bench.py prices a large scene's kernels against g_ops - g_ops_missed, not against the
+// brute-force loop's count (10 000 tests per query).
+inline thread_local OpCounts g_ops_missed;
+struct MissedSphereTest {
+    OpCounts before;
+    MissedSphereTest() : before(g_ops) {}
+    void missed()
+    {
+        g_ops_missed.add += g_ops.add - before.add; g_ops_missed.mul += g_ops.mul - before.mul; g_ops_missed.div += g_ops.div - before.div;
+        g_ops_missed.sqrt += g_ops.sqrt - before.sqrt; g_ops_missed.transc += g_ops.transc - before.transc; g_ops_missed.cmp += g_ops.cmp - before.cmp;
+    }
+};
 struct F {
     float v;
     F() : v(0.0f) {}
@@ -76,6 +89,7 @@ typedef float F;
 inline float raw(F a) { return a; }
 inline void count_sqrt() {}
 inline void count_transc() {}
+struct MissedSphereTest { void missed() {} };
 #endif
 
 // crate constants: rust-pathtracer/src/lib.rs:8-10
@@ -502,7 +516,9 @@ struct Scene {
         for (const rpt_sphere& s : spheres) {
             F3 center(s.center[0], s.center[1], s.center[2]);
             F dd;
-            if (sphere(ray, center, s.radius, dd)) {
+            MissedSphereTest mt;
+            if (!sphere(ray, center, s.radius, dd)) mt.missed();
+            else {
                 if (first || dd < dist) {
                     F3 hp = ray.at(dd);
                     state.hit_dist = dd;
@@ -551,8 +567,9 @@ struct Scene {
         bool use_max = (d.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
         for (const rpt_sphere& s : spheres) {
             F dd;
-            if (sphere(ray, F3(s.center[0], s.center[1], s.center[2]), s.radius, dd))
-                if (!use_max || dd < max_dist) return true;
+            MissedSphereTest mt;
+            if (!sphere(ray, F3(s.center[0], s.center[1], s.center[2]), s.radius, dd)) mt.missed();
+            else if (!use_max || dd < max_dist) return true;
         }
         for (const rpt_plane& p : planes) {
             F dd;

@@ -126,18 +126,22 @@ struct RcclApi {
     std::string error;
 };
 
-static RcclApi* rccl_api()
+// Loads librccl once per process (thread-safe: a function-local static's initialiser); false when it cannot be loaded.
+static bool rccl_load(RcclApi& api)
 {
-    static RcclApi api;
-    static bool tried = false;
-    if (tried) return api.handle ? &api : nullptr;
-    tried = true;
+    const char* forced = getenv("RPT_RCCL_LIB");                     // tests: a name that cannot be loaded exercises the error path
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-        if (api.handle) break;
+    if (forced) api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+    else
+        for (const char* n : names) {
+            api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (api.handle) break;
+        }
+    if (!api.handle) {
+        const char* e = dlerror();                                   // (the call clears the pending error: read it once)
+        api.error = e ? e : "dlopen(librccl.so.1) failed";
+        return false;
     }
-    if (!api.handle) { api.error = dlerror() ? dlerror() : "dlopen(librccl.so.1) failed"; return nullptr; }
     bool ok = true;
     auto sym = [&](const char* name) { void* p = dlsym(api.handle, name); if (!p) { ok = false; api.error = std::string("librccl: missing symbol ") + name; } return p; };
     api.GetUniqueId = (decltype(api.GetUniqueId))sym("ncclGetUniqueId");
@@ -149,9 +153,17 @@ static RcclApi* rccl_api()
     api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
     api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
     api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
-    if (!ok) { dlclose(api.handle); api.handle = nullptr; return nullptr; }
-    return &api;
+    if (!ok) { dlclose(api.handle); api.handle = nullptr; return false; }
+    return true;
 }
+
+static RcclApi g_rccl;
+static RcclApi* rccl_api()
+{
+    static const bool loaded = rccl_load(g_rccl);
+    return loaded ? &g_rccl : nullptr;
+}
+static const char* rccl_why() { return g_rccl.error.empty() ? "unknown reason" : g_rccl.error.c_str(); }
 
 #define RPT_RCCL_CHECK(ctx, api, call)                                                            \
     do {                                                                                          \
@@ -181,6 +193,7 @@ static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_
 // Which form a large scene with a grid takes (include/rpt.h).  RPT_LARGE_FORM=wavefront|megakernel overrides flags and
 // default (A/B runs of unmodified callers).
 constexpr uint64_t kWavefrontMinPixels = 3ull << 19;                // 1.5 M
+constexpr uint64_t kWavefrontMaxBlindIterations = 256;              // iterations render_wavefront enqueues without looking at the device
 constexpr uint32_t kWavefrontMaxSpp = 8;                            // the megakernel regenerates over a launch's samples: from 16 per launch it is the faster form
 static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels, uint32_t spp)
 {
@@ -411,6 +424,16 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     if (wavefront) {
         const uint64_t n_slots = (uint64_t)rp.rows_local * width;
         const bool forced = (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
+        // The wavefront form enqueues up to 2 * (spp * max_depth + 1) launches per chunk and, past 256 iterations, has the host
+        // look at the device's "anything left?" flag every 256 (kernels.hip, render_wavefront) — a wait that would keep the one
+        // host thread of a multi-device context from feeding its other devices.  Such contexts take the megakernel for deep
+        // bounds unless the caller insists.
+        const uint32_t chunk_spp = spp < rptlaunch::max_spp_per_launch() ? spp : rptlaunch::max_spp_per_launch();
+        if (!forced && ctx->devs.size() > 1 && (uint64_t)chunk_spp * scl.max_depth + 1u > kWavefrontMaxBlindIterations) wavefront = false;
+    }
+    if (wavefront) {
+        const uint64_t n_slots = (uint64_t)rp.rows_local * width;
+        const bool forced = (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
         if (n_slots >= (1ull << 31)) {
             if (forced) { set_err(ctx, "render: tile too large for the wavefront form"); return RPT_ERR_INVALID_ARG; }
             wavefront = false;
@@ -439,8 +462,8 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         const uint32_t chunk = (spp - done > max_chunk) ? max_chunk : (spp - done);
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
-        if (wavefront && (flags & RPT_RENDER_FAST_MATH)) RPT_HIP_CHECK(ctx, rptlaunch_fast::render_wavefront(scl, rp, wb, ctx->devs.size() == 1, stream));
-        else if (wavefront) RPT_HIP_CHECK(ctx, rptlaunch::render_wavefront(scl, rp, wb, ctx->devs.size() == 1, stream));
+        if (wavefront && (flags & RPT_RENDER_FAST_MATH)) RPT_HIP_CHECK(ctx, rptlaunch_fast::render_wavefront(scl, rp, wb, stream));
+        else if (wavefront) RPT_HIP_CHECK(ctx, rptlaunch::render_wavefront(scl, rp, wb, stream));
         else if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
         else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
         done += chunk;
@@ -457,6 +480,20 @@ static int ensure_fb(rpt_ctx* ctx, DevState& d, size_t bytes)
     }
     return RPT_OK;
 }
+
+// Page-locks a caller's host buffer for the duration of one call (rpt_render on several devices).  A buffer the caller
+// has registered itself stays as it is; any other failure leaves the buffer pageable (the copies then take HIP's
+// staging path: correct, less overlap).
+struct HostPin {
+    void* p = nullptr;
+    void lock(void* ptr, size_t bytes)
+    {
+        const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+        if (e == hipSuccess) p = ptr;
+        else (void)hipGetLastError();
+    }
+    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+};
 
 extern "C" {
 
@@ -563,7 +600,7 @@ int rpt_create_multi(rpt_ctx** out, const int* device_ids, int n_devices)
     if (ctx->use_comm) {
         RcclApi* api = rccl_api();
         int rc = RPT_OK;
-        if (!api) { set_err(nullptr, "rpt_create_multi: cannot load RCCL"); rc = RPT_ERR_RCCL; }
+        if (!api) { set_err(nullptr, "rpt_create_multi: cannot load RCCL: %s", rccl_why()); rc = RPT_ERR_RCCL; }
         else {
             std::vector<ncclComm_t> comms((size_t)n_devices, nullptr);
             DeviceGuard guard(device_ids[0]);
@@ -582,7 +619,7 @@ int rpt_comm_unique_id(rpt_unique_id* out)
     static_assert(sizeof(rpt_unique_id) == sizeof(ncclUniqueId), "rpt_unique_id carries an ncclUniqueId");
     if (!out) { set_err(nullptr, "rpt_comm_unique_id: out is NULL"); return RPT_ERR_INVALID_ARG; }
     RcclApi* api = rccl_api();
-    if (!api) { set_err(nullptr, "rpt_comm_unique_id: cannot load RCCL"); return RPT_ERR_RCCL; }
+    if (!api) { set_err(nullptr, "rpt_comm_unique_id: cannot load RCCL: %s", rccl_why()); return RPT_ERR_RCCL; }
     ncclUniqueId id;
     ncclResult_t r = api->GetUniqueId(&id);
     if (r != ncclSuccess) { set_err(nullptr, "rpt_comm_unique_id: ncclGetUniqueId failed: %s", api->GetErrorString(r)); return RPT_ERR_RCCL; }
@@ -596,7 +633,7 @@ int rpt_create_rank(rpt_ctx** out, int device_id, int rank, int world, const rpt
     *out = nullptr;
     if (!id || world < 1 || rank < 0 || rank >= world) { set_err(nullptr, "rpt_create_rank: invalid argument (rank %d of %d)", rank, world); return RPT_ERR_INVALID_ARG; }
     RcclApi* api = rccl_api();
-    if (!api) { set_err(nullptr, "rpt_create_rank: cannot load RCCL"); return RPT_ERR_RCCL; }
+    if (!api) { set_err(nullptr, "rpt_create_rank: cannot load RCCL: %s", rccl_why()); return RPT_ERR_RCCL; }
     rpt_ctx* ctx = new (std::nothrow) rpt_ctx();
     if (!ctx) return RPT_ERR_HIP;
     ctx->devs.resize(1);
@@ -857,24 +894,64 @@ int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height, uin
         return RPT_ERR_UNSUPPORTED;
     }
     // The fan-out of tracer.rs:29-32: every device takes its rows of the caller's buffer (one strided copy each way,
-    // each device over its own PCIe link), all devices render concurrently, one host thread.
+    // each device over its own PCIe link) and all devices render concurrently, driven by one host thread.  Two things make
+    // that true on a caller's pageable Vec<f32>: (1) with more than one device the buffer is page-locked for the duration
+    // of the call (hipHostRegister), so every copy is a real asynchronous DMA — a copy to or from pageable memory returns
+    // only when it is done, i.e. after that device's kernel; (2) the copies back are enqueued in a second pass, after
+    // EVERY device has its upload and its launches, so even without the page lock (RPT_PIN_HOST=0, or a registration
+    // that fails) no device waits for another one's kernel before it starts.
     DeviceGuard guard(ctx->devs[0].device);
     const uint32_t world = (uint32_t)ctx->world;
     const uint32_t tile_rows = world == 1 ? height : ctx->tile_rows;
     const uint32_t rows_padded = rows_padded_for(height, tile_rows, world);
+    HostPin pin;
+    static const bool pin_wanted = !(getenv("RPT_PIN_HOST") && atoi(getenv("RPT_PIN_HOST")) == 0);
+    if (ctx->devs.size() > 1 && pin_wanted) pin.lock(pixels, (size_t)width * height * 16u);
+    const auto enqueue = [&]() -> int {
+        for (DevState& d : ctx->devs) {
+            RPT_HIP_CHECK(ctx, guard.to(d.device));
+            int rc = ensure_fb(ctx, d, (size_t)rows_padded * width * 16u);
+            if (rc != RPT_OK) return rc;
+            RPT_HIP_CHECK(ctx, hipEventRecord(d.ev_begin, d.stream));
+            RPT_HIP_CHECK(ctx, copy_rank_rows(true, pixels, d.fb, width, height, tile_rows, (uint32_t)d.rank, world, d.stream));
+            rc = launch_render(ctx, d, d.fb, width, height, frames_done, spp, seed, flags, tile_rows, (uint32_t)d.rank, world, d.stream);
+            if (rc != RPT_OK) return rc;
+            RPT_HIP_CHECK(ctx, hipEventRecord(d.ev_end, d.stream));
+        }
+        ctx->timed = true;
+        for (DevState& d : ctx->devs) {
+            RPT_HIP_CHECK(ctx, guard.to(d.device));
+            RPT_HIP_CHECK(ctx, copy_rank_rows(false, pixels, d.fb, width, height, tile_rows, (uint32_t)d.rank, world, d.stream));
+        }
+        return RPT_OK;
+    };
+    const int rc = enqueue();
+    // wait for every device whatever happened: copies already enqueued still use the caller's (page-locked) buffer
+    int rc_sync = RPT_OK;
     for (DevState& d : ctx->devs) {
-        RPT_HIP_CHECK(ctx, guard.to(d.device));
-        int rc = ensure_fb(ctx, d, (size_t)rows_padded * width * 16u);
-        if (rc != RPT_OK) return rc;
-        RPT_HIP_CHECK(ctx, copy_rank_rows(true, pixels, d.fb, width, height, tile_rows, (uint32_t)d.rank, world, d.stream));
-        rc = launch_render(ctx, d, d.fb, width, height, frames_done, spp, seed, flags, tile_rows, (uint32_t)d.rank, world, d.stream);
-        if (rc != RPT_OK) return rc;
-        RPT_HIP_CHECK(ctx, copy_rank_rows(false, pixels, d.fb, width, height, tile_rows, (uint32_t)d.rank, world, d.stream));
+        if (guard.to(d.device) != hipSuccess || hipStreamSynchronize(d.stream) != hipSuccess) {
+            if (rc == RPT_OK && rc_sync == RPT_OK) set_err(ctx, "rpt_render: waiting for device %d failed: %s", d.device, hipGetErrorString(hipGetLastError()));
+            rc_sync = RPT_ERR_HIP;
+        }
     }
-    for (DevState& d : ctx->devs) {
-        RPT_HIP_CHECK(ctx, guard.to(d.device));
-        RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
+    return rc != RPT_OK ? rc : rc_sync;
+}
+
+// Test probe (include/rpt.h): how long before device `a`'s last render ENDED device `b`'s began.
+int rpt_debug_render_overlap_ms(rpt_ctx* ctx, int a, int b, float* ms)
+{
+    if (!ctx || !ms || a < 0 || b < 0 || (size_t)a >= ctx->devs.size() || (size_t)b >= ctx->devs.size()) {
+        set_err(ctx, "rpt_debug_render_overlap_ms: invalid argument");
+        return RPT_ERR_INVALID_ARG;
     }
+    if (!ctx->timed) { set_err(ctx, "rpt_debug_render_overlap_ms: no render yet"); return RPT_ERR_INVALID_ARG; }
+    DevState &da = ctx->devs[(size_t)a], &db = ctx->devs[(size_t)b];
+    if (da.device != db.device) { set_err(ctx, "rpt_debug_render_overlap_ms: events of two physical devices cannot be compared"); return RPT_ERR_UNSUPPORTED; }
+    DeviceGuard guard(da.device);
+    RPT_HIP_CHECK(ctx, guard.status);
+    RPT_HIP_CHECK(ctx, hipEventSynchronize(da.ev_end));
+    RPT_HIP_CHECK(ctx, hipEventSynchronize(db.ev_begin));
+    RPT_HIP_CHECK(ctx, hipEventElapsedTime(ms, db.ev_begin, da.ev_end));
     return RPT_OK;
 }
 
@@ -1003,7 +1080,7 @@ static int gather_to_root(rpt_ctx* ctx, float* image_dst, float** image_out)
         // RCCL gather over xGMI: every rank sends its tile to rank 0, which posts one receive per rank; one group, so the
         // 7 incoming transfers use 7 links at once.  Each operation is ordered behind the render on its device's stream.
         RcclApi* api = rccl_api();
-        if (!api) { set_err(ctx, "gather: cannot load RCCL"); return RPT_ERR_RCCL; }
+        if (!api) { set_err(ctx, "gather: cannot load RCCL: %s", rccl_why()); return RPT_ERR_RCCL; }
         RPT_RCCL_CHECK(ctx, api, api->GroupStart());
         for (DevState& d : ctx->devs) {
             if (d.rank == 0)

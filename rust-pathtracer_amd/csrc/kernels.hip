@@ -892,6 +892,7 @@ __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_
 
 #endif  // RPT_AB_KERNELS
 
+#ifndef RPT_RENDER_KERNELS_ONLY      // (kernels_fast.hip: only kernels that contain relaxed arithmetic are built a second time)
 // Scatter rank-major gathered tiles into the full image (one float4 per thread).
 __global__ __launch_bounds__(256) void RPT_K(untile_kernel)(const float4* __restrict__ gathered, float4* __restrict__ image,
                                                      uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
@@ -1085,6 +1086,8 @@ __global__ __launch_bounds__(256) void RPT_K(probe_rays_kernel)(const SceneLarge
     out[i * 3 + 2] = any ? 1u : 0u;
 }
 
+#endif  // RPT_RENDER_KERNELS_ONLY
+
 // ---------------------------------------------------------------------------
 // launch wrappers (launch.h)
 // ---------------------------------------------------------------------------
@@ -1122,7 +1125,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     return hipGetLastError();
 }
 
-hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, bool host_checks, hipStream_t st)
+hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, hipStream_t st)
 {
     static const uint32_t refill_at = getenv("RPT_WF_REFILL_AT") ? ((uint32_t)atoi(getenv("RPT_WF_REFILL_AT")) & 63u) : 40u;
     static const uint32_t blocks_per_group = getenv("RPT_WF_BLOCKS_PER_GROUP") ? (uint32_t)atoi(getenv("RPT_WF_BLOCKS_PER_GROUP")) : 6u;
@@ -1130,15 +1133,17 @@ hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const 
     const dim3 wg(256), all((wb.n_seg * 64u + 255u) / 256u), walkers(kWalkGroups * (blocks_per_group ? blocks_per_group : 1u));
     hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, 0u, 1u);
     // a sample takes at most max_depth walks of its path ray; its last shadow ray is walked beside the next sample's first
-    // ray, except the launch's last sample's.  Launches after the last useful iteration return at once (any_active); when the
-    // bound is long (deep paths that mostly end early) and the caller allows it, the host also looks every 256 iterations.
+    // ray, except the launch's last sample's.  Launches after the last useful iteration return at once (any_active), and
+    // the host enqueues at most 256 iterations without looking: after every 256th it waits for the stream and reads the
+    // flag, so a long bound (deep paths that mostly end early) costs the launches of 256 idle iterations at most —
+    // spp * max_depth can reach 2 M — and a bound of up to 256 iterations is enqueued without any wait.
     const uint64_t bound = (uint64_t)rp.spp * sc.max_depth + 1u;
     uint32_t host_active = 1u;
     for (uint64_t k = 1; k <= bound; ++k) {
         const uint32_t parity = (uint32_t)(k & 1u);
         hipLaunchKernelGGL(RPT_K(wf_walk_kernel), walkers, wg, 0, st, sc, wb, parity, refill_at);
         hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, parity, 0u);
-        if (host_checks && (k & 255u) == 0u && bound - k > 256u) {
+        if ((k & 255u) == 0u && k < bound) {
             hipError_t e = hipMemcpyAsync(&host_active, &wb.any_active[parity], sizeof(uint32_t), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) return e;
@@ -1148,6 +1153,7 @@ hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const 
     return hipGetLastError();
 }
 
+#ifndef RPT_RENDER_KERNELS_ONLY
 hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
                   uint32_t rows_padded, hipStream_t st)
 {
@@ -1206,5 +1212,7 @@ hipError_t probe_rays(const SceneLarge& sc, const float* rays, uint32_t* out, ui
     hipLaunchKernelGGL(RPT_K(probe_rays_kernel), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, sc, rays, out, n);
     return hipGetLastError();
 }
+
+#endif  // RPT_RENDER_KERNELS_ONLY
 
 }  // namespace RPT_LAUNCH_NS

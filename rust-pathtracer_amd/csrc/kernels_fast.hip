@@ -4,6 +4,8 @@
 // reference arithmetic: an ulp-level difference occasionally flips a branch and changes a sample by O(1), so
 // this mode is validated statistically (tests/test_gpu_parity.py::test_fast_math_mode_is_statistically_equivalent)
 // and is never what bench.py measures.
+// Only the render kernels are built here: untile, the u8 conversions and the test probes have no relaxed form.
+#define RPT_RENDER_KERNELS_ONLY
 #define RPT_K(name) name##_fast
 #define RPT_LAUNCH_NS rptlaunch_fast
 #include "kernels.hip"

@@ -42,11 +42,10 @@ uint32_t max_spp_per_launch();      // samples one launch of the regenerating ke
 hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
                   const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr);
 // Large scenes with a grid, wavefront form (dev_wavefront.h): `spp` samples of every pixel of the tile; the buffers hold
-// rp.rows_local * rp.width slots.  Enqueues 1 + 2 * (spp * max_depth + 1) launches at most; launches after the last useful
-// iteration return at once.  `host_checks`: the host may also wait for the stream every 256 iterations of a long bound and stop
-// enqueueing (not in multi-device contexts, whose one thread must keep every device fed).
-hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, bool host_checks,
-                            hipStream_t st);
+// rp.rows_local * rp.width slots.  Needs at most 1 + 2 * (spp * max_depth + 1) launches; launches after the last useful
+// iteration return at once, and the host never has more than 256 iterations enqueued without having looked at the device's
+// "anything left?" flag (it waits for the stream there: a bound of up to 256 iterations is enqueued blind).
+hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st);
 hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
                   uint32_t rows_padded, hipStream_t st);
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st);
@@ -60,8 +59,7 @@ hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t*
 
 // the relaxed-arithmetic build of the same kernels (kernels_fast.hip)
 namespace rptlaunch_fast {
-hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, bool host_checks,
-                            hipStream_t st);
+hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st);
 hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
                   const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr);
 }  // namespace rptlaunch_fast

@@ -61,11 +61,30 @@ def gather_tiles(tile, world, group=None, dst=0):
 def rank_tracer(scene, local_device, seed=1, group=None):
     """One process per GPU: build this rank's Tracer.  Rank 0 asks the library for an RCCL unique id, the job's
     torch.distributed group (gloo or nccl, it only carries 128 bytes) hands it to everybody, and every rank joins
-    the library's own communicator (collective)."""
+    the library's own communicator (collective).
+
+    Every rank makes the same sequence of group calls whatever fails where: what can fail on one rank alone (the
+    library or RCCL not loading, no usable device) is tried first and agreed on with an all_reduce, and rank 0's id
+    travels together with its error, so either every rank reaches ncclCommInitRank or every rank raises."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [comm_unique_id() if rank == 0 else None]
+    why = ""
+    try:
+        comm_unique_id()                                  # RCCL loads in this process (the id itself is thrown away)
+        Tracer(scene, device=local_device, seed=seed).close()   # the device is there and is a gfx950
+    except Exception as e:                                # noqa: BLE001 - reported on every rank below
+        why = "rank %d: %s: %s" % (rank, type(e).__name__, e)
+    ok = torch.tensor([0 if why else 1])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    box = [None, why]
+    if int(ok.item()) == 1 and rank == 0:
+        try:
+            box = [comm_unique_id(), ""]
+        except Exception as e:                            # noqa: BLE001
+            box = [None, "rank 0: %s: %s" % (type(e).__name__, e)]
     dist.broadcast_object_list(box, src=0, group=group)
+    if int(ok.item()) == 0 or box[0] is None:
+        raise RuntimeError("rank_tracer: the library's communicator cannot be set up (%s)" % (why or box[1] or "a failure on another rank"))
     return Tracer(scene, device=local_device, seed=seed, rank=rank, world=world, unique_id=box[0])
 
 

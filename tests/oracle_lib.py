@@ -96,6 +96,15 @@ class Oracle:
         self.lib.oracle_opcount(C.byref(desc), width, height, spp, seed, c.ctypes.data)
         return dict(zip(("add", "mul", "div", "sqrt", "transc", "cmp"), (int(v) for v in c)))
 
+    def opcount_split(self, desc, width, height, spp, seed=1):
+        """(all operations, the part spent in scene-sphere tests that missed): what a brute-force loop does and what an
+        ideal acceleration structure would skip."""
+        c = np.zeros(12, dtype=np.uint64)
+        self.lib.oracle_opcount_split.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p]
+        self.lib.oracle_opcount_split(C.byref(desc), width, height, spp, seed, c.ctypes.data)
+        names = ("add", "mul", "div", "sqrt", "transc", "cmp")
+        return dict(zip(names, (int(v) for v in c[:6]))), dict(zip(names, (int(v) for v in c[6:])))
+
     def sphere(self, o, d, c, radius):
         o, d, c = (np.asarray(v, dtype=np.float32) for v in (o, d, c))
         t = C.c_float(0)

@@ -145,3 +145,27 @@ def test_tile_row_maps(rpt):
         assert sorted(owner) == list(range(height))
         counts = [tiling.tile_row_count(height, tile_rows, r, world) for r in range(world)]
         assert max(counts) - min(counts) <= tile_rows
+
+
+def test_rccl_that_cannot_be_loaded_is_an_error_not_a_crash(rpt):
+    """rpt_comm_unique_id / rpt_create_rank with an RCCL library that cannot be loaded return RPT_ERR_RCCL with dlopen's
+    message (round 2 read dlerror() twice and built a std::string from NULL).  RPT_RCCL_LIB is read once per process: child."""
+    import sys
+    code = r"""
+import ctypes as C, sys
+sys.path.insert(0, %r)
+import conftest
+rpt = conftest.load_package()
+uid = rpt._abi.rpt_unique_id()
+for _ in range(2):                                 # the second call takes the cached failure
+    rc = rpt.lib().rpt_comm_unique_id(C.byref(uid))
+    msg = rpt.lib().rpt_last_error(None)
+    assert rc == rpt._abi.RPT_ERR_RCCL, rc
+    assert b"cannot load RCCL" in msg and b"no-such-rccl" in msg, msg
+h = C.c_void_p()
+assert rpt.lib().rpt_create_rank(C.byref(h), 0, 0, 1, C.byref(uid)) == rpt._abi.RPT_ERR_RCCL
+print("ok")
+""" % os.path.join(ROOT, "tests")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RPT_RCCL_LIB="/no-such-rccl/librccl.so.1"))
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

@@ -96,6 +96,55 @@ def test_virtual_ranks_through_the_multi_context(rpt, oracle, torch_cuda, n, til
     t.close()
 
 
+@pytest.mark.parametrize("pin", ["1", "0"])
+def test_multi_device_render_fans_out(rpt, oracle, torch_cuda, pin):
+    """rpt_render on an n-device context is the reference's parallel render() (tracer.rs:29-32): every device must have BEGUN
+    its rows before the first one has finished.  Virtual ranks on one GPU: the event of rank k's begin (recorded on its stream
+    before its upload) must precede the event of rank 0's end (recorded behind its kernel) — with one loop doing upload ->
+    kernel -> download per device on a pageable buffer (round 2's code) rank 1 begins only after rank 0's download, i.e. after
+    rank 0's end.  Run in a child process per setting: RPT_PIN_HOST is read once per process (1: the caller's buffer is
+    page-locked for the call; 0: pageable copies, the two-pass order alone must do it)."""
+    import subprocess
+    import sys
+    code = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import conftest, oracle_lib
+rpt = conftest.load_package()
+os.environ["RPT_GATHER"] = "p2p"
+n, w, h, spp = 4, 512, 384, 64
+t = rpt.Tracer(rpt.AnalyticalScene(), devices=[0] * n, seed=1)
+buf = rpt.ColorBuffer(w, h)
+t.render_n(buf, 1)                                 # warm: module load, staging allocations
+buf = rpt.ColorBuffer(w, h)
+t.render_n(buf, spp)
+ms = C.c_float()
+gaps = []
+for b in range(1, n):
+    rpt._lib.check(rpt.lib().rpt_debug_render_overlap_ms(t._h, 0, b, C.byref(ms)), t._h)
+    gaps.append(ms.value)
+rpt._lib.check(rpt.lib().rpt_debug_render_overlap_ms(t._h, 0, 0, C.byref(ms)), t._h)
+own = ms.value
+o = oracle_lib.Oracle("liboracle.so")
+want = o.render(o.scene_analytical(), w, h, spp, seed=1)
+same = (buf.image().view(np.uint32) == want.view(np.uint32)).all()
+import json
+print("RESULT" + json.dumps([own, gaps, bool(same)]))
+t.close()
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    env = dict(os.environ, RPT_PIN_HOST=pin)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1]
+    import json
+    own, gaps, same = json.loads(line[len("RESULT"):])
+    assert same, "fan-out changed the image"
+    assert own > 0.0
+    # every other rank began before rank 0 ended (a positive gap), by a good part of rank 0's own span
+    assert all(g > 0.0 for g in gaps), "devices ran one after the other: begin(rank k) - end(rank 0) = %r ms (rank 0 took %.3f ms)" % (gaps, own)
+
+
 def test_duplicate_devices_need_peer_gather(rpt, torch_cuda):
     os.environ.pop("RPT_GATHER", None)
     h = C.c_void_p()

@@ -66,6 +66,44 @@ def test_two_rank_tiled_render_equals_single_process(tmp_path, oracle, tile_rows
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "step %d" % k
 
 
+def _failing_worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    if rank == 1:
+        os.environ["RPT_RCCL_LIB"] = "/no-such-rccl/librccl.so.1"     # this rank cannot even load RCCL
+    import conftest  # noqa: F401
+    import rust_pathtracer_amd as rpt
+    from rust_pathtracer_amd import tiling
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        why = ""
+        try:
+            tiling.rank_tracer(rpt.AnalyticalScene(), 0, seed=1)
+        except RuntimeError as e:
+            why = str(e)
+        # bench.py's next step: the ranks agree on the fallback (must not hang: every rank is here)
+        ok = torch.tensor([0 if why else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("%d|%s" % (int(ok.item()), why))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rank_tracer_fails_on_every_rank_together(tmp_path):
+    """tiling.rank_tracer when the library's communicator cannot be set up (here: no GPU on either rank, and rank 1 cannot load
+    RCCL at all): every rank raises, none is left waiting in a broadcast or inside ncclCommInitRank, and the job's next
+    collective (bench.py's agreement on the fallback) completes."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (on a GPU box rank_tracer succeeds)")
+    world = 2
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_failing_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        ok, why = open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read().split("|", 1)
+        assert ok == "0" and "cannot be set up" in why, (r, ok, why)
+
+
 def test_tile_copy_plan_covers_exactly_the_ranks_rows(rpt):
     """rpt_tile_copy_plan (what rpt_render / rpt_resident_upload follow for their one strided copy per device) against
     the row-by-row definition rpt_tile_global_row, for every rank of many image / block / world sizes."""

@@ -42,6 +42,8 @@ VARIANTS = {
     "base_w7": ["-DRPT_LARGE_WAVES_PER_SIMD=7"],
     "gridbatch1": ["-DRPT_GRID_BATCH=1", "-DRPT_GRID_BATCH_ANY=1"],
     "compact8": ["-DRPT_COMPACT_WAVES_PER_SIMD=8"],
+    # BASELINE.json's "scene/material/light tables staged in LDS": the headline kernel reading its tables from LDS instead of SGPRs
+    "scene_in_lds": ["-DRPT_AB_KERNELS", "-DRPT_SCENE_IN_LDS"],
 }
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_$V
 mkdir -p $OUT
 if [ $# -gt 0 ]; then PROG=("$@"); STATS_PROG=("$@"); KPAT=${RPT_PROFILE_KERNEL:-render_};
-else PROG=(bench.py --steps 2 --warmup 1 --no-cpu-baseline); STATS_PROG=(bench.py --steps 10 --warmup 2 --no-cpu-baseline); KPAT=render_small; fi
+else PROG=(bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only); STATS_PROG=(bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only); KPAT=render_small; fi
 cd /tmp && export TMPDIR=/tmp
 run() {   # name, rocprof args...
     local name=$1; shift
