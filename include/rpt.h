@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RPT_ABI_VERSION 2u
+#define RPT_ABI_VERSION 3u
 
 typedef enum rpt_status {
     RPT_OK              =  0,
@@ -63,8 +63,11 @@ enum {                                /* rpt_material.mask bits */
     RPT_MAT_CLEARCOAT_GLOSS = 1u << 10,
     RPT_MAT_SPEC_TRANS      = 1u << 11,
     RPT_MAT_IOR             = 1u << 12,
-    RPT_MAT_ALL             = (1u << 13) - 1u
+    RPT_MAT_ALL             = (1u << 13) - 1u,   /* every BSDF field */
+    RPT_MAT_MEDIUM          = 1u << 13           /* Material.medium (all four fields at once); only read under RPT_SCENE_MEDIA */
 };
+
+enum { RPT_MEDIUM_NONE = 0, RPT_MEDIUM_ABSORB = 1, RPT_MEDIUM_SCATTER = 2, RPT_MEDIUM_EMISSIVE = 3 };   /* MediumType, material.rs:8-13 */
 
 enum {                                /* rpt_material.proc_kind */
     RPT_PROC_NONE        = 0,
@@ -90,6 +93,11 @@ typedef struct rpt_material {         /* user-set fields of material.rs:48-78 th
     float spec_trans;
     float ior;
     float proc_params[4];
+    /* Material.medium (material.rs:16-21, 75, 107): see "participating media" below */
+    uint32_t medium_type;
+    float medium_density;
+    float medium_color[3];
+    float medium_anisotropy;
 } rpt_material;
 
 typedef struct rpt_sphere {           /* analytical.rs:166-190 */
@@ -183,8 +191,60 @@ enum {                                /* rpt_scene_desc.flags */
     /* Sample and intersect RECTANGULAR and DISTANT lights (project-defined, see rpt_light).  OFF reproduces the
      * reference, whose sample_light and Scene::sample_lights only know LightType::Spherical (tracer.rs:175-217,
      * scene.rs:68): such lights are still picked by the light-index draw but contribute nothing. */
-    RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES = 1u << 1
+    RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES = 1u << 1,
+    /* Participating media (project-defined, see below).  OFF reproduces the reference, which never reads a Medium. */
+    RPT_SCENE_MEDIA = 1u << 2
 };
+
+/* ---- participating media — PROJECT-DEFINED: THERE IS NO REFERENCE BEHAVIOUR TO MATCH ----------------
+ * The reference declares Medium {medium_type, density, color, anisotropy} (material.rs:8-34), carries one in every Material
+ * (material.rs:75,107) and one in State (globals.rs:19,37), clamps the anisotropy in Material::finalize (material.rs:126) —
+ * and tracer.rs never reads any of it ("Support of mediums / volumetric objects" is a Todo, Readme.md:13).  With
+ * RPT_SCENE_MEDIA the fields mean what they mean in the renderer tracer.rs is a port of (its default build: homogeneous
+ * media bounded by surfaces, no nesting, binary shadow rays), made consistent in two places (marked *): the medium acts on
+ * a segment BEFORE what lies at its end is looked at, and a light sample taken inside a medium is attenuated by it.  The
+ * arithmetic (f32, operation order) is the one written in oracle/rpt_oracle.hpp, Tracer::sample_pixel; exp and ln are
+ * rpt_expf / rpt_logf of include/rpt_strict_math.h.
+ *
+ * A path carries `in_medium` (false at the camera) and a copy of the medium it is in (State.medium).  One iteration of
+ * the bounce loop (tracer.rs:61-103) becomes:
+ *   1. state.is_emitter = false (the reference never clears it, which is harmless only because an emitter hit ends the
+ *      path there; here a path can go on after one).  closest_hit; a miss adds the background and ends the path as always
+ *      (also inside a medium: a medium acts only on segments that end on something).
+ *   2.* if in_medium, over seg = state.hit_dist:
+ *        ABSORB    throughput.c *= exp(-(((1 - color.c) * seg) * density))            per channel (Beer-Lambert)
+ *        EMISSIVE  radiance += ((color * seg) * density) * throughput
+ *        SCATTER   one draw r;  d = min(-ln(r) / density, seg)  (f32::min);  if d < seg the path SCATTERS at p = ray.at(d):
+ *                    throughput *= color;
+ *                    next-event estimation from p exactly as direct_light (tracer.rs:126-170) with scatter_pos = p (no
+ *                    offset) and the phase function in place of the BSDF: f = pdf = phase_hg(dot(-ray.direction,
+ *                    light.direction), g), same MIS weight, same `pdf > 0` guard;
+ *                    two draws r1, r2;  dir = sample_hg(-ray.direction, g, r1, r2);  scatter_sample.pdf =
+ *                    phase_hg(dot(-ray.direction, dir), g);  scatter_sample.l = dir;  ray = Ray(p, dir)  (no eps offset);
+ *                    then Russian roulette as after a surface bounce, and the next iteration.  The iteration counts
+ *                    against max_depth like a surface bounce; in_medium stays as it is.
+ *      g = the medium's anisotropy, clamped to [-0.9, 0.9] by Material::finalize (material.rs:126).
+ *   3. (no scatter event) the reference's iteration as it is: State::finalize, emission, the emitter exit — its MIS weight
+ *      reads scatter_sample.pdf, which after a medium scatter is the phase pdf —, direct_light, disney_sample, next ray.
+ *      * In direct_light, when in_medium and light_sample.dist is finite, the unoccluded light's `li` is multiplied by the
+ *      medium's transmittance over light_sample.dist: ABSORB exp(-(((1 - color.c) * dist) * density)) per channel,
+ *      SCATTER exp(-(dist * density)), EMISSIVE 1.  (Shadow rays are the scene's binary any_hit, so this matters for lights
+ *      INSIDE a medium — use RPT_SCENE_ANYHIT_USES_MAX_DIST there; a medium's own boundary occludes lights outside it.)
+ *   4. after the next ray is set (tracer.rs:100-101), if state.material.medium.medium_type != NONE:
+ *        in_medium = dot(ray.direction, state.normal) < 0      (the NEW direction against the geometric normal: entering)
+ *        and when that is true state.medium = state.material.medium.
+ *      Media are entered and left through their boundary surface (a refraction into it, spec_trans > 0, or any scatter
+ *      that ends up on the inner side); there is no stack: media do not nest.
+ *   phase_hg(c, g)  = INV_4_PI * (1 - g*g) / (d * sqrt(d)),  d = 1 + g*g + 2*g*c,  INV_4_PI = 1 / (4 * PI)  (f32)
+ *   sample_hg(v, g, r1, r2):  cos = |g| < 0.001 ? 1 - 2*r2 : -(1 + g*g - q*q) / (2*g),  q = (1 - g*g) / (1 + g - 2*g*r2);
+ *                             phi = r1 * TWO_PI;  sin = clamp(sqrt(1 - cos*cos), 0, 1);  (t, b) = onb(v)  (tracer.rs:184-189);
+ *                             dir = (sin * cos(phi)) * t + (sin * sin(phi)) * b + cos * v
+ * Draw order of an iteration inside a SCATTER medium: the distance draw; then, on a scatter event, light index, light r1,
+ * r2 (if the scene has lights), r1, r2 of sample_hg, [roulette]; otherwise the surface bounce's draws as always.
+ * Materials of small scenes are patches: RPT_MAT_MEDIUM writes all four medium fields.  rpt_upload_scene rejects a
+ * negative or non-finite density.  Kernel forms: every default form renders media (megakernel, nested loops, the
+ * compacting kernel, the SDF march kernel, large scenes' megakernel and wavefront forms); RPT_RENDER_FAST_MATH and the
+ * A/B kernels do not (RPT_ERR_UNSUPPORTED). */
 
 typedef struct rpt_scene_desc {
     uint32_t abi_version;             /* RPT_ABI_VERSION */
@@ -393,7 +453,7 @@ int rpt_synchronize(rpt_ctx* ctx, void* stream);
  * leaf functions with the oracle bit for bit.  Not part of the drop-in surface.  */
 enum {
     RPT_PROBE_SIN = 0, RPT_PROBE_COS = 1, RPT_PROBE_LOG2 = 2, RPT_PROBE_POW = 3,
-    RPT_PROBE_DIV = 4, RPT_PROBE_SQRT = 5, RPT_PROBE_RNG = 6
+    RPT_PROBE_DIV = 4, RPT_PROBE_SQRT = 5, RPT_PROBE_RNG = 6, RPT_PROBE_EXP = 7, RPT_PROBE_LOG = 8
 };
 int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b_dev,
                    float* out_dev, uint64_t n, void* stream);

@@ -20,6 +20,7 @@
  *                 ~1e-7 of inputs
  *   rpt_powf    : f64 core (log2 abs err 1.5e-12, exp2 rel err 1.4e-14), rounded
  *                 once to f32 -> <= 0.5001 ulp
+ *   rpt_expf, rpt_logf : the same cores (2^(x log2 e), log2(x) ln 2), rounded once to f32
  * Coefficients come from tools/gen_strict_math_coeffs.py (mpmath chebyfit).
  *
  * Compile every translation unit that includes this with -ffp-contract=off:
@@ -186,6 +187,24 @@ RPT_HD float rpt_powf(float x, float y)
     if (yint == 0) return __builtin_nanf("");
     float r = rpt_exp2_core((double)y * rpt_log2_core(rpt_u2f(ax)));
     return (yint == 1) ? -r : r;
+}
+
+/* expf / logf (natural): Rust f32::exp / f32::ln semantics for the special cases; the same f64 cores, so <= 0.5001 ulp.
+ * Only the project-defined participating media use them (include/rpt.h): the reference's tracer calls neither. */
+RPT_HD float rpt_expf(float x)
+{
+    if (x != x) return x;                               /* NaN (the clamp below would not propagate it) */
+    return rpt_exp2_core((double)x * 0x1.71547652b82fep+0);   /* 2^(x * log2 e); +-inf -> the clamp -> inf / 0 */
+}
+
+RPT_HD float rpt_logf(float x)
+{
+    uint32_t ix = rpt_f2u(x);
+    if (ix - 1u < 0x7f7fffffu)                          /* 0 < x < inf */
+        return (float)(rpt_log2_core(x) * 0x1.62e42fefa39efp-1);   /* ln 2 */
+    if ((ix << 1) == 0u) return -__builtin_inff();      /* +-0 -> -inf */
+    if (ix == 0x7f800000u) return x;                    /* +inf */
+    return __builtin_nanf("");                          /* negative or NaN */
 }
 
 #endif /* RPT_STRICT_MATH_H */

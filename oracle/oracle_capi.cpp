@@ -396,10 +396,20 @@ void oracle_math(uint32_t fn, const float* a, const float* b, float* out, uint64
         case 3: out[i] = raw(f_powf(a[i], b[i])); break;
         case 4: out[i] = a[i] / b[i]; break;
         case 5: out[i] = std::sqrt(a[i]); break;
-        case 7: out[i] = raw(f_tan(a[i])); break;
+        case 7: out[i] = raw(f_exp(a[i])); break;           // RPT_PROBE_EXP
+        case 8: out[i] = raw(f_ln(a[i])); break;            // RPT_PROBE_LOG
+        case 100: out[i] = raw(f_tan(a[i])); break;         // host only (the camera's fov)
         default: out[i] = 0.0f;
         }
     }
+}
+
+// Media leaves (PROJECT-DEFINED, include/rpt.h): the phase function and its sampling.
+float oracle_phase_hg(float cos_theta, float g) { return raw(Tracer::phase_hg(cos_theta, g)); }
+void oracle_sample_hg(const float* v, float g, float r1, float r2, float* out)
+{
+    F3 d = Tracer::sample_hg(F3(v[0], v[1], v[2]), g, r1, r2);
+    out[0] = raw(d.x); out[1] = raw(d.y); out[2] = raw(d.z);
 }
 
 // ColorBuffer::convert_to_u8, buffer.rs:55-64: (p.powf(0.4545) * 255.0) as u8 for

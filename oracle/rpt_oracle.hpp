@@ -96,6 +96,7 @@ struct MissedSphereTest { void missed() {} };
 static const float PI_F = 3.14159265358979323846f;          // std::f32::consts::PI
 static const float INV_PI_F = 1.0f / 3.14159265358979323846f;
 static const float TWO_PI_F = 3.14159265358979323846f * 2.0f;
+static const float INV_4_PI_F = 0.0795774715459476679f;     // PROJECT-DEFINED (media, include/rpt.h): 1 / (4 pi) rounded to f32
 
 // --- f32 intrinsics with Rust semantics -----------------------------------
 inline F f_sqrt(F x) { count_sqrt(); return F(std::sqrt(raw(x))); }
@@ -117,6 +118,13 @@ inline F f_clamp(F x, float lo, float hi)
     if (a > hi) return F(hi);
     return F(a);
 }
+inline F f_min(F self, F other)
+{
+    float a = raw(self), b = raw(other);
+    if (a != a) return F(b);
+    if (b != b) return F(a);
+    return F(a < b ? a : b);
+}
 // Rust's `%` on f32 is C fmodf (exact).
 inline F f_rem(F a, float b) { return F(std::fmod(raw(a), b)); }
 
@@ -126,12 +134,16 @@ inline F f_cos(F x) { count_transc(); return F(::cosf(raw(x))); }
 inline F f_tan(F x) { count_transc(); return F(::tanf(raw(x))); }
 inline F f_powf(F x, F y) { count_transc(); return F(::powf(raw(x), raw(y))); }
 inline F f_log2(F x) { count_transc(); return F(::log2f(raw(x))); }
+inline F f_exp(F x) { count_transc(); return F(::expf(raw(x))); }
+inline F f_ln(F x) { count_transc(); return F(::logf(raw(x))); }
 #else
 inline F f_sin(F x) { count_transc(); return F(rpt_sinf(raw(x))); }
 inline F f_cos(F x) { count_transc(); return F(rpt_cosf(raw(x))); }
 inline F f_tan(F x) { count_transc(); return F(rpt_tanf(raw(x))); }
 inline F f_powf(F x, F y) { count_transc(); return F(rpt_powf(raw(x), raw(y))); }
 inline F f_log2(F x) { count_transc(); return F(rpt_log2f(raw(x))); }
+inline F f_exp(F x) { count_transc(); return F(rpt_expf(raw(x))); }
+inline F f_ln(F x) { count_transc(); return F(rpt_logf(raw(x))); }
 #endif
 
 // ---------------------------------------------------------------------------
@@ -191,10 +203,19 @@ struct Ray {
 // ---------------------------------------------------------------------------
 // Material — rust-pathtracer/src/material.rs:48-131 (fields the tracer reads)
 // ---------------------------------------------------------------------------
+struct Medium {                                                                   // material.rs:16-34
+    uint32_t medium_type;                                                         // MediumType, material.rs:8-13: RPT_MEDIUM_*
+    F density;
+    F3 color;
+    F anisotropy;
+    Medium() : medium_type(RPT_MEDIUM_NONE), density(0.0f), color(0.0f, 0.0f, 0.0f), anisotropy(0.0f) {}   // material.rs:25-32
+};
+
 struct Material {
     F3 rgb, emission;
     F anisotropic, metallic, roughness, subsurface, specular_tint, sheen, sheen_tint;
     F clearcoat, clearcoat_gloss, clearcoat_roughness, spec_trans, ior, ax, ay;
+    Medium medium;                                                                // material.rs:75,107; read only under RPT_SCENE_MEDIA
 
     Material()                                                                    // material.rs:82-114
         : rgb(1.5f, 1.5f, 1.5f), emission(0.0f, 0.0f, 0.0f), anisotropic(0.0f), metallic(0.0f),
@@ -208,6 +229,7 @@ struct Material {
     {
         roughness = f_max(roughness, 0.01f);
         clearcoat_roughness = mix_ptf(0.1f, 0.001f, clearcoat_gloss);
+        medium.anisotropy = f_clamp(medium.anisotropy, -0.9f, 0.9f);              // material.rs:126
         F aspect = f_sqrt(F(1.0f) - anisotropic * F(0.9f));
         ax = f_max(roughness / aspect, 0.001f);
         ay = f_max(roughness * aspect, 0.001f);
@@ -221,6 +243,7 @@ struct State {
     F3 fhp, normal, ffnormal;
     bool is_emitter;
     Material material;
+    Medium medium;                                                                // globals.rs:19,37; the medium the path is in (media, include/rpt.h)
 
     State() : depth(4), eta(0.0f), hit_dist(-1.0f), is_emitter(false) {}          // globals.rs:23-39
 
@@ -396,6 +419,12 @@ struct Scene {
         if (m.mask & RPT_MAT_CLEARCOAT_GLOSS) out.clearcoat_gloss = m.clearcoat_gloss;
         if (m.mask & RPT_MAT_SPEC_TRANS) out.spec_trans = m.spec_trans;
         if (m.mask & RPT_MAT_IOR) out.ior = m.ior;
+        if (m.mask & RPT_MAT_MEDIUM) {                                             // Material.medium as one more field (material.rs:75)
+            out.medium.medium_type = m.medium_type;
+            out.medium.density = m.medium_density;
+            out.medium.color = F3(m.medium_color[0], m.medium_color[1], m.medium_color[2]);
+            out.medium.anisotropy = m.medium_anisotropy;
+        }
         if (m.proc_kind == RPT_PROC_CHECKER_DIR) {                                 // analytical.rs:107-115
             F s(m.proc_params[0]), o(m.proc_params[1]);
             F x = ray.direction.x / ray.direction.y * s + o;
@@ -957,11 +986,45 @@ struct Tracer {
         light_sample.pdf = dist_sq / (F(light.area) * F(0.5f) * f_abs(dot(light_sample.normal, light_sample.direction)));
     }
 
-    // tracer.rs:126-170
-    F3 direct_light(const Ray& ray, const State& state, Rng& rng) const
+    // ---- participating media: PROJECT-DEFINED (include/rpt.h, "participating media"); no reference counterpart ----
+    static F phase_hg(F cos_theta, F g)                                            // Henyey-Greenstein, cos against the direction back along the ray
+    {
+        F denom = F(1.0f) + g * g + F(2.0f) * g * cos_theta;
+        return F(INV_4_PI_F) * (F(1.0f) - g * g) / (denom * f_sqrt(denom));
+    }
+    static F3 sample_hg(const F3& v, F g, F r1, F r2)
+    {
+        F cos_theta;
+        if (f_abs(g) < F(0.001f)) cos_theta = F(1.0f) - F(2.0f) * r2;
+        else {
+            F sqr_term = (F(1.0f) - g * g) / (F(1.0f) + g - F(2.0f) * g * r2);
+            cos_theta = -(F(1.0f) + g * g - sqr_term * sqr_term) / (F(2.0f) * g);
+        }
+        F phi = r1 * F(TWO_PI_F);
+        F sin_theta = f_clamp(f_sqrt(F(1.0f) - (cos_theta * cos_theta)), 0.0f, 1.0f);
+        F sin_phi = f_sin(phi);
+        F cos_phi = f_cos(phi);
+        F3 t, b;
+        onb(v, t, b);
+        return (sin_theta * cos_phi) * t + (sin_theta * sin_phi) * b + cos_theta * v;
+    }
+    // what is left of a light's radiance after `dist` inside the medium
+    static F3 medium_transmittance(const Medium& md, F dist)
+    {
+        if (md.medium_type == RPT_MEDIUM_ABSORB)
+            return F3(f_exp(-(((F(1.0f) - md.color.x) * dist) * md.density)), f_exp(-(((F(1.0f) - md.color.y) * dist) * md.density)),
+                      f_exp(-(((F(1.0f) - md.color.z) * dist) * md.density)));
+        if (md.medium_type == RPT_MEDIUM_SCATTER) return F3::new_x(f_exp(-(dist * md.density)));
+        return F3(1.0f, 1.0f, 1.0f);
+    }
+
+    // tracer.rs:126-170.  The two extra arguments are the media extension (both off = the reference): `phase` — the
+    // estimate is taken at a medium scatter point (state.fhp, no offset) with the phase function of that medium in place
+    // of the BSDF; `inside` — the medium the path is in, which attenuates the light on its way to the point.
+    F3 direct_light(const Ray& ray, const State& state, Rng& rng, const Medium* phase = nullptr, const Medium* inside = nullptr) const
     {
         F3 ld = F3::zeros();
-        F3 scatter_pos = state.fhp + eps * state.ffnormal;
+        F3 scatter_pos = phase ? state.fhp : state.fhp + eps * state.ffnormal;
         ScatterSampleRec scatter_sample;
         size_t number_lights = scene.number_of_lights();
         if (number_lights > 0) {
@@ -980,7 +1043,14 @@ struct Tracer {
                 bool in_shadow = scene.any_hit(shadow_ray, light_sample.dist - eps);
                 log_event(in_shadow ? 's' : 'v');
                 if (!in_shadow) {
-                    scatter_sample.f = disney_eval(state, -ray.direction, state.ffnormal, light_sample.direction, scatter_sample.pdf);
+                    if (inside && raw(light_sample.dist) <= 3.40282347e+38f) li = li * medium_transmittance(*inside, light_sample.dist);
+                    if (phase) {
+                        F p = phase_hg(dot(-ray.direction, light_sample.direction), phase->anisotropy);
+                        scatter_sample.f = F3::new_x(p);
+                        scatter_sample.pdf = p;
+                    } else {
+                        scatter_sample.f = disney_eval(state, -ray.direction, state.ffnormal, light_sample.direction, scatter_sample.pdf);
+                    }
                     F mis_weight(1.0f);
                     if (F(light.area) > F(0.0f)) mis_weight = power_heuristic(light_sample.pdf, scatter_sample.pdf);
                     if (scatter_sample.pdf > F(0.0f)) ld += mis_weight * li * (scatter_sample.f / F3::new_x(light_sample.pdf));
@@ -1018,13 +1088,57 @@ struct Tracer {
         ScatterSampleRec scatter_sample;
         state.depth = scene.recursion_depth();                                     // tracer.rs:57
 
+        // PROJECT-DEFINED, off by default (include/rpt.h, RPT_RENDER_RUSSIAN_ROULETTE): the reference's loop has no
+        // roulette (tracer.rs:61-103).  One more draw, after all other draws of the bounce.  True: the path ends.
+        auto roulette = [&](uint16_t bounce) {
+            if (russian_roulette && (uint32_t)bounce + 1u >= 2u && (uint32_t)bounce + 1u < (uint32_t)state.depth) {
+                F q = f_max(f_max(throughput.x, throughput.y), throughput.z);
+                q = f_clamp(q, 0.05f, 1.0f);
+                F r = rng.gen();
+                if (r >= q) { log_event('r'); return true; }
+                throughput = throughput / F3::new_x(q);
+            }
+            return false;
+        };
+        // PROJECT-DEFINED, off by default (include/rpt.h, RPT_SCENE_MEDIA): the reference never reads a Medium.
+        const bool media = (scene.d.flags & RPT_SCENE_MEDIA) != 0;
+        bool in_medium = false;
+
         for (uint16_t bounce = 0; bounce < state.depth; ++bounce) {                // tracer.rs:61
             state.material = Material();
+            if (media) state.is_emitter = false;                                   // (media: a path can go on after an emitter was seen)
             bool hit = scene.closest_hit(ray, state, light_sample);
             if (!hit) {
                 log_event('M');
                 radiance += scene.background(ray) * throughput;
                 break;
+            }
+            if (media && in_medium) {                                              // the medium acts on the segment [0, hit_dist] first
+                const Medium md = state.medium;
+                F seg = state.hit_dist;
+                if (md.medium_type == RPT_MEDIUM_ABSORB) {
+                    throughput = throughput * medium_transmittance(md, seg);
+                } else if (md.medium_type == RPT_MEDIUM_EMISSIVE) {
+                    radiance += md.color.mult_f(seg).mult_f(md.density) * throughput;
+                } else if (md.medium_type == RPT_MEDIUM_SCATTER) {
+                    F r = rng.gen();
+                    F d = f_min(-f_ln(r) / md.density, seg);
+                    if (d < seg) {                                                 // a scatter event before the segment's end
+                        log_event('V');
+                        throughput = throughput * md.color;
+                        ray.origin = ray.at(d);
+                        state.fhp = ray.origin;
+                        radiance += direct_light(ray, state, rng, &md, &md) * throughput;
+                        F r1 = rng.gen();
+                        F r2 = rng.gen();
+                        F3 dir = sample_hg(-ray.direction, md.anisotropy, r1, r2);
+                        scatter_sample.pdf = phase_hg(dot(-ray.direction, dir), md.anisotropy);
+                        scatter_sample.l = dir;
+                        ray.direction = dir;
+                        if (roulette(bounce)) break;
+                        continue;
+                    }
+                }
             }
             log_event(state.is_emitter ? 'E' : 'H');
             if (!state.is_emitter && raw(state.material.clearcoat) != 0.0f) log_event('k');   // surface with a clearcoat lobe
@@ -1036,21 +1150,17 @@ struct Tracer {
                 radiance += mis_weight * light_sample.emission * throughput;
                 break;
             }
-            radiance += direct_light(ray, state, rng) * throughput;
+            radiance += direct_light(ray, state, rng, nullptr, (media && in_medium) ? &state.medium : nullptr) * throughput;
             scatter_sample.f = disney_sample(state, -ray.direction, state.ffnormal, scatter_sample.l, scatter_sample.pdf, rng);
             if (scatter_sample.pdf > F(0.0f)) throughput = throughput * (scatter_sample.f / F3::new_x(scatter_sample.pdf));
             else { log_event('x'); break; }
             ray.direction = scatter_sample.l;
             ray.origin = state.fhp + eps * ray.direction;
-            // PROJECT-DEFINED, off by default (include/rpt.h, RPT_RENDER_RUSSIAN_ROULETTE): the reference's loop has no
-            // roulette (tracer.rs:61-103).  One more draw, after all other draws of the bounce.
-            if (russian_roulette && (uint32_t)bounce + 1u >= 2u && (uint32_t)bounce + 1u < (uint32_t)state.depth) {
-                F q = f_max(f_max(throughput.x, throughput.y), throughput.z);
-                q = f_clamp(q, 0.05f, 1.0f);
-                F r = rng.gen();
-                if (r >= q) { log_event('r'); break; }
-                throughput = throughput / F3::new_x(q);
+            if (media && state.material.medium.medium_type != RPT_MEDIUM_NONE) {   // crossing (or staying on one side of) a medium's boundary
+                in_medium = dot(ray.direction, state.normal) < F(0.0f);
+                if (in_medium) state.medium = state.material.medium;
             }
+            if (roulette(bounce)) break;
         }
         log_event('.');
         return radiance;

@@ -1,7 +1,7 @@
 """ctypes mirror of include/rpt.h (the C ABI).  Plain data only."""
 import ctypes as C
 
-RPT_ABI_VERSION = 2
+RPT_ABI_VERSION = 3
 
 RPT_OK = 0
 RPT_ERR_INVALID_ARG = -1
@@ -25,6 +25,9 @@ RPT_MAT_CLEARCOAT_GLOSS = 1 << 10
 RPT_MAT_SPEC_TRANS = 1 << 11
 RPT_MAT_IOR = 1 << 12
 RPT_MAT_ALL = (1 << 13) - 1
+RPT_MAT_MEDIUM = 1 << 13
+
+RPT_MEDIUM_NONE, RPT_MEDIUM_ABSORB, RPT_MEDIUM_SCATTER, RPT_MEDIUM_EMISSIVE = range(4)
 
 RPT_PROC_NONE = 0
 RPT_PROC_CHECKER_DIR = 1
@@ -38,6 +41,7 @@ RPT_BG_GRADIENT_Y = 1
 
 RPT_SCENE_ANYHIT_USES_MAX_DIST = 1 << 0
 RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES = 1 << 1
+RPT_SCENE_MEDIA = 1 << 2
 
 RPT_RENDER_DEFAULT = 0
 RPT_RENDER_NESTED_LOOPS = 1 << 0
@@ -51,7 +55,8 @@ RPT_RENDER_LARGE_MEGAKERNEL = 1 << 7
 RPT_RENDER_SMALL_COMPACT = 1 << 8
 RPT_RENDER_SDF_COMPACT = 1 << 9
 
-RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG = range(7)
+(RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG, RPT_PROBE_EXP,
+ RPT_PROBE_LOG) = range(9)
 (RPT_PROBE_FN_GEN_RAY, RPT_PROBE_FN_HIT_SPHERE, RPT_PROBE_FN_HIT_PLANE, RPT_PROBE_FN_SAMPLE_LIGHT, RPT_PROBE_FN_DISNEY_EVAL,
  RPT_PROBE_FN_DISNEY_SAMPLE, RPT_PROBE_FN_COUNT) = range(7)
 RPT_PROBE_IN_STRIDE = 32
@@ -71,6 +76,7 @@ class rpt_material(C.Structure):
         ("sheen_tint", C.c_float), ("clearcoat", C.c_float), ("clearcoat_gloss", C.c_float),
         ("spec_trans", C.c_float), ("ior", C.c_float),
         ("proc_params", F4),
+        ("medium_type", C.c_uint32), ("medium_density", C.c_float), ("medium_color", F3), ("medium_anisotropy", C.c_float),
     ]
 
 

@@ -81,12 +81,18 @@ class Material:
         "spec_trans": _abi.RPT_MAT_SPEC_TRANS, "ior": _abi.RPT_MAT_IOR,
     }
 
-    def __init__(self, checker_dir=None, **fields):
+    MEDIUM_TYPES = {"none": _abi.RPT_MEDIUM_NONE, "absorb": _abi.RPT_MEDIUM_ABSORB, "scatter": _abi.RPT_MEDIUM_SCATTER,
+                    "emissive": _abi.RPT_MEDIUM_EMISSIVE}
+
+    def __init__(self, checker_dir=None, medium=None, **fields):
         for k in fields:
             if k not in self._FIELDS:
                 raise TypeError("unknown material field %r" % k)
         self.fields = fields
         self.checker_dir = checker_dir       # (scale, offset, colour_a, colour_b) or None
+        # Material.medium (material.rs:16-21): dict(type="absorb"|"scatter"|"emissive"|"none", density, color, anisotropy);
+        # read only by scenes with `media = True` (project-defined, include/rpt.h)
+        self.medium = medium
 
     def to_c(self):
         m = _abi.rpt_material()
@@ -99,6 +105,13 @@ class Material:
         if self.checker_dir is not None:
             m.proc_kind = _abi.RPT_PROC_CHECKER_DIR
             m.proc_params = _abi.F4(*self.checker_dir)
+        if self.medium is not None:
+            m.mask |= _abi.RPT_MAT_MEDIUM
+            t = self.medium.get("type", "none")
+            m.medium_type = self.MEDIUM_TYPES[t] if isinstance(t, str) else int(t)
+            m.medium_density = float(self.medium.get("density", 0.0))
+            m.medium_color = _abi.F3(*self.medium.get("color", (0.0, 0.0, 0.0)))
+            m.medium_anisotropy = float(self.medium.get("anisotropy", 0.0))
         return m
 
 
@@ -117,6 +130,7 @@ class Scene:
         self.max_depth = 4       # scene.rs:28-30
         self.any_hit_uses_max_dist = False
         self.sample_all_light_types = False   # rectangular / distant lights do something (project-defined; off = the reference)
+        self.media = False       # Material.medium is read: participating media (project-defined, include/rpt.h; off = the reference)
         self.sdf = None          # dict(prims=[(kind, center, (p0, p1))], material, smooth_k, max_steps, hit_eps, max_t, normal_eps)
         self._keep = None
 
@@ -134,7 +148,8 @@ class Scene:
         d = _abi.rpt_scene_desc()
         d.abi_version = _abi.RPT_ABI_VERSION
         d.flags = (_abi.RPT_SCENE_ANYHIT_USES_MAX_DIST if self.any_hit_uses_max_dist else 0) | \
-                  (_abi.RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES if self.sample_all_light_types else 0)
+                  (_abi.RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES if self.sample_all_light_types else 0) | \
+                  (_abi.RPT_SCENE_MEDIA if self.media else 0)
         d.camera.origin = _abi.F3(*self.camera.origin)
         d.camera.center = _abi.F3(*self.camera.center)
         d.camera.fov_deg = self.camera.fov

@@ -52,6 +52,7 @@ struct rpt_ctx {
     uint32_t tile_rows = 2;
     bool has_scene = false;
     bool large = false;               // scene exceeds the kernarg tables: SceneLarge + device tables
+    bool media = false;               // RPT_SCENE_MEDIA and some material carries a medium: the media kernels (dev_media.h)
     SceneSmallSdf scene;              // camera part is filled per launch (depends on width/height); sdf.n_prims == 0: plain
     rpt_camera camera;
     // resident ColorBuffer (buffer.rs:6-14): pixels as per-rank tiles + frames
@@ -235,6 +236,8 @@ static DevMaterial dev_material(const rpt_material& a)
     m.specular_tint = a.specular_tint; m.sheen = a.sheen; m.sheen_tint = a.sheen_tint; m.clearcoat = a.clearcoat;
     m.clearcoat_gloss = a.clearcoat_gloss; m.spec_trans = a.spec_trans; m.ior = a.ior;
     for (int k = 0; k < 4; ++k) m.proc_params[k] = a.proc_params[k];
+    m.medium_type = a.medium_type; m.medium_density = a.medium_density; m.medium_anisotropy = a.medium_anisotropy;
+    for (int k = 0; k < 3; ++k) m.medium_color[k] = a.medium_color[k];
     return m;
 }
 static DevBackground dev_background(const rpt_background& b)
@@ -413,6 +416,10 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         return RPT_ERR_UNSUPPORTED;
     }
 #endif
+    if (ctx->media && (flags & (RPT_RENDER_FAST_MATH | RPT_RENDER_SDF_POOL_MARCH | RPT_RENDER_SDF_COMPACT))) {
+        set_err(ctx, "render: scenes with participating media (RPT_SCENE_MEDIA) have no relaxed-arithmetic or A/B kernel form");
+        return RPT_ERR_UNSUPPORTED;
+    }
     const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
     // wavefront form of large scenes with a grid (max_depth == 0 has no bounce loop: the megakernel's prologue does that)
     if ((flags & RPT_RENDER_LARGE_WAVEFRONT) && (flags & RPT_RENDER_LARGE_MEGAKERNEL)) {
@@ -463,9 +470,9 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
         if (wavefront && (flags & RPT_RENDER_FAST_MATH)) RPT_HIP_CHECK(ctx, rptlaunch_fast::render_wavefront(scl, rp, wb, stream));
-        else if (wavefront) RPT_HIP_CHECK(ctx, rptlaunch::render_wavefront(scl, rp, wb, stream));
+        else if (wavefront) RPT_HIP_CHECK(ctx, rptlaunch::render_wavefront(scl, rp, wb, stream, ctx->media));
         else if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
-        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
+        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev, ctx->media));
         done += chunk;
     }
     return RPT_OK;
@@ -708,6 +715,21 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         if (s->planes[i].material >= s->n_materials) { set_err(ctx, "rpt_upload_scene: plane %u material out of range", i); return RPT_ERR_INVALID_ARG; }
     for (uint32_t i = 0; i < s->n_lights; ++i)
         if (s->lights[i].type > RPT_LIGHT_DISTANT) { set_err(ctx, "rpt_upload_scene: light %u has an unknown type", i); return RPT_ERR_INVALID_ARG; }
+    // participating media (include/rpt.h): used only under RPT_SCENE_MEDIA, and then only when some material carries one
+    bool media = false;
+    if (s->flags & RPT_SCENE_MEDIA) {
+        for (uint32_t i = 0; i < s->n_materials; ++i) {
+            const rpt_material& m = s->materials[i];
+            if (!(m.mask & RPT_MAT_MEDIUM)) continue;
+            if (m.medium_type > RPT_MEDIUM_EMISSIVE) { set_err(ctx, "rpt_upload_scene: material %u has an unknown medium type", i); return RPT_ERR_INVALID_ARG; }
+            if (!(m.medium_density >= 0.0f) || !std::isfinite(m.medium_density)) {
+                set_err(ctx, "rpt_upload_scene: material %u: the medium's density must be finite and >= 0", i);
+                return RPT_ERR_INVALID_ARG;
+            }
+            media = media || m.medium_type != RPT_MEDIUM_NONE;
+        }
+        if (media && s->n_materials > kMaxMediaMaterials) { set_err(ctx, "rpt_upload_scene: scenes with media can have at most %u materials", kMaxMediaMaterials); return RPT_ERR_UNSUPPORTED; }
+    }
 
     if (s->sdf.n_prims) {
         if (s->sdf.n_prims > (uint32_t)kMaxSdfPrims || !s->sdf.prims || s->sdf.material >= s->n_materials || !(s->sdf.smooth_k > 0.0f)) {
@@ -723,6 +745,12 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         // Layered patches need a bit per primitive; large scenes must use full sphere materials.
         for (uint32_t i = 0; i < s->n_spheres; ++i) {
             const rpt_material& m = s->materials[s->spheres[i].material];
+            if (media && !(m.mask & RPT_MAT_MEDIUM)) {
+                // (with patches a nearer sphere WITHOUT a medium would inherit the medium of a farther one accepted before it)
+                set_err(ctx, "rpt_upload_scene: in a large scene with media every sphere material must set RPT_MAT_MEDIUM "
+                             "(medium_type RPT_MEDIUM_NONE for none); sphere %u does not", i);
+                return RPT_ERR_UNSUPPORTED;
+            }
             if ((m.mask & RPT_MAT_ALL) != RPT_MAT_ALL || m.proc_kind != RPT_PROC_NONE) {
                 set_err(ctx, "rpt_upload_scene: scenes beyond %d spheres / %d lights / %d materials need full sphere materials "
                              "(mask == RPT_MAT_ALL, no procedural part); sphere %u does not", kMaxSpheres, kMaxLights, kMaxMaterials, i);
@@ -782,6 +810,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         }
         ctx->camera = s->camera;
         ctx->large = true;
+        ctx->media = media;
         ctx->has_scene = true;
         return RPT_OK;
     }
@@ -818,6 +847,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
     }
     ctx->camera = s->camera;
     ctx->large = false;
+    ctx->media = media;
     ctx->has_scene = true;
     return RPT_OK;
 }
@@ -1228,7 +1258,7 @@ int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint6
 int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b_dev, float* out_dev, uint64_t n, void* stream)
 {
     if (!ctx) { set_err(nullptr, "rpt_probe_math: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
-    if (!a_dev || !b_dev || !out_dev || fn > RPT_PROBE_RNG) { set_err(ctx, "rpt_probe_math: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    if (!a_dev || !b_dev || !out_dev || fn > RPT_PROBE_LOG) { set_err(ctx, "rpt_probe_math: invalid argument"); return RPT_ERR_INVALID_ARG; }
     if (n == 0) return RPT_OK;
     RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, rptlaunch::probe_math(fn, a_dev, b_dev, out_dev, n, (hipStream_t)stream));

@@ -3,6 +3,7 @@
 #pragma once
 
 #include "dev_bsdf.h"
+#include "dev_media.h"
 #include "dev_scene.h"
 
 namespace rptdev {
@@ -394,6 +395,45 @@ RPT_DEV v3 hit_normal(const SceneSmallSdf& sc, const RayD& ray, float dist, cons
 RPT_DEV void hit_material(const SceneSmall& sc, const RayD& ray, const GeomHit& g, Mat& mat) { material_small<false>(sc, nullptr, ray, g.code, mat); }
 RPT_DEV void hit_material(const SceneSmallSdf& sc, const RayD& ray, const GeomHit& g, Mat& mat) { material_small<true>(sc, &sc.sdf, ray, g.code, mat); }
 
+// Media (dev_media.h): which material's Medium the layered material of a hit carries — the last accepted primitive whose
+// patch writes the medium (RPT_MAT_MEDIUM), kNoMediumIdx when none does (Material::new()'s Medium is MediumType::None).
+template <bool SDF>
+RPT_DEV uint32_t medium_index_small(const SceneSmall& sc, const DevSdf* sdf, uint32_t accepted)
+{
+    uint32_t idx = kNoMediumIdx;
+    for (uint32_t i = 0; i < sc.n_spheres; ++i) {
+        const uint32_t mi = sc.spheres[i].material;
+        if (sc.materials[mi].mask & RPT_MAT_MEDIUM) idx = ((accepted >> i) & 1u) ? mi : idx;
+    }
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        const uint32_t mi = sc.planes[k].material;
+        if (sc.materials[mi].mask & RPT_MAT_MEDIUM) idx = ((accepted >> (kMaxSpheres + k)) & 1u) ? mi : idx;
+    }
+    if (SDF) {
+        const uint32_t mi = sdf->material;
+        if (sc.materials[mi].mask & RPT_MAT_MEDIUM) idx = ((accepted >> (kMaxSpheres + kMaxPlanes)) & 1u) ? mi : idx;
+    }
+    return idx;
+}
+RPT_DEV uint32_t hit_medium_index(const SceneSmall& sc, const GeomHit& g) { return medium_index_small<false>(sc, nullptr, g.code); }
+RPT_DEV uint32_t hit_medium_index(const SceneSmallSdf& sc, const GeomHit& g) { return medium_index_small<true>(sc, &sc.sdf, g.code); }
+
+// The Medium of material `index` (a per-lane index: a select chain over the wave-uniform table), finalized.
+RPT_DEV DevMedium medium_at(const SceneSmall& sc, uint32_t index)
+{
+    uint32_t type = RPT_MEDIUM_NONE;
+    float density = 0.0f, cx = 0.0f, cy = 0.0f, cz = 0.0f, aniso = 0.0f;
+    for (uint32_t i = 0; i < sc.n_materials; ++i) {
+        const DevMaterial& m = sc.materials[i];
+        const bool pick = (index == i);
+        type = pick ? m.medium_type : type;
+        density = pick ? m.medium_density : density;
+        cx = pick ? m.medium_color[0] : cx; cy = pick ? m.medium_color[1] : cy; cz = pick ? m.medium_color[2] : cz;
+        aniso = pick ? m.medium_anisotropy : aniso;
+    }
+    return DevMedium{type, density, mk3(cx, cy, cz), clampf(aniso, -0.9f, 0.9f)};             // material.rs:126
+}
+
 // AnalyticalScene::any_hit (analytical.rs:130-145); it ignores max_dist unless the
 // scene opts in.
 RPT_DEV bool any_hit_analytic(const SceneSmall& sc, const RayD& ray, float max_dist)
@@ -533,16 +573,21 @@ RPT_DEV DevLight light_at(const SceneSmall& sc, uint32_t index)
 
 // How the integrator asks the scene its two questions.  The default asks directly; the resumable-march
 // kernel substitutes a query that carries the outcome of a march it ran as a separate scheduling state.
+// `any` may also leave the question open (`pending`: the wavefront form walks the shadow ray in another kernel and is
+// handed what the radiance gains if the answer turns out to be "free", through park()); the direct forms never do.
 struct DirectQuery {
-    template <class S> RPT_DEV bool any(const S& sc, const RayD& ray, float max_dist) const { return any_hit(sc, ray, max_dist); }
+    template <class S> RPT_DEV bool any(const S& sc, const RayD& ray, float max_dist, v3, bool& pending) const { pending = false; return any_hit(sc, ray, max_dist); }
     template <class S> RPT_DEV bool geom(const S& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) const { return closest_geom(sc, ray, ps, g, e); }
+    RPT_DEV void park(v3) const {}
 };
 
 // Head of direct_light (tracer.rs:130-145): pick a light, sample it.  Returns the facing test of tracer.rs:147.
-template <class S>
+// OFFSET false: the estimate is taken at a point inside a medium (media, dev_media.h): scatter_pos is `fhp` itself.
+template <bool OFFSET = true, class S>
 RPT_DEV bool nee_sample(const S& sc, v3 fhp, v3 ffnormal, Rng& rng, v3& scatter_pos, float& light_area, LightSample& ls)
 {
-    scatter_pos = fhp + sc.eps * ffnormal;
+    if (OFFSET) scatter_pos = fhp + sc.eps * ffnormal;
+    else scatter_pos = fhp;
     float random = rng.gen();
     random = random * sc.n_lights_f;
     uint32_t index = (uint32_t)random;                              // `as usize`
@@ -561,27 +606,29 @@ RPT_DEV bool nee_sample(const S& sc, v3 fhp, v3 ffnormal, Rng& rng, v3& scatter_
 // shadow query out of the shading block's register peak; measured: no spills left in a 4-wave large-scene kernel, but 1.2 %
 // slower on BASELINE configs[1], so the reference's order is kept.)
 struct NeeQuery {
-    bool lit;                  // a light was sampled, it faces the point, and the shadow ray is free
+    bool lit;                  // a light was sampled, it faces the point, and the shadow ray is free (or its answer is pending)
+    bool pending;              // the shadow query was left open (DirectQuery)
     float light_area;
     LightSample ls;
 };
 
-template <class S, class Q>
-RPT_DEV NeeQuery nee_query(const S& sc, const Q& q, v3 fhp, v3 ffnormal, Rng& rng)
+template <bool OFFSET = true, class S, class Q>
+RPT_DEV NeeQuery nee_query(const S& sc, const Q& q, v3 fhp, v3 ffnormal, Rng& rng, v3 throughput)
 {
     NeeQuery n;
     n.lit = false;
+    n.pending = false;
     n.light_area = 0.0f;
     n.ls.normal = mk3(0.0f, 0.0f, 0.0f); n.ls.emission = mk3(0.0f, 0.0f, 0.0f); n.ls.direction = mk3(0.0f, 0.0f, 0.0f);
     n.ls.dist = 0.0f; n.ls.pdf = 0.0f;
     if (sc.n_lights == 0) return n;
     v3 scatter_pos;
     bool facing;
-    { RPT_PROF(PB_NEE_SAMPLE); facing = nee_sample(sc, fhp, ffnormal, rng, scatter_pos, n.light_area, n.ls); }
+    { RPT_PROF(PB_NEE_SAMPLE); facing = nee_sample<OFFSET>(sc, fhp, ffnormal, rng, scatter_pos, n.light_area, n.ls); }
     if (facing) {
         RayD shadow{scatter_pos, n.ls.direction};
         bool in_shadow;
-        { RPT_PROF(PB_ANYHIT); in_shadow = q.any(sc, shadow, n.ls.dist - sc.eps); }
+        { RPT_PROF(PB_ANYHIT); in_shadow = q.any(sc, shadow, n.ls.dist - sc.eps, throughput, n.pending); }
         n.lit = !in_shadow;
     }
     return n;
@@ -631,6 +678,7 @@ struct PathRegs {
     uint32_t bounce;           // ScatterSampleRec.l needs no register: it is zeros before the first
                                // bounce and equals ray.d afterwards (tracer.rs:100)
     Rng rng;
+    uint32_t medium;           // media kernels only (dev_media.h): 0, or 1 + the material whose Medium the path is in [| kMediumScatterNow]
 };
 
 // tracer.rs:44-57.  HASHED: `pixel` is already pcg_hash(pixel index) (the state-machine kernels keep that in LDS: left to
@@ -648,6 +696,7 @@ RPT_DEV void path_begin(const S& sc, PathRegs& p, float px, float py, uint32_t f
     p.ps.hit_dist = -1.0f;
     p.ps.scatter_pdf = 0.0f;
     p.bounce = 0;
+    p.medium = 0u;
 }
 
 // One iteration of the loop at tracer.rs:61-103 in two halves, split where the work stops being needed by every ray:
@@ -657,8 +706,10 @@ RPT_DEV void path_begin(const S& sc, PathRegs& p, float px, float py, uint32_t f
 // material writes and finalize cost about as much as the three sphere tests; in TRACE they ran for the 62 % of its
 // lanes that hit a surface (42 % of the wave), in SHADE they run with the shading block's 84 %.  Per lane the
 // operations and their order are unchanged, so images stay bit-identical.
+// 0: the ray left the scene (the background is still to be added), 1: it ended on an emitter (radiance updated), 2: the bounce
+// goes on in SHADE — a surface was hit, or (media kernels) the path scatters inside the medium it is in.
 template <class S, class Q>
-RPT_DEV bool path_trace_geom(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
+RPT_DEV uint32_t path_trace_geom_split(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
 {
     EmitterHit e;
     e.is_emitter = false;
@@ -666,10 +717,27 @@ RPT_DEV bool path_trace_geom(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
     e.light_emission = mk3(0.0f, 0.0f, 0.0f);
     bool hit;
     { RPT_PROF(PB_CLOSEST); hit = q.geom(sc, p.ray, p.ps, g, e); }
-    if (!hit) {
-        RPT_PROF(PB_BACKGROUND);
-        p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
-        return false;
+    if (!hit) return 0u;
+    if constexpr (S::kMedia) {
+        // the medium acts on the segment [0, hit_dist] before what lies at its end is looked at (include/rpt.h, media, step 2)
+        if (p.medium != 0u) {
+            const DevMedium md = medium_at(sc, p.medium - 1u);
+            const float seg = p.ps.hit_dist;
+            if (md.type == RPT_MEDIUM_ABSORB) {
+                p.throughput = p.throughput * medium_transmittance(md, seg);
+            } else if (md.type == RPT_MEDIUM_EMISSIVE) {
+                p.radiance = p.radiance + scale3(scale3(md.color, seg), md.density) * p.throughput;
+            } else if (md.type == RPT_MEDIUM_SCATTER) {
+                const float r = p.rng.gen();
+                const float d = rmin(-rpt_logf(r) / md.density, seg);
+                if (d < seg) {                                      // a scatter event before the segment's end: SHADE does the rest
+                    p.throughput = p.throughput * md.color;
+                    p.ray.o = p.ray.o + d * p.ray.d;
+                    p.medium |= kMediumScatterNow;
+                    return 2u;
+                }
+            }
+        }
     }
     if (e.is_emitter) {
         RPT_PROF(PB_FINALIZE);
@@ -677,9 +745,71 @@ RPT_DEV bool path_trace_geom(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
         // state.depth > 0 always holds (tracer.rs:57,80): the MIS weight is always applied
         float mis_weight = power_heuristic(p.ps.scatter_pdf, e.light_pdf);
         p.radiance = p.radiance + (mis_weight * e.light_emission) * p.throughput;
-        return false;
+        return 1u;
     }
-    return true;
+    return 2u;
+}
+
+template <class S, class Q>
+RPT_DEV bool path_trace_geom(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
+{
+    const uint32_t what = path_trace_geom_split(sc, q, p, g);
+    if (what == 0u) {
+        RPT_PROF(PB_BACKGROUND);
+        p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
+    }
+    return what == 2u;
+}
+
+// What every bounce ends with once the next ray is set: the depth test of tracer.rs:61 and the project's Russian roulette
+// (include/rpt.h RPT_RENDER_RUSSIAN_ROULETTE).  True: the path is over.
+template <class S>
+RPT_DEV bool path_next_bounce(const S& sc, PathRegs& p)
+{
+    p.bounce += 1;
+    if (p.bounce >= sc.max_depth) return true;
+    if ((sc.flags & kSceneFlagRussianRoulette) && p.bounce >= 2u) {
+        const v3 thr = p.throughput;
+        float q = rmax(rmax(thr.x, thr.y), thr.z);
+        q = clampf(q, 0.05f, 1.0f);
+        const float r = p.rng.gen();
+        if (r >= q) return true;
+        p.throughput = divs3(thr, q);
+    }
+    return false;
+}
+
+// Media kernels: the bounce is a scatter event inside the medium (p.ray.o is the scatter point — `cold` when the caller
+// lent p.ray.o to a shadow march): next-event estimation with the phase function, then a Henyey-Greenstein direction.
+template <class S, class Q>
+RPT_DEV bool path_shade_medium(const S& sc, const Q& q, PathRegs& p, const volatile float4* cold)
+{
+    p.medium &= ~kMediumScatterNow;
+    const DevMedium md = medium_at(sc, p.medium - 1u);
+    const v3 fhp = cold ? mk3(cold->x, cold->y, cold->z) : p.ray.o;
+    const v3 wo = -p.ray.d;
+    {
+        NeeQuery nq = nee_query<false>(sc, q, fhp, mk3(0.0f, 0.0f, 0.0f), p.rng, p.throughput);
+        v3 ld = mk3(0.0f, 0.0f, 0.0f);
+        if (nq.lit) {
+            v3 li = nq.ls.emission;
+            if (nq.ls.dist <= 3.40282347e+38f) li = li * medium_transmittance(md, nq.ls.dist);
+            const float ph = phase_hg(dot3(wo, nq.ls.direction), md.anisotropy);
+            float mis_weight = 1.0f;
+            if (nq.light_area > 0.0f) mis_weight = power_heuristic(nq.ls.pdf, ph);
+            if (ph > 0.0f) ld = ld + (mis_weight * li) * divs3(mk3(ph, ph, ph), nq.ls.pdf);
+        }
+        const v3 gain = ld * p.throughput;
+        if (nq.pending) q.park(gain);
+        else p.radiance = p.radiance + gain;
+    }
+    const float r1 = p.rng.gen();
+    const float r2 = p.rng.gen();
+    const v3 dir = sample_hg(wo, md.anisotropy, r1, r2);
+    p.ps.scatter_pdf = phase_hg(dot3(wo, dir), md.anisotropy);
+    p.ray.o = fhp;
+    p.ray.d = dir;
+    return path_next_bounce(sc, p);
 }
 
 // Returns true when the path is over (pdf <= 0 or depth exhausted).
@@ -689,6 +819,9 @@ RPT_DEV bool path_trace_geom(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
 template <class S, class Q>
 RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit& g, const v3* n_pre = nullptr, const volatile float4* cold = nullptr)
 {
+    if constexpr (S::kMedia) {
+        if (p.medium & kMediumScatterNow) return path_shade_medium(sc, q, p, cold);
+    }
     const v3 normal = n_pre ? *n_pre : hit_normal(sc, p.ray, p.ps.hit_dist, g);
     const float ndd = dot3(normal, p.ray.d);
     const bool front = (ndd <= 0.0f);
@@ -706,8 +839,15 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
     ShadeFrame fr;
     { RPT_PROF(PB_FRAME); fr = make_frame(mat, eta, -p.ray.d, ffnormal); }
     {
-        const NeeQuery nq = nee_query(sc, q, fhp, ffnormal, p.rng);
-        p.radiance = p.radiance + nee_eval(nq, mat, eta, fr, ffnormal) * p.throughput;
+        NeeQuery nq = nee_query(sc, q, fhp, ffnormal, p.rng, p.throughput);
+        if constexpr (S::kMedia) {
+            // inside a medium the light arrives attenuated (include/rpt.h, media, step 3)
+            if (p.medium != 0u && nq.lit && nq.ls.dist <= 3.40282347e+38f)
+                nq.ls.emission = nq.ls.emission * medium_transmittance(medium_at(sc, p.medium - 1u), nq.ls.dist);
+        }
+        const v3 gain = nee_eval(nq, mat, eta, fr, ffnormal) * p.throughput;
+        if (nq.pending) q.park(gain);
+        else p.radiance = p.radiance + gain;
     }
     float pdf;
     v3 scatter_l = (p.bounce > 0) ? p.ray.d : mk3(0.0f, 0.0f, 0.0f);   // the stale `l` of tracer.rs:531
@@ -721,17 +861,14 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
     const v3 fhp2 = cold ? mk3(cold->x, cold->y, cold->z) : (p.ray.o + p.ps.hit_dist * p.ray.d);
     p.ray.o = fhp2 + sc.eps * scatter_l;
     p.ray.d = scatter_l;
-    p.bounce += 1;
-    if (p.bounce >= sc.max_depth) return true;
-    if ((sc.flags & kSceneFlagRussianRoulette) && p.bounce >= 2u) {   // project extension, include/rpt.h RPT_RENDER_RUSSIAN_ROULETTE
-        const v3 thr = p.throughput;
-        float q = rmax(rmax(thr.x, thr.y), thr.z);
-        q = clampf(q, 0.05f, 1.0f);
-        const float r = p.rng.gen();
-        if (r >= q) return true;
-        p.throughput = divs3(thr, q);
+    if constexpr (S::kMedia) {
+        // crossing, or staying on one side of, the boundary of a medium (include/rpt.h, media, step 4)
+        const uint32_t mi = hit_medium_index(sc, g);
+        if (mi != kNoMediumIdx) {
+            if (medium_at(sc, mi).type != RPT_MEDIUM_NONE) p.medium = (dot3(scatter_l, normal) < 0.0f) ? (mi + 1u) : 0u;
+        }
     }
-    return false;
+    return path_next_bounce(sc, p);
 }
 
 

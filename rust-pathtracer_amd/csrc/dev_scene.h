@@ -48,6 +48,10 @@ struct DevMaterial {
     float anisotropic, metallic, roughness, subsurface, specular_tint, sheen, sheen_tint;
     float clearcoat, clearcoat_gloss, spec_trans, ior;
     float proc_params[4];
+    uint32_t medium_type;      // Material.medium (material.rs:16-21); read only by the media kernels (WithMedia, below)
+    float medium_density;
+    float medium_color[3];
+    float medium_anisotropy;
 };
 
 // Pinhole::gen_ray (camera/pinhole.rs:38-60) split at its frame-invariant part:
@@ -87,6 +91,7 @@ struct DevSdf {
 constexpr uint32_t kSceneFlagRussianRoulette = 1u << 31;       // RPT_RENDER_RUSSIAN_ROULETTE
 
 struct SceneSmall {
+    static constexpr bool kMedia = false;                          // see WithMedia
     uint32_t n_spheres, n_planes, n_lights, n_materials;
     uint32_t flags, max_depth;
     float eps;
@@ -103,6 +108,16 @@ struct SceneSmall {
 // analytical scenes (the benchmark path) contains no sphere-marching code.
 struct SceneSmallSdf : SceneSmall {
     DevSdf sdf;
+};
+
+// Participating media (include/rpt.h, RPT_SCENE_MEDIA; project-defined) are a COMPILE-TIME property of the scene type: the
+// same tables, but the path functions (dev_integrator.h) carry the medium a path is in and act on it.  Scenes without media
+// — the reference's, every benchmark scene — run kernels that contain none of that code.
+template <class Base>
+struct WithMedia : Base {
+    static constexpr bool kMedia = true;
+    WithMedia() = default;
+    explicit WithMedia(const Base& b) : Base(b) {}
 };
 
 // One launch's worth of render parameters.

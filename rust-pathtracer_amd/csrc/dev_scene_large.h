@@ -23,6 +23,7 @@ namespace rptdev {
 #define RPT_CONST_AS __attribute__((address_space(4)))
 
 struct SceneLarge {
+    static constexpr bool kMedia = false;                          // dev_scene.h, WithMedia
     uint32_t n_spheres, n_planes, n_lights, n_materials;
     uint32_t flags, max_depth;
     float eps;
@@ -76,14 +77,17 @@ RPT_DEV DevLight light_uniform(const SceneLarge& sc, uint32_t i)
 
 RPT_DEV DevMaterial material_uniform(const SceneLarge& sc, uint32_t i)
 {
-    static_assert(sizeof(DevMaterial) == 23 * 4, "DevMaterial is 23 dwords");
-    cfloat_p p = (cfloat_p)sc.materials + 23u * i;
+    static_assert(sizeof(DevMaterial) == 29 * 4, "DevMaterial is 29 dwords");
+    cfloat_p p = (cfloat_p)sc.materials + 29u * i;
     DevMaterial m;
     m.mask = ((cuint_p)p)[0]; m.proc_kind = ((cuint_p)p)[1];
     for (int c = 0; c < 3; ++c) { m.rgb[c] = p[2 + c]; m.emission[c] = p[5 + c]; }
     m.anisotropic = p[8]; m.metallic = p[9]; m.roughness = p[10]; m.subsurface = p[11]; m.specular_tint = p[12];
     m.sheen = p[13]; m.sheen_tint = p[14]; m.clearcoat = p[15]; m.clearcoat_gloss = p[16]; m.spec_trans = p[17]; m.ior = p[18];
     for (int c = 0; c < 4; ++c) m.proc_params[c] = p[19 + c];
+    m.medium_type = ((cuint_p)p)[23]; m.medium_density = p[24];
+    for (int c = 0; c < 3; ++c) m.medium_color[c] = p[25 + c];
+    m.medium_anisotropy = p[28];
     return m;
 }
 
@@ -472,6 +476,25 @@ RPT_DEV v3 normal_large(const SceneLarge& sc, const RayD& ray, float dist, const
     v3 sn = norm3(hp - c);
     return mk3(win_plane ? pn.x : sn.x, win_plane ? pn.y : sn.y, win_plane ? pn.z : sn.z);
 }
+
+// Media (dev_media.h): the material whose Medium the layered material of the hit carries — the nearest sphere's when it
+// writes one, then the accepted planes' patches in order.
+RPT_DEV uint32_t hit_medium_index(const SceneLarge& sc, const GeomHit& g)
+{
+    const uint32_t best = g.code & kNoSphere;
+    const uint32_t accepted_planes = g.code >> 28;
+    uint32_t idx = kNoMediumIdx;
+    if (best != kNoSphere) {
+        const uint32_t mi = sc.sphere_material[best];
+        if (sc.materials[mi].mask & RPT_MAT_MEDIUM) idx = mi;
+    }
+    for (uint32_t k = 0; k < sc.n_planes; ++k) {
+        const uint32_t mi = sc.planes[k].material;
+        if (((cuint_p)sc.materials)[29u * mi] & RPT_MAT_MEDIUM) idx = ((accepted_planes >> k) & 1u) ? mi : idx;
+    }
+    return idx;
+}
+RPT_DEV DevMedium medium_at(const SceneLarge& sc, uint32_t index) { return medium_of(sc.materials[index]); }   // per-lane gather
 
 RPT_DEV v3 hit_normal(const SceneLarge& sc, const RayD& ray, float dist, const GeomHit& g) { return normal_large(sc, ray, dist, g); }
 RPT_DEV void hit_material(const SceneLarge& sc, const RayD& ray, const GeomHit& g, Mat& mat) { material_large(sc, ray, g.code, mat); }

@@ -53,10 +53,12 @@ struct SdfInjectedQuery {
     {
         return closest_geom_small<true>(sc, &sc.sdf, ray, ps, g, e, &r, &a);
     }
-    RPT_DEV bool any(const SceneSmallSdf& sc, const RayD& ray, float max_dist) const
+    RPT_DEV bool any(const SceneSmallSdf& sc, const RayD& ray, float max_dist, v3, bool& pending) const
     {
+        pending = false;
         return any_hit_small<true>(sc, &sc.sdf, ray, max_dist, &r);
     }
+    RPT_DEV void park(v3) const {}
 };
 
 // Start the closest_hit march of the path's current ray.
@@ -76,6 +78,8 @@ RPT_DEV AnalyticPre march_analytic(const MarchRegs& m) { return AnalyticPre{m.t_
 // consuming the path's random numbers (SHADE replays the same draws from p.rng).  Returns true when a
 // march was started (origin in p.ray.o); false when any_hit's answer does not depend on the SDF object,
 // in which case m.hit is set to what the march would be allowed to report (nothing).
+// OFFSET false (media kernels): `fhp` is a scatter point inside a medium, the shadow ray starts exactly there.
+template <bool OFFSET = true>
 RPT_DEV bool march_begin_shadow(const SceneSmallSdf& sc, PathRegs& p, v3 fhp, v3 ffnormal, MarchRegs& m)
 {
     m.hit = false;
@@ -85,7 +89,7 @@ RPT_DEV bool march_begin_shadow(const SceneSmallSdf& sc, PathRegs& p, v3 fhp, v3
     v3 scatter_pos;
     float light_area;
     LightSample ls;
-    if (!nee_sample(sc, fhp, ffnormal, rng, scatter_pos, light_area, ls)) return false;
+    if (!nee_sample<OFFSET>(sc, fhp, ffnormal, rng, scatter_pos, light_area, ls)) return false;
     const float max_dist = ls.dist - sc.eps;
     const RayD shadow{scatter_pos, ls.direction};
     if (any_hit_analytic(sc, shadow, max_dist)) return false;      // occluded whatever the march says

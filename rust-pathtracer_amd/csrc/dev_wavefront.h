@@ -82,25 +82,6 @@ RPT_DEV bool closest_before_walk(const SceneLarge& sc, const RayD& ray, float& d
     return true;
 }
 
-// path_trace_geom (dev_integrator.h) with the miss left to the caller: 0 the ray left the scene (the background is still to
-// be added), 1 it ended on an emitter (radiance updated), 2 a surface was hit.
-template <class S, class Q>
-RPT_DEV uint32_t path_trace_geom_split(const S& sc, const Q& q, PathRegs& p, GeomHit& g)
-{
-    EmitterHit e;
-    e.is_emitter = false;
-    e.light_pdf = 0.0f;
-    e.light_emission = mk3(0.0f, 0.0f, 0.0f);
-    if (!q.geom(sc, p.ray, p.ps, g, e)) return 0u;
-    if (e.is_emitter) {
-        p.radiance = p.radiance + hit_emission(sc, g) * p.throughput;                      // tracer.rs:74
-        const float mis_weight = power_heuristic(p.ps.scatter_pdf, e.light_pdf);
-        p.radiance = p.radiance + (mis_weight * e.light_emission) * p.throughput;
-        return 1u;
-    }
-    return 2u;
-}
-
 struct ShadowReq {
     bool pending;              // the shadow ray still needs its grid walk
     RayD ray;
@@ -108,79 +89,42 @@ struct ShadowReq {
     v3 c_lit;                  // what the radiance gains if the walk finds nothing
 };
 
-// path_shade_full (dev_integrator.h) with the shadow ray's grid walk left to the walk kernel.
-RPT_DEV bool path_shade_deferred(const SceneLarge& sc, PathRegs& p, const GeomHit& g, ShadowReq& sr)
-{
-    sr.pending = false;
-    const v3 normal = hit_normal(sc, p.ray, p.ps.hit_dist, g);
-    const float ndd = dot3(normal, p.ray.d);
-    const bool front = (ndd <= 0.0f);
-    const v3 ffnormal = mk3(front ? normal.x : -normal.x, front ? normal.y : -normal.y, front ? normal.z : -normal.z);
-    Mat mat;
-    float eta;
-    hit_material(sc, p.ray, g, mat);
-    mat_finalize(mat);
-    eta = (ndd < 0.0f) ? (1.0f / mat.ior) : mat.ior;
-    p.radiance = p.radiance + mat.emission * p.throughput;
-    const v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
-    const ShadeFrame fr = make_frame(mat, eta, -p.ray.d, ffnormal);
+// The shadow query of path_shade_full (dev_integrator.h) with the grid walk left to the walk kernel: any_hit taken apart —
+// planes, reach test and oversize spheres here; when those leave the question open the ray is handed to the caller (`sr`) and
+// SHADE goes on as if the light were visible; what that adds to the radiance is parked (c_lit) until the walk has answered.
+// A lane whose throughput is not finite resolves its shadow ray on the spot: there "add nothing" and "add 0 x throughput" differ.
+struct DeferredQuery {
+    ShadowReq* sr;
+    RPT_DEV bool any(const SceneLarge& sc, const RayD& shadow, float max_dist, v3 th, bool& pending) const
     {
-        // nee_query (dev_integrator.h) with any_hit taken apart: planes, reach test, oversize spheres here; the grid walk later
-        NeeQuery n;
-        n.lit = false;
-        n.light_area = 0.0f;
-        n.ls.normal = mk3(0.0f, 0.0f, 0.0f); n.ls.emission = mk3(0.0f, 0.0f, 0.0f); n.ls.direction = mk3(0.0f, 0.0f, 0.0f);
-        n.ls.dist = 0.0f; n.ls.pdf = 0.0f;
-        if (sc.n_lights != 0) {
-            v3 scatter_pos;
-            const bool facing = nee_sample(sc, fhp, ffnormal, p.rng, scatter_pos, n.light_area, n.ls);
-            if (facing) {
-                const RayD shadow{scatter_pos, n.ls.direction};
-                const float max_dist = n.ls.dist - sc.eps;
-                const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
-                bool occluded = any_hit_finish(sc, shadow, max_dist, false);                  // the planes
-                if (!occluded) {
-                    const v3 th = p.throughput;
-                    const bool finite = (__builtin_fabsf(th.x) < __builtin_inff()) && (__builtin_fabsf(th.y) < __builtin_inff()) &&
-                                        (__builtin_fabsf(th.z) < __builtin_inff());
-                    if (!grid_usable(sc, shadow) || !finite) {
-                        occluded = grid_any_sphere(sc, shadow, use_max, max_dist);
-                    } else {
-                        for (uint32_t j = 0; j < sc.n_oversize; ++j) {
-                            const float4 s = sphere_uniform(sc, ((cuint_p)sc.oversize)[j]);
-                            float t;
-                            if (hit_sphere(shadow, mk3(s.x, s.y, s.z), s.w, t) && (!use_max || t < max_dist)) occluded = true;
-                        }
-                        if (!occluded) { sr.pending = true; sr.ray = shadow; sr.max_dist = max_dist; }
-                    }
+        pending = false;
+        const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
+        bool occluded = any_hit_finish(sc, shadow, max_dist, false);                          // the planes
+        if (!occluded) {
+            const bool finite = (__builtin_fabsf(th.x) < __builtin_inff()) && (__builtin_fabsf(th.y) < __builtin_inff()) &&
+                                (__builtin_fabsf(th.z) < __builtin_inff());
+            if (!grid_usable(sc, shadow) || !finite) {
+                occluded = grid_any_sphere(sc, shadow, use_max, max_dist);
+            } else {
+                for (uint32_t j = 0; j < sc.n_oversize; ++j) {
+                    const float4 s = sphere_uniform(sc, ((cuint_p)sc.oversize)[j]);
+                    float t;
+                    if (hit_sphere(shadow, mk3(s.x, s.y, s.z), s.w, t) && (!use_max || t < max_dist)) occluded = true;
                 }
-                n.lit = !occluded;
+                if (!occluded) { pending = true; sr->pending = true; sr->ray = shadow; sr->max_dist = max_dist; }
             }
         }
-        const v3 ld = nee_eval(n, mat, eta, fr, ffnormal);
-        if (sr.pending) sr.c_lit = ld * p.throughput;
-        else p.radiance = p.radiance + ld * p.throughput;
+        return occluded;
     }
-    float pdf;
-    v3 scatter_l = (p.bounce > 0) ? p.ray.d : mk3(0.0f, 0.0f, 0.0f);
-    const v3 f = disney_sample(mat, eta, fr, ffnormal, scatter_l, pdf, p.rng);
-    p.ps.scatter_pdf = pdf;
-    if (!(pdf > 0.0f)) return true;
-    p.throughput = p.throughput * divs3(f, pdf);
-    const v3 fhp2 = p.ray.o + p.ps.hit_dist * p.ray.d;
-    p.ray.o = fhp2 + sc.eps * scatter_l;
-    p.ray.d = scatter_l;
-    p.bounce += 1;
-    if (p.bounce >= sc.max_depth) return true;
-    if ((sc.flags & kSceneFlagRussianRoulette) && p.bounce >= 2u) {
-        const v3 thr = p.throughput;
-        float q = rmax(rmax(thr.x, thr.y), thr.z);
-        q = clampf(q, 0.05f, 1.0f);
-        const float r = p.rng.gen();
-        if (r >= q) return true;
-        p.throughput = divs3(thr, q);
-    }
-    return false;
+    RPT_DEV void park(v3 gain) const { sr->c_lit = gain; }
+};
+
+// path_shade_full with the shadow ray's grid walk left to the walk kernel.
+template <class S>
+RPT_DEV bool path_shade_deferred(const S& sc, PathRegs& p, const GeomHit& g, ShadowReq& sr)
+{
+    sr.pending = false;
+    return path_shade_full(sc, DeferredQuery{&sr}, p, g);
 }
 
 // ---------------------------------------------------------------------------

@@ -120,6 +120,12 @@ RPT_DEV void render_nested_body(const S& sc, const RenderParams& rp)
 __global__ __launch_bounds__(256) void RPT_K(render_small_nested_kernel)(const SceneSmall sc, const RenderParams rp) { render_nested_body(sc, rp); }
 __global__ __launch_bounds__(256) void RPT_K(render_large_nested_kernel)(const SceneLarge sc, const RenderParams rp) { render_nested_body(sc, rp); }
 __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(sc, rp); }
+#ifndef RPT_NO_MEDIA_KERNELS
+// The same kernels for scenes with participating media (dev_scene.h WithMedia, dev_media.h): every form below has one.
+__global__ __launch_bounds__(256) void RPT_K(render_small_nested_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void RPT_K(render_large_nested_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_nested_body(sc, rp); }
+#endif
 
 // The production megakernel.  Same arithmetic per sample, different schedule:
 //  * each lane runs its pixel's whole sample loop as a state machine (dev_integrator.h,
@@ -268,6 +274,11 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
+#ifndef RPT_NO_MEDIA_KERNELS
+__global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_regen_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_regen_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_regen_body(sc, rp); }
+#endif
 
 // Large scenes as a wavefront (dev_wavefront.h): WALK(k) walks the rays SHADE(k-1) listed, SHADE(k) does the rest of the bounce
 // for every slot that still has work and lists the next rays.
@@ -307,6 +318,18 @@ struct WfRecords {
     uint32_t u[5][256];        // rng key, counter; bounce; GeomHit; sample << 8 | flags | status
 };
 
+// PathRegs.bounce and .medium share a dword wherever a path is stored (bounce <= 4096, medium < 2^16); kernels without media
+// never look at the upper half.
+template <bool MEDIA>
+RPT_DEV uint32_t pack_bounce(const PathRegs& p) { return MEDIA ? (p.bounce | (p.medium << 16)) : p.bounce; }
+template <bool MEDIA>
+RPT_DEV void unpack_bounce(uint32_t v, PathRegs& p)
+{
+    p.bounce = MEDIA ? (v & 0xFFFFu) : v;
+    p.medium = MEDIA ? (v >> 16) : 0u;
+}
+
+template <bool MEDIA = false>
 RPT_DEV void wf_rec_put(WfRecords& r, uint32_t i, const PathRegs& p, uint32_t gcode, uint32_t ctl)
 {
     r.f[0][i] = p.ray.o.x; r.f[1][i] = p.ray.o.y; r.f[2][i] = p.ray.o.z;
@@ -314,9 +337,10 @@ RPT_DEV void wf_rec_put(WfRecords& r, uint32_t i, const PathRegs& p, uint32_t gc
     r.f[6][i] = p.throughput.x; r.f[7][i] = p.throughput.y; r.f[8][i] = p.throughput.z;
     r.f[9][i] = p.radiance.x; r.f[10][i] = p.radiance.y; r.f[11][i] = p.radiance.z;
     r.f[12][i] = p.ps.hit_dist; r.f[13][i] = p.ps.scatter_pdf;
-    r.u[0][i] = p.rng.key; r.u[1][i] = p.rng.counter; r.u[2][i] = p.bounce; r.u[3][i] = gcode; r.u[4][i] = ctl;
+    r.u[0][i] = p.rng.key; r.u[1][i] = p.rng.counter; r.u[2][i] = pack_bounce<MEDIA>(p); r.u[3][i] = gcode; r.u[4][i] = ctl;
 }
 
+template <bool MEDIA = false>
 RPT_DEV void wf_rec_get(const WfRecords& r, uint32_t i, PathRegs& p, uint32_t& gcode, uint32_t& ctl)
 {
     p.ray.o = mk3(r.f[0][i], r.f[1][i], r.f[2][i]);
@@ -324,7 +348,7 @@ RPT_DEV void wf_rec_get(const WfRecords& r, uint32_t i, PathRegs& p, uint32_t& g
     p.throughput = mk3(r.f[6][i], r.f[7][i], r.f[8][i]);
     p.radiance = mk3(r.f[9][i], r.f[10][i], r.f[11][i]);
     p.ps.hit_dist = r.f[12][i]; p.ps.scatter_pdf = r.f[13][i];
-    p.rng.key = r.u[0][i]; p.rng.counter = r.u[1][i]; p.bounce = r.u[2][i]; gcode = r.u[3][i]; ctl = r.u[4][i];
+    p.rng.key = r.u[0][i]; p.rng.counter = r.u[1][i]; unpack_bounce<MEDIA>(r.u[2][i], p); gcode = r.u[3][i]; ctl = r.u[4][i];
 }
 
 // append `value` to a workgroup list in LDS for the lanes that `want` (one LDS atomic per wave)
@@ -341,8 +365,10 @@ RPT_DEV void wf_list_add(T* list, uint32_t* count, bool want, uint32_t value)
     if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (T)value;
 }
 
-__global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_shade_kernel)(const SceneLarge sc, const RenderParams rp, const WfBuffers wb, uint32_t parity, uint32_t first)
+template <class S>
+RPT_DEV void wf_shade_body(const S& sc, const RenderParams& rp, const WfBuffers& wb, uint32_t parity, uint32_t first)
 {
+    constexpr bool M = S::kMedia;
     __shared__ WfRecords rec;
     __shared__ uint32_t l_shade[256], l_fin[256];
     __shared__ uint32_t n_lists[2];
@@ -370,7 +396,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
             if (first) {
                 p.ray.o = p.ray.d = p.throughput = p.radiance = mk3(0.0f, 0.0f, 0.0f);
                 p.ps.hit_dist = 0.0f; p.ps.scatter_pdf = 0.0f;
-                p.rng.key = 0u; p.rng.counter = 0u; p.bounce = 0u;
+                p.rng.key = 0u; p.rng.counter = 0u; p.bounce = 0u; p.medium = 0u;
                 ctl = WF_WALKING;                                   // sample 0, nothing to blend: F starts its camera path
                 to_fin = true;
             } else {
@@ -378,7 +404,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
                 p.ray.o = mk3(a.x, a.y, a.z); p.ray.d = mk3(b.x, b.y, b.z);
                 p.throughput = mk3(t.x, t.y, t.z); p.ps.hit_dist = t.w;
                 p.radiance = mk3(r.x, r.y, r.z); p.ps.scatter_pdf = r.w;
-                p.rng.key = c.x; p.rng.counter = c.y; p.bounce = c.z;
+                p.rng.key = c.x; p.rng.counter = c.y; unpack_bounce<M>(c.z, p);
                 const uint32_t s = c.w >> 8;
                 const uint32_t status = c.w & 3u;
                 // last bounce's light sample: visible unless its walk found an occluder
@@ -410,7 +436,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
                     else { to_fin = true; ctl |= WFF_BLEND | (what == 0u ? WFF_MISS : 0u); }
                 }
             }
-            wf_rec_put(rec, tid, p, g.code, ctl);
+            wf_rec_put<M>(rec, tid, p, g.code, ctl);
         }
         wf_list_add(l_shade, &n_lists[0], to_shade, tid);
         wf_list_add(l_fin, &n_lists[1], to_fin, tid);
@@ -426,7 +452,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
             i = l_shade[tid];
             PathRegs p;
             uint32_t gcode, ctl;
-            wf_rec_get(rec, i, p, gcode, ctl);
+            wf_rec_get<M>(rec, i, p, gcode, ctl);
             GeomHit g;
             g.code = gcode;
             ShadowReq sr;
@@ -450,7 +476,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
             } else {
                 ctl = (ctl & ~3u) | WF_ENDING;                      // the launch's last sample waits for the answer
             }
-            wf_rec_put(rec, i, p, gcode, ctl);
+            wf_rec_put<M>(rec, i, p, gcode, ctl);
         }
         wf_list_add(l_fin, &n_lists[1], to_fin, i);
     }
@@ -461,7 +487,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
         const uint32_t i = l_fin[tid];
         PathRegs p;
         uint32_t gcode, ctl;
-        wf_rec_get(rec, i, p, gcode, ctl);
+        wf_rec_get<M>(rec, i, p, gcode, ctl);
         uint32_t s = ctl >> 8;
         bool begin = true;
         if (ctl & WFF_MISS) p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
@@ -485,7 +511,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
         } else {
             ctl |= WF_DONE;
         }
-        wf_rec_put(rec, i, p, gcode, ctl);
+        wf_rec_put<M>(rec, i, p, gcode, ctl);
     }
     __syncthreads();
 
@@ -494,13 +520,13 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
     if (live) {
         PathRegs p;
         uint32_t gcode, ctl;
-        wf_rec_get(rec, tid, p, gcode, ctl);
+        wf_rec_get<M>(rec, tid, p, gcode, ctl);
         float dist = 0.0f;
         uint32_t best = 0xFFFFFFFFu;
         bool walk_closest = false;
         if (ctl & WFF_NEWRAY) walk_closest = closest_before_walk(sc, p.ray, dist, best);
         keep = (ctl & 3u) != WF_DONE;
-        wb.ctl[slot] = make_uint4(p.rng.key, p.rng.counter, p.bounce, ctl & ~(WFF_NEWRAY | WFF_MISS | WFF_BLEND));
+        wb.ctl[slot] = make_uint4(p.rng.key, p.rng.counter, pack_bounce<M>(p), ctl & ~(WFF_NEWRAY | WFF_MISS | WFF_BLEND));
         if (keep) {
             wb.ray_o[slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, dist);
             wb.ray_d[slot] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, rpt_u2f(best));
@@ -524,6 +550,17 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
         if (mk != 0ull) wb.any_active[parity] = 1u;
     }
 }
+
+__global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_shade_kernel)(const SceneLarge sc, const RenderParams rp, const WfBuffers wb, uint32_t parity, uint32_t first)
+{
+    wf_shade_body(sc, rp, wb, parity, first);
+}
+#ifndef RPT_NO_MEDIA_KERNELS
+__global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_shade_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp, const WfBuffers wb, uint32_t parity, uint32_t first)
+{
+    wf_shade_body(sc, rp, wb, parity, first);
+}
+#endif
 
 // Small scenes, FEW samples per launch (the reference's own usage: one render() per redraw).  With nothing to regenerate a
 // wave of the megakernel drains: its lanes end one by one and the wave runs on for its longest path.  Here the workgroup's 256
@@ -557,8 +594,10 @@ RPT_DEV bool compact_finish(const S& sc, const RenderParams& rp, uint32_t i, Pat
 // Per pass two barriers:  TRACE for the trace list (closest_hit only: surface -> S, miss / emitter -> F)  |  SHADE for the
 // entries of S from thread 0 up and, at the same time, FINISH (background for a miss, blend, the pixel's next camera path)
 // for the entries of F from thread 255 down — |S| + |F| <= 256, so at most one wave has both kinds.
-RPT_DEV void render_compact_body(const SceneSmall& sc, const RenderParams& rp)
+template <class S>
+RPT_DEV void render_compact_body(const S& sc, const RenderParams& rp)
 {
+    constexpr bool M = S::kMedia;
     __shared__ WfRecords rec;                                       // u[4] = sample index << 1 | "the ray left the scene"
     __shared__ uint8_t l_trace[2][256], l_shade[256], l_fin[256];   // path = pixel of the tile = thread that started it
     __shared__ uint32_t n_trace[2], n_shade[2], n_fin[2];
@@ -578,7 +617,7 @@ RPT_DEV void render_compact_body(const SceneSmall& sc, const RenderParams& rp)
     if (ps.valid) {
         PathRegs p;
         path_begin(sc, p, ps.px, ps.py, frame_key_hd(rp.seed, rp.frames_done), ps.pixel_index);
-        wf_rec_put(rec, tid, p, 0u, 0u);
+        wf_rec_put<M>(rec, tid, p, 0u, 0u);
     }
     wf_list_add(l_trace[0], &n_trace[0], ps.valid, tid);
     __syncthreads();
@@ -593,13 +632,13 @@ RPT_DEV void render_compact_body(const SceneSmall& sc, const RenderParams& rp)
                 i = l_trace[cur][tid];
                 PathRegs p;
                 uint32_t gcode, ctl;
-                wf_rec_get(rec, i, p, gcode, ctl);
+                wf_rec_get<M>(rec, i, p, gcode, ctl);
                 GeomHit g;
                 g.code = 0u;
                 const uint32_t what = path_trace_geom_split(sc, DirectQuery{}, p, g);
                 to_shade = what == 2u;
                 to_fin = !to_shade;
-                wf_rec_put(rec, i, p, g.code, (ctl & ~1u) | (what == 0u ? 1u : 0u));
+                wf_rec_put<M>(rec, i, p, g.code, (ctl & ~1u) | (what == 0u ? 1u : 0u));
             }
             wf_list_add(l_shade, &n_shade[cur], to_shade, i);
             wf_list_add(l_fin, &n_fin[cur], to_fin, i);
@@ -614,22 +653,22 @@ RPT_DEV void render_compact_body(const SceneSmall& sc, const RenderParams& rp)
                 i = l_shade[tid];
                 PathRegs p;
                 uint32_t gcode, ctl;
-                wf_rec_get(rec, i, p, gcode, ctl);
+                wf_rec_get<M>(rec, i, p, gcode, ctl);
                 GeomHit g;
                 g.code = gcode;
                 uint32_t s = ctl >> 1;
                 if (path_shade_full(sc, DirectQuery{}, p, g)) to_trace = compact_finish(sc, rp, i, p, s);
                 else to_trace = true;
-                if (to_trace) wf_rec_put(rec, i, p, 0u, s << 1);
+                if (to_trace) wf_rec_put<M>(rec, i, p, 0u, s << 1);
             } else if (255u - tid < n_f) {
                 i = l_fin[255u - tid];
                 PathRegs p;
                 uint32_t gcode, ctl;
-                wf_rec_get(rec, i, p, gcode, ctl);
+                wf_rec_get<M>(rec, i, p, gcode, ctl);
                 uint32_t s = ctl >> 1;
                 if (ctl & 1u) p.radiance = p.radiance + background(sc, p.ray) * p.throughput;     // tracer.rs:64-68
                 to_trace = compact_finish(sc, rp, i, p, s);
-                if (to_trace) wf_rec_put(rec, i, p, 0u, s << 1);
+                if (to_trace) wf_rec_put<M>(rec, i, p, 0u, s << 1);
             }
             wf_list_add(l_trace[cur ^ 1u], &n_trace[cur ^ 1u], to_trace, i);
         }
@@ -642,6 +681,9 @@ __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_
 // chip needs: six resident per CU (80 VGPRs, 112 B of scratch) make that 1.2 instead of 1.5 rounds, 0.096 instead of 0.101 ms;
 // from 1080p up the five-per-CU build is 1 % faster.
 __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(sc, rp); }
+#ifndef RPT_NO_MEDIA_KERNELS
+__global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_compact_body(sc, rp); }
+#endif
 
 #ifdef RPT_AB_KERNELS
 #include "ab/kernel_sdf_compact.h"
@@ -659,7 +701,8 @@ __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_kerne
 // 24 lanes wait, as in the regeneration kernel, is slower than bounce-granular: three rooms dilute 64 lanes.)
 enum : uint32_t { SM_MARCH_P = 0u, SM_MARCH_S = 1u, SM_RESOLVE = 2u, SM_SHADE = 3u, SM_DONE = 4u, SM_FINISH = 5u };
 
-RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& rp)
+template <class S>
+RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& rp)
 {
     RPT_PROF_INIT();
     __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
@@ -733,12 +776,21 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
                 RPT_PROF(PB_TRACE);
                 const SdfInjectedQuery q{{m.hit, m.t}, march_analytic(m)};
                 if (path_trace_geom(sc, q, p, g)) {
-                    normal = hit_normal(sc, p.ray, p.ps.hit_dist, g);
-                    const bool front = (dot3(normal, p.ray.d) <= 0.0f);             // State::finalize, globals.rs:53-57
-                    const v3 ffnormal = mk3(front ? normal.x : -normal.x, front ? normal.y : -normal.y, front ? normal.z : -normal.z);
-                    const v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
-                    s_hit[tid] = make_float4(fhp.x, fhp.y, fhp.z, 0.0f);
-                    state = march_begin_shadow(sc, p, fhp, ffnormal, m) ? SM_MARCH_S : SM_SHADE;
+                    bool scatters = false;
+                    if constexpr (S::kMedia) scatters = (p.medium & kMediumScatterNow) != 0u;
+                    if (scatters) {
+                        // a scatter event inside a medium: p.ray.o is the scatter point, where the shadow ray starts
+                        const v3 fhp = p.ray.o;
+                        s_hit[tid] = make_float4(fhp.x, fhp.y, fhp.z, 0.0f);
+                        state = march_begin_shadow<false>(sc, p, fhp, mk3(0.0f, 0.0f, 0.0f), m) ? SM_MARCH_S : SM_SHADE;
+                    } else {
+                        normal = hit_normal(sc, p.ray, p.ps.hit_dist, g);
+                        const bool front = (dot3(normal, p.ray.d) <= 0.0f);         // State::finalize, globals.rs:53-57
+                        const v3 ffnormal = mk3(front ? normal.x : -normal.x, front ? normal.y : -normal.y, front ? normal.z : -normal.z);
+                        const v3 fhp = p.ray.o + p.ps.hit_dist * p.ray.d;
+                        s_hit[tid] = make_float4(fhp.x, fhp.y, fhp.z, 0.0f);
+                        state = march_begin_shadow(sc, p, fhp, ffnormal, m) ? SM_MARCH_S : SM_SHADE;
+                    }
                 } else {
                     state = SM_FINISH;
                 }
@@ -750,6 +802,9 @@ RPT_DEV void render_sdf_march_body(const SceneSmallSdf& sc, const RenderParams& 
 }
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
+#ifndef RPT_NO_MEDIA_KERNELS
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
+#endif
 
 #ifdef RPT_AB_KERNELS
 // SDF scenes, workgroup-wide march pool (dev_sdf_pool.h): the lane states are those of the march kernel above, but a
@@ -960,6 +1015,8 @@ __global__ __launch_bounds__(256) void RPT_K(probe_math_kernel)(uint32_t fn, con
     case RPT_PROBE_POW: r = rpt_powf(a[i], b[i]); break;
     case RPT_PROBE_DIV: r = a[i] / b[i]; break;
     case RPT_PROBE_SQRT: r = __builtin_sqrtf(a[i]); break;
+    case RPT_PROBE_EXP: r = rpt_expf(a[i]); break;
+    case RPT_PROBE_LOG: r = rpt_logf(a[i]); break;
     case RPT_PROBE_RNG: {                                            // a = seed bits, b = frame bits, i = pixel; first draw
         Rng rng;
         rng.init(frame_key_hd((uint64_t)rpt_f2u(a[i]), (uint64_t)rpt_f2u(b[i])), (uint32_t)i);
@@ -1096,12 +1153,31 @@ namespace RPT_LAUNCH_NS {
 uint32_t max_spp_per_launch() { return kMaxSppPerLaunch; }
 
 hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, bool nested, const RenderParams& rp, uint32_t nblocks, hipStream_t st,
-                  const SceneSmallSdf* scs_dev)
+                  const SceneSmallSdf* scs_dev, bool media)
 {
     const bool has_sdf = !large && scs.sdf.n_prims > 0;
     const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
     const dim3 tiles(nblocks), wg(256);
     (void)hipGetLastError();                                         // the thread's sticky error may be somebody else's (a host process's own HIP calls)
+    if (media) {
+#ifndef RPT_NO_MEDIA_KERNELS
+        // scenes with participating media: the same forms, instantiated for WithMedia<Scene> (the A/B kernels have none)
+        const WithMedia<SceneSmall> msc(sc);
+        const WithMedia<SceneSmallSdf> mscs(scs);
+        const WithMedia<SceneLarge> mscl(scl);
+        if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_media_kernel), tiles, wg, 0, st, mscl, rp);
+        else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_media_kernel), tiles, wg, 0, st, mscl, rp);
+        else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_media_kernel), tiles, wg, 0, st, mscs, rp);
+        else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_media_kernel), tiles, wg, 0, st, mscs, rp);
+        else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_media_kernel), tiles, wg, 0, st, mscs, rp);
+        else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_media_kernel), tiles, wg, 0, st, msc, rp);
+        else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_media_kernel), tiles, wg, 0, st, msc, rp);
+        else hipLaunchKernelGGL(RPT_K(render_small_regen_media_kernel), tiles, wg, 0, st, msc, rp);
+        return hipGetLastError();
+#else
+        return hipErrorNotSupported;
+#endif
+    }
     if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), tiles, wg, 0, st, scl, rp);
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), tiles, wg, 0, st, scl, rp);
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), tiles, wg, 0, st, scs, rp);
@@ -1125,13 +1201,23 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     return hipGetLastError();
 }
 
-hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, hipStream_t st)
+hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, hipStream_t st, bool media)
 {
     static const uint32_t refill_at = getenv("RPT_WF_REFILL_AT") ? ((uint32_t)atoi(getenv("RPT_WF_REFILL_AT")) & 63u) : 40u;
     static const uint32_t blocks_per_group = getenv("RPT_WF_BLOCKS_PER_GROUP") ? (uint32_t)atoi(getenv("RPT_WF_BLOCKS_PER_GROUP")) : 6u;
     (void)hipGetLastError();
     const dim3 wg(256), all((wb.n_seg * 64u + 255u) / 256u), walkers(kWalkGroups * (blocks_per_group ? blocks_per_group : 1u));
-    hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, 0u, 1u);
+#ifndef RPT_NO_MEDIA_KERNELS
+    const WithMedia<SceneLarge> msc(sc);
+    const auto shade = [&](uint32_t parity, uint32_t first) {
+        if (media) hipLaunchKernelGGL(RPT_K(wf_shade_media_kernel), all, wg, 0, st, msc, rp, wb, parity, first);
+        else hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, parity, first);
+    };
+#else
+    if (media) return hipErrorNotSupported;
+    const auto shade = [&](uint32_t parity, uint32_t first) { hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, parity, first); };
+#endif
+    shade(0u, 1u);
     // a sample takes at most max_depth walks of its path ray; its last shadow ray is walked beside the next sample's first
     // ray, except the launch's last sample's.  Launches after the last useful iteration return at once (any_active), and
     // the host enqueues at most 256 iterations without looking: after every 256th it waits for the stream and reads the
@@ -1142,7 +1228,7 @@ hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const 
     for (uint64_t k = 1; k <= bound; ++k) {
         const uint32_t parity = (uint32_t)(k & 1u);
         hipLaunchKernelGGL(RPT_K(wf_walk_kernel), walkers, wg, 0, st, sc, wb, parity, refill_at);
-        hipLaunchKernelGGL(RPT_K(wf_shade_kernel), all, wg, 0, st, sc, rp, wb, parity, 0u);
+        shade(parity, 0u);
         if ((k & 255u) == 0u && k < bound) {
             hipError_t e = hipMemcpyAsync(&host_active, &wb.any_active[parity], sizeof(uint32_t), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);

@@ -6,6 +6,7 @@
 // and is never what bench.py measures.
 // Only the render kernels are built here: untile, the u8 conversions and the test probes have no relaxed form.
 #define RPT_RENDER_KERNELS_ONLY
+#define RPT_NO_MEDIA_KERNELS          // scenes with participating media have no relaxed form (RPT_ERR_UNSUPPORTED)
 #define RPT_K(name) name##_fast
 #define RPT_LAUNCH_NS rptlaunch_fast
 #include "kernels.hip"

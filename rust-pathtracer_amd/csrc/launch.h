@@ -39,13 +39,16 @@ uint32_t max_spp_per_launch();      // samples one launch of the regenerating ke
 // One launch of the megakernel on `nblocks` 16x16 tiles: picks the instantiation (small / SDF / large,
 // regenerating or nested) from the scene.  `small_scene_dev`: the same small scene in device memory (only the compacting SDF
 // kernel, rp.sdf_resumable_march == 3, reads it; without it that mode falls back to the march kernel).
+// `media`: the scene has participating media — the same forms instantiated for WithMedia<Scene> (dev_scene.h).
 hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr);
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr,
+                  bool media = false);
 // Large scenes with a grid, wavefront form (dev_wavefront.h): `spp` samples of every pixel of the tile; the buffers hold
 // rp.rows_local * rp.width slots.  Needs at most 1 + 2 * (spp * max_depth + 1) launches; launches after the last useful
 // iteration return at once, and the host never has more than 256 iterations enqueued without having looked at the device's
 // "anything left?" flag (it waits for the stream there: a bound of up to 256 iterations is enqueued blind).
-hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st);
+hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st,
+                            bool media = false);
 hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
                   uint32_t rows_padded, hipStream_t st);
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st);
@@ -59,7 +62,9 @@ hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t*
 
 // the relaxed-arithmetic build of the same kernels (kernels_fast.hip)
 namespace rptlaunch_fast {
-hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st);
+hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st,
+                            bool media = false);
 hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr);
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr,
+                  bool media = false);
 }  // namespace rptlaunch_fast

@@ -10,11 +10,12 @@ _DEFAULTS = dict(rgb=(1.5, 1.5, 1.5), emission=(0.0, 0.0, 0.0), anisotropic=0.0,
                  spec_trans=0.0, ior=1.45)                      # Material::new, material.rs:82-114
 
 
-def full_material(**fields):
-    """A patch that sets every field (mask == RPT_MAT_ALL): what large scenes require for spheres."""
+def full_material(medium=None, **fields):
+    """A patch that sets every field (mask == RPT_MAT_ALL): what large scenes require for spheres.  `medium`: also the
+    Medium (large scenes with media need it on every sphere material; dict(type="none") for none)."""
     d = dict(_DEFAULTS)
     d.update(fields)
-    return Material(**d)
+    return Material(medium=medium, **d)
 
 
 def pcg_hash(v):
@@ -33,7 +34,27 @@ class _U:
         return lo + (hi - lo) * u
 
 
-def random_spheres_scene(n_spheres=10000, n_lights=16, seed=0x5EED0005, n_palette=64):
+def media_scene():
+    """Participating media (project-defined, include/rpt.h) in the reference's scene: the left sphere becomes a glass ball
+    full of forward-scattering fog, the right one a ball of absorbing amber, a third small one glows (an emissive medium), and
+    a small light sits inside the fog (visible from inside it: any_hit honours max_dist)."""
+    from .api import AnalyticalScene
+    s = AnalyticalScene()
+    s.media = True
+    s.any_hit_uses_max_dist = True
+    s.max_depth = 12
+    s.materials[0] = Material(rgb=(1.0, 1.0, 1.0), roughness=0.05, spec_trans=1.0, ior=1.2,
+                              medium=dict(type="scatter", density=1.6, color=(0.95, 0.9, 0.8), anisotropy=0.6))
+    s.materials[1] = Material(rgb=(1.0, 0.9, 0.7), roughness=0.1, spec_trans=1.0, ior=1.33,
+                              medium=dict(type="absorb", density=1.2, color=(0.9, 0.55, 0.1)))
+    s.materials.append(Material(rgb=(1.0, 1.0, 1.0), roughness=0.02, spec_trans=1.0, ior=1.05,
+                                medium=dict(type="emissive", density=0.8, color=(0.2, 0.6, 1.0), anisotropy=2.0)))
+    s.spheres.append(((0.0, -0.6, 1.2), 0.4, 3))
+    s.lights.append(AnalyticalLight.spherical((-1.1, 0.0, 0.0), 0.12, (12.0, 12.0, 12.0)))
+    return s
+
+
+def random_spheres_scene(n_spheres=10000, n_lights=16, seed=0x5EED0005, n_palette=64, media=False):
     """spheres uniform in [-60,60]x[0,12]x[-120,0], radii U[0.3,1.2], a
     palette of full materials (rgb U[.05,1]^3, roughness U[.02,1], metallic 1 with p=.3, clearcoat 1
     with p=.2), a checker plane y=-1, spherical lights (r=1, emission 5) on a grid at y=15."""
@@ -42,13 +63,22 @@ def random_spheres_scene(n_spheres=10000, n_lights=16, seed=0x5EED0005, n_palett
     s.camera = Pinhole((0.0, 6.0, 14.0), (0.0, 2.0, -40.0), 70.0)
     s.background = dict(kind=_abi.RPT_BG_GRADIENT_Y, colour_a=(1.0, 1.0, 1.0), colour_b=(0.5, 0.7, 1.0), gamma=2.2, scale=0.5)
     s.any_hit_uses_max_dist = True
+    s.media = media
     s.materials = []
     for _ in range(n_palette):
         rgb = (u(0.05, 1.0), u(0.05, 1.0), u(0.05, 1.0))
         rough = u(0.02, 1.0)
         metallic = 1.0 if u() < 0.3 else 0.0
         coat = 1.0 if u() < 0.2 else 0.0
-        s.materials.append(full_material(rgb=rgb, roughness=rough, metallic=metallic, clearcoat=coat, clearcoat_gloss=coat))
+        medium = None
+        if media:                                     # a third of the palette: glass full of fog / coloured absorber / glow
+            kind = (len(s.materials) % 6)
+            medium = (dict(type="scatter", density=0.9, color=rgb, anisotropy=0.5), dict(type="absorb", density=1.5, color=rgb),
+                      dict(type="emissive", density=0.3, color=rgb), dict(type="none"), dict(type="none"), dict(type="none"))[kind]
+            if kind < 3:
+                s.materials.append(full_material(medium=medium, rgb=(1.0, 1.0, 1.0), roughness=0.05, spec_trans=1.0, ior=1.3))
+                continue
+        s.materials.append(full_material(medium=medium, rgb=rgb, roughness=rough, metallic=metallic, clearcoat=coat, clearcoat_gloss=coat))
     s.materials.append(Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1)))     # the reference's floor
     floor = len(s.materials) - 1
     s.spheres = []

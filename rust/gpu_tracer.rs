@@ -17,6 +17,8 @@ pub struct RptMaterial {
     pub anisotropic: f32, pub metallic: f32, pub roughness: f32, pub subsurface: f32, pub specular_tint: f32,
     pub sheen: f32, pub sheen_tint: f32, pub clearcoat: f32, pub clearcoat_gloss: f32, pub spec_trans: f32, pub ior: f32,
     pub proc_params: [f32; 4],
+    /// `Material.medium` (material.rs:16-21, 75): read only by scenes with `RPT_SCENE_MEDIA` (project-defined, include/rpt.h).
+    pub medium_type: u32, pub medium_density: f32, pub medium_color: [f32; 3], pub medium_anisotropy: f32,
 }
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptSphere { pub center: [f32; 3], pub radius: f32, pub material: u32 }
 #[repr(C)] #[derive(Clone, Copy, Default)] pub struct RptPlane { pub normal: [f32; 3], pub point: [f32; 3], pub min_denom: f32, pub material: u32, pub max_t: f32 }
@@ -44,7 +46,7 @@ pub struct RptSceneDesc {
 }
 #[repr(C)] #[derive(Clone, Copy)] pub struct RptUniqueId { pub bytes: [c_char; 128] }
 
-pub const RPT_ABI_VERSION: u32 = 2;
+pub const RPT_ABI_VERSION: u32 = 3;
 // Constants of include/rpt.h (tests/test_rust_binding.py compares every one of them with the header).
 pub const RPT_OK: i32 = 0;
 pub const RPT_ERR_INVALID_ARG: i32 = -1;
@@ -54,6 +56,11 @@ pub const RPT_ERR_NO_SCENE: i32 = -4;
 pub const RPT_ERR_UNSUPPORTED: i32 = -5;
 pub const RPT_ERR_RCCL: i32 = -6;
 pub const RPT_MAT_ALL: u32 = 0x1FFF;
+pub const RPT_MAT_MEDIUM: u32 = 0x2000;
+pub const RPT_MEDIUM_NONE: u32 = 0;
+pub const RPT_MEDIUM_ABSORB: u32 = 1;
+pub const RPT_MEDIUM_SCATTER: u32 = 2;
+pub const RPT_MEDIUM_EMISSIVE: u32 = 3;
 pub const RPT_LIGHT_RECTANGULAR: u32 = 0;
 pub const RPT_LIGHT_SPHERICAL: u32 = 1;
 pub const RPT_LIGHT_DISTANT: u32 = 2;
@@ -61,6 +68,7 @@ pub const RPT_BG_CONSTANT: u32 = 0;
 pub const RPT_BG_GRADIENT_Y: u32 = 1;
 pub const RPT_SCENE_ANYHIT_USES_MAX_DIST: u32 = 1;
 pub const RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES: u32 = 2;
+pub const RPT_SCENE_MEDIA: u32 = 4;
 pub const RPT_RENDER_DEFAULT: u32 = 0;
 pub const RPT_RENDER_NESTED_LOOPS: u32 = 1;
 pub const RPT_RENDER_FAST_MATH: u32 = 2;

@@ -34,7 +34,7 @@ def test_struct_layout_matches_c(rpt, tmp_path):
 #define O(t, f) printf(#t "." #f " %zu\n", offsetof(t, f))
 int main(void) {
   S(rpt_material); S(rpt_sphere); S(rpt_plane); S(rpt_light); S(rpt_camera); S(rpt_background); S(rpt_scene_desc);
-  O(rpt_material, rgb); O(rpt_material, ior); O(rpt_material, proc_params);
+  O(rpt_material, rgb); O(rpt_material, ior); O(rpt_material, proc_params); O(rpt_material, medium_type); O(rpt_material, medium_color); O(rpt_material, medium_anisotropy);
   O(rpt_light, radius); O(rpt_light, area); O(rpt_plane, min_denom);
   O(rpt_scene_desc, camera); O(rpt_scene_desc, background); O(rpt_scene_desc, eps); O(rpt_scene_desc, spheres);
   O(rpt_scene_desc, planes); O(rpt_scene_desc, lights); O(rpt_scene_desc, n_materials); O(rpt_scene_desc, materials);

@@ -223,7 +223,7 @@ def check_binding(rust_src, tmp_path):
     # constants: every `pub const RPT_*` must have the header's value (gcc evaluates the enumerators), and every render /
     # scene flag and status code of the header must be there
     r_consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"pub const (RPT_[A-Z0-9_]+): [iu]32 = (-?(?:0x[0-9A-Fa-f]+|\d+));", rust_src)}
-    hdr_names = sorted(set(re.findall(r"\b(RPT_(?:RENDER|SCENE|ERR|LIGHT|BG)_[A-Z0-9_]+|RPT_OK|RPT_MAT_ALL)\s*=", open(HEADER).read())))
+    hdr_names = sorted(set(re.findall(r"\b(RPT_(?:RENDER|SCENE|ERR|LIGHT|BG|MEDIUM)_[A-Z0-9_]+|RPT_OK|RPT_MAT_ALL|RPT_MAT_MEDIUM)\s*=", open(HEADER).read())))
     prog = os.path.join(str(tmp_path), "consts.c")
     with open(prog, "w") as f:
         f.write('#include <stdio.h>\n#include "rpt.h"\nint main(void) {\n')
