@@ -139,6 +139,29 @@ def other_configs(rpt, torch, device, small):
                                "kernel_ms": round(t8 * 1e3, 3), "value": round(w * h * 8 / t8 / 1e6, 2),
                                "frac": round(ops["flops_per_sample"] * w * h * 8 / t8 / 1e12 / FP32_PEAK_TFLOPS, 5)}
     out["roofline_c5"] = blk
+    # the denoiser (include/rpt.h, project-defined): an HBM pass, 32 B per pixel per iteration
+    for name, (dw, dh) in (("roofline_denoise_1080p", (1920 // div, 1080 // div)), ("roofline_denoise_4k", (3840 // div, 2160 // div))):
+        buf = rpt.DeviceColorBuffer(dw, dh, device="cuda:%d" % device)
+        buf.pixels.uniform_(0.0, 2.0)
+        iters = 3
+        res = buf.denoise(iters, 2.0)
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            buf.denoise(iters, 2.0, out=res)
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        del res
+        t = min(ms) / 1e3
+        gbs = iters * 32.0 * dw * dh / t / 1e9
+        out[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                     "traffic": None, "kernel": "denoise_first_kernel + %d x denoise_step_kernel" % (iters - 1), "kernel_ms": round(t * 1e3, 4),
+                     "algorithmic_bytes_per_step": iters * 32.0 * dw * dh,
+                     "workload": "a-trous denoiser, %d iterations on a %dx%d RGBA f32 buffer (16 B read + 16 B written per pixel per iteration)" % (iters, dw, dh)}
+        del buf
     return out
 
 

@@ -442,6 +442,30 @@ int rpt_convert_to_u8_device(rpt_ctx* ctx, const float* pixels_dev, uint8_t* out
 int rpt_convert_to_u8_at_device(rpt_ctx* ctx, const float* pixels_dev, uint32_t width, uint32_t height, uint8_t* frame_dev,
                                 uint32_t at_x, uint32_t at_y, uint32_t frame_width, uint32_t frame_height, void* stream);
 
+/* ---- denoiser ("Implement a denoiser" is a Todo of the reference, Readme.md:14) — PROJECT-DEFINED -----------
+ * An edge-avoiding a-trous wavelet filter (Dammertz et al., HPG 2010) on the colour buffer alone, run in a compressed colour
+ * space so that fireflies do not dominate: a separate pass over a ColorBuffer, never part of render().  There is no reference
+ * behaviour to match; the arithmetic (f32, this operation order) is the one in oracle/rpt_oracle.hpp, denoise():
+ *   c' = c / (1 + c)                                       per r, g, b of every pixel (alpha is not filtered)
+ *   iteration i = 0 .. iterations-1, step s = 2^i, k_i = edge_k * 4^i; for every pixel p, over the 3x3 taps
+ *   q = p + s * (dx, dy), dy = -1..1 outer, dx = -1..1 inner, q inside the image:
+ *       d = c'_p - c'_q;  d2 = d.r*d.r + d.g*d.g + d.b*d.b;  a tap whose d2 is NaN is skipped;
+ *       t = 1 - d2 * k_i;  g = t > 0 ? t : 0;  wt = (H[dy+1] * H[dx+1]) * (g * g),  H = {0.25, 0.5, 0.25};
+ *       acc += c'_q * wt;  wsum += wt
+ *   c'_p <- wsum > 0 ? acc / wsum : c'_p                   (all pixels at once: out of place)
+ *   finally c = c' / (1 - c'), alpha = the input's; a pixel whose input r, g or b is not finite is copied through unchanged
+ *   (and, being NaN in the compressed space, takes no part in its neighbours' sums).
+ * The filter is a weighted mean of compressed colours: it darkens a noisy region slightly (1-4 % at 1-4 spp on the
+ * reference's scene; tests/test_denoise.py) — the price of taming fireflies without auxiliary buffers.
+ * iterations 1..6 (footprint 2^(iterations+1) - 1 pixels), edge_k > 0 (larger = sharper edges, less smoothing; 2 is a good
+ * default at 1-16 spp).  Per iteration the pass reads and writes the buffer once: 32 B per pixel of HBM traffic.
+ * pixels_dev and out_dev are width*height*4 f32 device buffers and must not overlap; the context keeps one more buffer of
+ * that size between calls. */
+int rpt_denoise_device(rpt_ctx* ctx, const float* pixels_dev, float* out_dev, uint32_t width, uint32_t height,
+                       uint32_t iterations, float edge_k, void* stream);
+/* The same on HOST buffers (upload, filter, download; blocks). */
+int rpt_denoise(rpt_ctx* ctx, const float* pixels, float* out, uint32_t width, uint32_t height, uint32_t iterations, float edge_k);
+
 /* The same on HOST buffers (upload, convert, download; blocks): what ColorBuffer::convert_to_u8
  * does for a caller that owns a host ColorBuffer (buffer.rs:55-64, frame = width*height*4 bytes). */
 int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_t width, uint32_t height);

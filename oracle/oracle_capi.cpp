@@ -455,4 +455,10 @@ void oracle_convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint
     }
 }
 
+// the denoiser of include/rpt.h (project-defined)
+void oracle_denoise(const float* pixels, float* out, uint32_t width, uint32_t height, uint32_t iterations, float edge_k)
+{
+    denoise(pixels, out, width, height, iterations, edge_k);
+}
+
 }  // extern "C"

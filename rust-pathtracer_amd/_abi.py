@@ -173,6 +173,8 @@ SYMBOLS = {
     "rpt_convert_to_u8_at_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_uint32, C.c_void_p]),
     "rpt_convert_to_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]),
+    "rpt_denoise_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]),
+    "rpt_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
     "rpt_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_probe_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "rpt_debug_render_overlap_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),

@@ -238,6 +238,14 @@ class ColorBuffer:
     def to_u8_vec(self):                                           # buffer.rs:37-52 (same arithmetic)
         return self.convert_to_u8()
 
+    def denoise(self, iterations=3, edge_k=2.0, device=0):
+        """A denoised copy (project-defined, include/rpt.h "denoiser"; the reference lists one as a Todo): a new ColorBuffer."""
+        out = ColorBuffer(self.width, self.height)
+        ctx = _ctx_for(device)
+        check(lib().rpt_denoise(ctx, self.pixels.ctypes.data, out.pixels.ctypes.data, self.width, self.height, iterations, edge_k), ctx)
+        out.frames = self.frames
+        return out
+
 
 class DeviceColorBuffer:
     """ColorBuffer whose pixels live in HBM (a torch CUDA tensor): what the render loop
@@ -258,6 +266,19 @@ class DeviceColorBuffer:
 
     def convert_to_u8(self):
         return _convert_to_u8_tensor(self.pixels, self.width, self.height)
+
+    def denoise(self, iterations=3, edge_k=2.0, out=None):
+        """A denoised copy on the device (include/rpt.h "denoiser"): a new DeviceColorBuffer, or `out` (same size)."""
+        import torch
+        if out is None:
+            out = DeviceColorBuffer(self.width, self.height, device=self.pixels.device)
+        assert out.width == self.width and out.height == self.height
+        ctx = _ctx_for(self.pixels.device.index or 0)
+        stream = torch.cuda.current_stream(self.pixels.device).cuda_stream
+        check(lib().rpt_denoise_device(ctx, self.pixels.data_ptr(), out.pixels.data_ptr(), self.width, self.height, iterations, edge_k,
+                                       C.c_void_p(stream)), ctx)
+        out.frames = self.frames
+        return out
 
     def convert_to_u8_at(self, frame, at):
         """buffer.rs:67-89: blit into `frame` (a CUDA uint8 tensor [at[3], at[2], 4]) at offset (at[0], at[1])."""

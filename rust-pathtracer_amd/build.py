@@ -13,7 +13,7 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpt_hip.so")
-SOURCES = ["kernels.hip", "kernels_fast.hip", "capi.hip"]
+SOURCES = ["kernels.hip", "kernels_fast.hip", "denoise.hip", "capi.hip"]
 # kernels_fast.hip: the same kernels with relaxed arithmetic (RPT_RENDER_FAST_MATH); every other file is strict
 EXTRA_FLAGS = {"kernels_fast.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"]}
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only

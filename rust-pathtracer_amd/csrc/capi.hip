@@ -41,6 +41,8 @@ struct DevState {
     SceneSmallSdf* scene_small_dev = nullptr;   // the small scene in device memory, for the one kernel that reads it from there (SDF compact)
     void* wf = nullptr;               // wavefront state of large scenes (dev_wavefront.h), grown on demand
     size_t wf_bytes = 0;
+    float* dn = nullptr;              // the denoiser's intermediate buffer, grown on demand
+    size_t dn_bytes = 0;
     ncclComm_t comm = nullptr;
 };
 
@@ -252,6 +254,7 @@ static void free_dev(DevState& d)
     if (d.tile) (void)hipFree(d.tile);
     if (d.tables) (void)hipFree(d.tables);
     if (d.wf) (void)hipFree(d.wf);
+    if (d.dn) (void)hipFree(d.dn);
     if (d.scene_small_dev) (void)hipFree(d.scene_small_dev);
     if (d.ev_begin) (void)hipEventDestroy(d.ev_begin);
     if (d.ev_end) (void)hipEventDestroy(d.ev_end);
@@ -1213,6 +1216,47 @@ int rpt_convert_to_u8_at_device(rpt_ctx* ctx, const float* pixels_dev, uint32_t 
     }
     RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, rptlaunch::convert_to_u8_at(pixels_dev, width, height, frame_dev, at_x, at_y, frame_width, frame_height, (hipStream_t)stream));
+    return RPT_OK;
+}
+
+int rpt_denoise_device(rpt_ctx* ctx, const float* pixels_dev, float* out_dev, uint32_t width, uint32_t height, uint32_t iterations,
+                       float edge_k, void* stream)
+{
+    if (!ctx) { set_err(nullptr, "rpt_denoise_device: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    const size_t bytes = (size_t)width * height * 16u;
+    if (!pixels_dev || !out_dev || width == 0 || height == 0 || iterations < 1u || iterations > 6u || !(edge_k > 0.0f) || !std::isfinite(edge_k)) {
+        set_err(ctx, "rpt_denoise_device: invalid argument (iterations 1..6, edge_k > 0)");
+        return RPT_ERR_INVALID_ARG;
+    }
+    if ((((uintptr_t)pixels_dev | (uintptr_t)out_dev) & 15u) != 0) { set_err(ctx, "rpt_denoise_device: buffers must be 16-byte aligned"); return RPT_ERR_INVALID_ARG; }
+    const char *a = (const char*)pixels_dev, *b = (const char*)out_dev;
+    if (a < b + bytes && b < a + bytes) { set_err(ctx, "rpt_denoise_device: pixels_dev and out_dev overlap"); return RPT_ERR_INVALID_ARG; }
+    RPT_ON_DEVICE(ctx);
+    DevState& d = ctx->devs[0];
+    if (iterations > 1u && bytes > d.dn_bytes) {
+        if (d.dn) { RPT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream)); RPT_HIP_CHECK(ctx, hipFree(d.dn)); d.dn = nullptr; d.dn_bytes = 0; }
+        RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.dn, bytes));
+        d.dn_bytes = bytes;
+    }
+    RPT_HIP_CHECK(ctx, rptlaunch::denoise(pixels_dev, out_dev, d.dn, width, height, iterations, edge_k, (hipStream_t)stream));
+    return RPT_OK;
+}
+
+int rpt_denoise(rpt_ctx* ctx, const float* pixels, float* out, uint32_t width, uint32_t height, uint32_t iterations, float edge_k)
+{
+    if (!ctx) { set_err(nullptr, "rpt_denoise: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
+    if (!pixels || !out || width == 0 || height == 0) { set_err(ctx, "rpt_denoise: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    RPT_ON_DEVICE(ctx);
+    DevState& d = ctx->devs[0];
+    const size_t bytes = (size_t)width * height * 16u;
+    int rc = ensure_fb(ctx, d, 2u * bytes);                           // input and output, one allocation
+    if (rc != RPT_OK) return rc;
+    float* out_dev = reinterpret_cast<float*>(reinterpret_cast<char*>(d.fb) + bytes);
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(d.fb, pixels, bytes, hipMemcpyHostToDevice, d.stream));
+    rc = rpt_denoise_device(ctx, d.fb, out_dev, width, height, iterations, edge_k, d.stream);
+    if (rc != RPT_OK) return rc;
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(out, out_dev, bytes, hipMemcpyDeviceToHost, d.stream));
+    RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
     return RPT_OK;
 }
 

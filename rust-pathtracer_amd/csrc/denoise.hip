@@ -1,0 +1,134 @@
+// denoise.hip — the denoiser of include/rpt.h ("denoiser": project-defined, the reference only lists one as a Todo,
+// Readme.md:14): an edge-avoiding a-trous filter over the colour buffer, in a compressed colour space.  A separate HBM pass
+// over a ColorBuffer, not part of the render path.  Specification and parity oracle: oracle/rpt_oracle.hpp, denoise().
+//
+// Roofline: HBM.  Every iteration reads and writes the buffer once (16 B + 16 B per pixel); the nine taps of a pixel are
+// re-reads of lines its neighbours fetch (L1 / L2).  The first iteration compresses the colours (three correctly rounded
+// divides per pixel) once per LOADED pixel, through an 18 x 18 tile in LDS, instead of once per tap.
+#include <hip/hip_runtime.h>
+
+#include "dev_math.h"
+#include "launch.h"
+
+using namespace rptdev;
+
+namespace {
+
+struct DnSum {
+    v3 acc;
+    float wsum;
+};
+
+// one tap of the filter (rpt.h: d2, the NaN skip, the edge-stopping weight)
+RPT_DEV void dn_tap(DnSum& s, v3 cp, v3 cq, float hw, float k)
+{
+    const float d0 = cp.x - cq.x, d1 = cp.y - cq.y, d2c = cp.z - cq.z;
+    const float d2 = d0 * d0 + d1 * d1 + d2c * d2c;
+    if (!(d2 == d2)) return;
+    const float t = 1.0f - d2 * k;
+    const float g = t > 0.0f ? t : 0.0f;
+    const float wt = hw * (g * g);
+    s.acc.x = s.acc.x + cq.x * wt;
+    s.acc.y = s.acc.y + cq.y * wt;
+    s.acc.z = s.acc.z + cq.z * wt;
+    s.wsum = s.wsum + wt;
+}
+
+RPT_DEV float dn_h(int d) { return d == 0 ? 0.5f : 0.25f; }
+
+RPT_DEV float4 dn_finish(const DnSum& s, v3 cp, bool last, float4 orig)
+{
+    const bool ok = s.wsum > 0.0f;
+    const v3 o = mk3(ok ? s.acc.x / s.wsum : cp.x, ok ? s.acc.y / s.wsum : cp.y, ok ? s.acc.z / s.wsum : cp.z);
+    if (!last) return make_float4(o.x, o.y, o.z, 0.0f);
+    const float inf = __builtin_inff();
+    const bool finite = (__builtin_fabsf(orig.x) < inf) && (__builtin_fabsf(orig.y) < inf) && (__builtin_fabsf(orig.z) < inf);
+    if (!finite) return orig;
+    return make_float4(o.x / (1.0f - o.x), o.y / (1.0f - o.y), o.z / (1.0f - o.z), orig.w);
+}
+
+// iteration 0 (step 1): c' = c / (1 + c) once per loaded pixel, through LDS
+__global__ __launch_bounds__(256) void denoise_first_kernel(const float4* __restrict__ in, float4* __restrict__ out, uint32_t w, uint32_t h,
+                                                            float k, uint32_t last)
+{
+    __shared__ float s_c[3][18 * 18];
+    const int x0 = (int)blockIdx.x * 16, y0 = (int)blockIdx.y * 16;
+    for (uint32_t e = threadIdx.x; e < 324u; e += 256u) {
+        const int lx = (int)(e % 18u), ly = (int)(e / 18u);
+        const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+        float c0 = __builtin_nanf(""), c1 = c0, c2 = c0;              // outside the image: NaN, i.e. a tap that is skipped
+        if (gx >= 0 && gy >= 0 && gx < (int)w && gy < (int)h) {
+            const float4 v = in[(size_t)gy * w + (size_t)gx];
+            c0 = v.x / (1.0f + v.x); c1 = v.y / (1.0f + v.y); c2 = v.z / (1.0f + v.z);
+        }
+        s_c[0][e] = c0; s_c[1][e] = c1; s_c[2][e] = c2;
+    }
+    __syncthreads();
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t x = (uint32_t)x0 + tx, y = (uint32_t)y0 + ty;
+    if (x >= w || y >= h) return;
+    const uint32_t ce = (ty + 1u) * 18u + tx + 1u;
+    const v3 cp = mk3(s_c[0][ce], s_c[1][ce], s_c[2][ce]);
+    DnSum s{mk3(0.0f, 0.0f, 0.0f), 0.0f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const uint32_t e = (uint32_t)((int)ce + dy * 18 + dx);
+            dn_tap(s, cp, mk3(s_c[0][e], s_c[1][e], s_c[2][e]), dn_h(dy) * dn_h(dx), k);
+        }
+    const size_t p = (size_t)y * w + x;
+    float4 orig = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (last) orig = in[p];
+    out[p] = dn_finish(s, cp, last != 0u, orig);
+}
+
+// iterations 1.. (step 2^i): taps straight from the compressed buffer
+__global__ __launch_bounds__(256) void denoise_step_kernel(const float4* __restrict__ cur, const float4* __restrict__ orig_in,
+                                                           float4* __restrict__ out, uint32_t w, uint32_t h, int step, float k, uint32_t last)
+{
+    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t x = blockIdx.x * 16u + tx, y = blockIdx.y * 16u + ty;
+    if (x >= w || y >= h) return;
+    const size_t p = (size_t)y * w + x;
+    const float4 c4 = cur[p];
+    const v3 cp = mk3(c4.x, c4.y, c4.z);
+    DnSum s{mk3(0.0f, 0.0f, 0.0f), 0.0f};
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const long long qx = (long long)x + (long long)step * dx, qy = (long long)y + (long long)step * dy;
+            if (qx < 0 || qy < 0 || qx >= (long long)w || qy >= (long long)h) continue;
+            const float4 q = (dx == 0 && dy == 0) ? c4 : cur[(size_t)qy * w + (size_t)qx];
+            dn_tap(s, cp, mk3(q.x, q.y, q.z), dn_h(dy) * dn_h(dx), k);
+        }
+    float4 orig = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (last) orig = orig_in[p];
+    out[p] = dn_finish(s, cp, last != 0u, orig);
+}
+
+}  // namespace
+
+namespace rptlaunch {
+
+// `iterations` passes: in -> t0 -> t1 -> ... -> out, alternating between `out` and `scratch` so that the last one lands in `out`.
+hipError_t denoise(const float* in, float* out, float* scratch, uint32_t width, uint32_t height, uint32_t iterations, float edge_k,
+                   hipStream_t st)
+{
+    (void)hipGetLastError();
+    const dim3 grid((width + 15u) / 16u, (height + 15u) / 16u), wg(256);
+    float k = edge_k;
+    const float4* cur = nullptr;
+    for (uint32_t i = 0; i < iterations; ++i) {
+        const bool last = i + 1u == iterations;
+        float4* dst = (float4*)(((iterations - 1u - i) & 1u) ? scratch : out);
+        if (i == 0) hipLaunchKernelGGL(denoise_first_kernel, grid, wg, 0, st, (const float4*)in, dst, width, height, k, last ? 1u : 0u);
+        else hipLaunchKernelGGL(denoise_step_kernel, grid, wg, 0, st, cur, (const float4*)in, dst, width, height, 1 << i, k, last ? 1u : 0u);
+        cur = dst;
+        k = k * 4.0f;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace rptlaunch

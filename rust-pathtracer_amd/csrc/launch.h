@@ -54,6 +54,9 @@ hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t 
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st);
 hipError_t convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8_t* frame, uint32_t at0, uint32_t at1, uint32_t width,
                             uint32_t height, hipStream_t st);
+// the denoiser (denoise.hip): `iterations` a-trous passes in -> out through `scratch` (each width * height * 4 f32)
+hipError_t denoise(const float* in, float* out, float* scratch, uint32_t width, uint32_t height, uint32_t iterations, float edge_k,
+                   hipStream_t st);
 hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t st);
 hipError_t probe_fn(uint32_t fn, const rptdev::DevCamera& cam, const float* in, float* out, uint64_t n, hipStream_t st);
 hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st);

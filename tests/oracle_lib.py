@@ -174,6 +174,13 @@ class Oracle:
         self.lib.oracle_convert_to_u8_at(pixels.ctypes.data, bw, bh, frame.ctypes.data, at[0], at[1], at[2], at[3])
         return frame
 
+    def denoise(self, pixels, width, height, iterations=3, edge_k=2.0):
+        pixels = np.ascontiguousarray(pixels, dtype=np.float32)
+        out = np.zeros((height, width, 4), dtype=np.float32)
+        self.lib.oracle_denoise.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]
+        self.lib.oracle_denoise(pixels.ctypes.data, out.ctypes.data, width, height, iterations, edge_k)
+        return out
+
     def convert_to_u8(self, pixels, width, height):
         pixels = np.ascontiguousarray(pixels, dtype=np.float32)
         out = np.zeros(width * height * 4, dtype=np.uint8)
