@@ -120,7 +120,7 @@ def other_configs(rpt, torch, device, small):
     sdf = scenes.sdf_scene()
     w, h, spp = 1920 // div, 1080 // div, 64 // (4 if small else 1)
     t = run(sdf, w, h, spp, 3)
-    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march_kernel", 1, w * h)
+    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march2_kernel", 1, w * h)
     blk.update({"workload": "SDF sphere-march scene %dx%d x %d spp per step (BASELINE.json configs[3])" % (w, h, spp),
                 "value": round(w * h * spp / t / 1e6, 2), "value_unit": "Msamples/s"})
     out["roofline_c4"] = blk

@@ -274,7 +274,7 @@ enum {
      * Not bit-identical to the reference arithmetic (statistically equivalent); off by default, never benchmarked. */
     RPT_RENDER_FAST_MATH    = 1u << 1,
     /* Scenes with an SDF object: run the sphere march inside closest_hit / any_hit (one bounce per scheduling
-     * step) instead of as a resumable scheduling state of its own.  Same image bit for bit; kept for A/B. */
+     * step) instead of as a resumable scheduling state of the lane (the default).  Same image bit for bit; kept for A/B. */
     RPT_RENDER_SDF_INLINE_MARCH = 1u << 2,
     /* REMOVED (accepted for source compatibility, rpt_render* return RPT_ERR_UNSUPPORTED): the grid walk of large scenes as a
      * resumable scheduling state.  Measured slower in round 1. */
@@ -310,7 +310,11 @@ enum {
     /* Scenes with an SDF object: the same idea with the sphere march as one of the stages (paths in LDS, marching paths
      * re-dealt every few iterations).  Same image bit for bit; measured SLOWER than the default march kernel (1.7 vs 2.4
      * Gsamples/s: DESIGN.md 4b); only in builds with -DRPT_AB_KERNELS, otherwise RPT_ERR_UNSUPPORTED. */
-    RPT_RENDER_SDF_COMPACT = 1u << 9
+    RPT_RENDER_SDF_COMPACT = 1u << 9,
+    /* Scenes with an SDF object: round 2's march kernel (three waiting rooms per wave: RESOLVE, the shadow march, SHADE) instead of
+     * the default two-room one, which marches the shadow ray of a bounce right before the next path ray and does the rest of the
+     * bounce in one block.  Same image bit for bit; kept for A/B (2.35 vs 2.41 Gsamples/s on configs[3]). */
+    RPT_RENDER_SDF_THREE_ROOM_MARCH = 1u << 10
 };
 
 /* ---- context --------------------------------------------------------------- */
@@ -489,11 +493,11 @@ int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b
  *   HIT_SPHERE     {o[3], d[3], centre[3], radius} -> {hit, t}                       analytical.rs:166-190
  *   HIT_PLANE      {o[3], d[3], normal[3], point[3], min_denom, max_t} -> {hit, t}   analytical.rs:193-204
  *   SAMPLE_LIGHT   {type, position[3], emission[3], radius, area, u[3], v[3], scatter_pos[3], n_lights, scene flags,
- *                   fkey, pixel, counter} -> {normal[3], emission[3], direction[3], dist, pdf, draws}   tracer.rs:173-220
+ *                   rng state, rng increment, -} -> {normal[3], emission[3], direction[3], dist, pdf, draws}   tracer.rs:173-220
  *   DISNEY_EVAL    {material: rgb[3], emission[3], anisotropic, metallic, roughness, subsurface, specular_tint, sheen,
  *                   sheen_tint, clearcoat, clearcoat_gloss, spec_trans, ior (before finalize), eta, v[3], n[3], l[3]}
  *                  -> {f[3], pdf}                                                    tracer.rs:555-626
- *   DISNEY_SAMPLE  {material (17), eta, v[3], n[3], l_stale[3], fkey, pixel, counter}
+ *   DISNEY_SAMPLE  {material (17), eta, v[3], n[3], l_stale[3], rng state, rng increment, -}
  *                  -> {f[3], l[3], pdf, draws}                                       tracer.rs:441-553            */
 enum {
     RPT_PROBE_FN_GEN_RAY = 0, RPT_PROBE_FN_HIT_SPHERE = 1, RPT_PROBE_FN_HIT_PLANE = 2, RPT_PROBE_FN_SAMPLE_LIGHT = 3,

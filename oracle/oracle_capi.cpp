@@ -299,14 +299,15 @@ void oracle_disney_sample(const float* m, float eta, const float* v, const float
     st.material = material_from_array(m);
     st.material.finalize();
     st.eta = eta;
-    Rng rng(fkey, pixel);
-    rng.counter = counter;
+    (void)counter;                                           // (the records' third RNG field is unused since the RNG is a stream)
+    Rng rng(fkey, pixel);                                    // = (state, increment)
+    const Rng rng0 = rng;
     F3 l(l_stale[0], l_stale[1], l_stale[2]);
     F pdf(0.0f);
     F3 f = tr.disney_sample(st, F3(v[0], v[1], v[2]), F3(n[0], n[1], n[2]), l, pdf, rng);
     out[0] = raw(f.x); out[1] = raw(f.y); out[2] = raw(f.z);
     out[3] = raw(l.x); out[4] = raw(l.y); out[5] = raw(l.z);
-    out[6] = raw(pdf); out[7] = (float)(rng.counter - counter);
+    out[6] = raw(pdf); out[7] = (float)rng_draws_between(rng0, rng);
 }
 
 // sample_light with an explicit RNG position: light = rpt_light; out = {normal[3], emission[3], direction[3], dist, pdf, draws_used}
@@ -319,14 +320,15 @@ void oracle_sample_light(const rpt_light* light, const float* scatter_pos, uint3
     d.flags = scene_flags;
     Scene scene(d);
     Tracer tr(scene);
-    Rng rng(fkey, pixel);
-    rng.counter = counter;
+    (void)counter;
+    Rng rng(fkey, pixel);                                    // = (state, increment)
+    const Rng rng0 = rng;
     LightSampleRec ls;
     tr.sample_light(*light, F3(scatter_pos[0], scatter_pos[1], scatter_pos[2]), ls, rng);
     out[0] = raw(ls.normal.x); out[1] = raw(ls.normal.y); out[2] = raw(ls.normal.z);
     out[3] = raw(ls.emission.x); out[4] = raw(ls.emission.y); out[5] = raw(ls.emission.z);
     out[6] = raw(ls.direction.x); out[7] = raw(ls.direction.y); out[8] = raw(ls.direction.z);
-    out[9] = raw(ls.dist); out[10] = raw(ls.pdf); out[11] = (float)(rng.counter - counter);
+    out[9] = raw(ls.dist); out[10] = raw(ls.pdf); out[11] = (float)rng_draws_between(rng0, rng);
 }
 
 // The record-per-call layouts of include/rpt.h's rpt_probe_fn, evaluated by the oracle (one call for n records).

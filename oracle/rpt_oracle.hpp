@@ -265,9 +265,9 @@ struct LightSampleRec {                                                         
 };
 
 // ---------------------------------------------------------------------------
-// RNG — replaces rand::thread_rng (tracer.rs:44).  PCG hash (Jarzynski & Olano,
-// "Hash Functions for GPU Rendering", JCGT 2020) of a per-path key plus a draw
-// counter; u32 -> f32 exactly as rand 0.8.5's Standard distribution.
+// RNG — replaces rand::thread_rng (tracer.rs:44).  The hash that builds the keys is the PCG hash of Jarzynski & Olano
+// ("Hash Functions for GPU Rendering", JCGT 2020); the draws come from one PCG stream per path (below);
+// u32 -> f32 exactly as rand 0.8.5's Standard distribution.
 // ---------------------------------------------------------------------------
 inline uint32_t pcg_hash(uint32_t v)
 {
@@ -275,20 +275,51 @@ inline uint32_t pcg_hash(uint32_t v)
     uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
     return (word >> 22u) ^ word;
 }
-inline uint32_t frame_key(uint64_t seed, uint64_t frame)
+// (seed, frame) -> two independently folded words: 64 bits of key per frame
+struct FrameKey {
+    uint32_t k0, k1;
+};
+inline FrameKey frame_key(uint64_t seed, uint64_t frame)
 {
+    FrameKey fk;
     uint32_t k = pcg_hash((uint32_t)(seed >> 32));
     k = pcg_hash(k ^ (uint32_t)seed);
     k = pcg_hash(k ^ (uint32_t)(frame >> 32));
-    k = pcg_hash(k ^ (uint32_t)frame);
-    return k;
+    fk.k0 = pcg_hash(k ^ (uint32_t)frame);
+    uint32_t j = pcg_hash((uint32_t)(seed >> 32) ^ 0x85EBCA6Bu);
+    j = pcg_hash(j ^ (uint32_t)seed);
+    j = pcg_hash(j ^ (uint32_t)(frame >> 32));
+    fk.k1 = pcg_hash(j ^ (uint32_t)frame);
+    return fk;
 }
+// One PCG stream per path: PCG-RXS-M-XS-32 (O'Neill, "PCG: A Family of Simple Fast Space-Efficient Statistically Good Algorithms
+// for Random Number Generation", 2014) — a 32-bit LCG whose odd increment selects the stream, the RXS-M-XS output permutation —
+// started from (state, increment) hashed from (seed, frame, pixel).  (Until round 3: pcg_hash(key + counter) with a 32-bit key —
+// paths with nearby keys read overlapping windows of one sequence.)
 struct Rng {
-    uint32_t key, counter;
-    Rng(uint32_t fkey, uint32_t pixel_index) : key(pcg_hash(pcg_hash(pixel_index) ^ fkey)), counter(0) {}
-    uint32_t next_u32() { return pcg_hash(key + counter++); }
+    uint32_t state, inc;
+    Rng(FrameKey fk, uint32_t pixel_index)
+    {
+        const uint32_t a = pcg_hash(pixel_index), b = pcg_hash(a);
+        state = pcg_hash(a ^ fk.k0);
+        inc = pcg_hash(b ^ fk.k1) | 1u;
+    }
+    Rng(uint32_t state_, uint32_t inc_) : state(state_), inc(inc_ | 1u) {}          // tests: a stream at an explicit position
+    uint32_t next_u32()
+    {
+        state = state * 747796405u + inc;
+        uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+        return (word >> 22u) ^ word;
+    }
     F gen() { return F((float)(next_u32() >> 8) * (1.0f / 16777216.0f)); }
 };
+// tests: how many draws lie between two positions of one stream (at most `limit`)
+inline uint32_t rng_draws_between(Rng from, const Rng& to, uint32_t limit = 64u)
+{
+    uint32_t n = 0u;
+    while (from.state != to.state && n < limit) { (void)from.next_u32(); ++n; }
+    return n;
+}
 
 // ---------------------------------------------------------------------------
 // Scene — data-driven restatement of trait Scene (scene.rs:5-90) as implemented
@@ -1064,7 +1095,7 @@ struct Tracer {
 
     // One pixel-sample: the closure body of tracer.rs:33-117 up to `color`.
     //   col,row_mem: pixel position in the top-down buffer; returns the radiance.
-    F3 sample_pixel(uint32_t col, uint32_t row_mem, uint32_t width_u, uint32_t height_u, uint32_t fkey) const
+    F3 sample_pixel(uint32_t col, uint32_t row_mem, uint32_t width_u, uint32_t height_u, FrameKey fkey) const
     {
         F width = F((float)width_u);
         F height = F((float)height_u);
@@ -1174,7 +1205,7 @@ struct Tracer {
     {
         for (uint32_t s = 0; s < spp; ++s) {
             uint64_t frames = frames_done + s;
-            uint32_t fkey = frame_key(seed, frames);
+            FrameKey fkey = frame_key(seed, frames);
             F v = F(1.0f) / F((float)(frames + 1));                                // tracer.rs:115
 #pragma omp parallel for schedule(dynamic, 1)
             for (int64_t jj = 0; jj < (int64_t)(row_end - row_begin); ++jj) {      // one task per scanline, tracer.rs:24,29-32

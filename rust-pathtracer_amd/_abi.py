@@ -54,6 +54,7 @@ RPT_RENDER_LARGE_WAVEFRONT = 1 << 6
 RPT_RENDER_LARGE_MEGAKERNEL = 1 << 7
 RPT_RENDER_SMALL_COMPACT = 1 << 8
 RPT_RENDER_SDF_COMPACT = 1 << 9
+RPT_RENDER_SDF_THREE_ROOM_MARCH = 1 << 10
 
 (RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG, RPT_PROBE_EXP,
  RPT_PROBE_LOG) = range(9)

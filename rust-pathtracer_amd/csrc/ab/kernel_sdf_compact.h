@@ -26,7 +26,7 @@ RPT_DEV void sc_put_path(SdfRecords& r, uint32_t i, const PathRegs& p)
     r.f[6][i] = p.throughput.x; r.f[7][i] = p.throughput.y; r.f[8][i] = p.throughput.z;
     r.f[9][i] = p.radiance.x; r.f[10][i] = p.radiance.y; r.f[11][i] = p.radiance.z;
     r.f[12][i] = p.ps.hit_dist; r.f[13][i] = p.ps.scatter_pdf;
-    r.u[0][i] = p.rng.key; r.u[1][i] = p.rng.counter; r.u[2][i] = p.bounce;
+    r.u[0][i] = p.rng.state; r.u[1][i] = p.rng.inc; r.u[2][i] = p.bounce;
 }
 RPT_DEV void sc_get_path(const SdfRecords& r, uint32_t i, PathRegs& p)
 {
@@ -35,7 +35,7 @@ RPT_DEV void sc_get_path(const SdfRecords& r, uint32_t i, PathRegs& p)
     p.throughput = mk3(r.f[6][i], r.f[7][i], r.f[8][i]);
     p.radiance = mk3(r.f[9][i], r.f[10][i], r.f[11][i]);
     p.ps.hit_dist = r.f[12][i]; p.ps.scatter_pdf = r.f[13][i];
-    p.rng.key = r.u[0][i]; p.rng.counter = r.u[1][i]; p.bounce = r.u[2][i];
+    p.rng.state = r.u[0][i]; p.rng.inc = r.u[1][i]; p.bounce = r.u[2][i];
 }
 RPT_DEV void sc_put_march(SdfRecords& r, uint32_t i, const MarchRegs& m)
 {

@@ -188,7 +188,12 @@ static uint32_t env_lanes(const char* name, long dflt)
 // Scheduling knobs (they change when work runs, never its result): lanes that must be waiting before a wave
 // runs a block.
 static uint32_t shade_threshold() { static const uint32_t v = env_lanes("RPT_SHADE_THRESHOLD", 56); return v; }
-static uint32_t sdf_march_min_lanes() { static const uint32_t v = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8); return v; }
+static uint32_t finish_threshold() { static const uint32_t v = env_lanes("RPT_FINISH_THRESHOLD", 16); return v; }
+static uint32_t sdf_march_min_lanes(bool two_rooms)
+{
+    static const uint32_t two = env_lanes("RPT_SDF_MARCH_MIN_LANES", 12), three = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8);
+    return two_rooms ? two : three;
+}
 static uint32_t sdf_pool_shade_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_SHADE_LANES", 48); return v; }
 static uint32_t sdf_pool_resolve_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_RESOLVE_LANES", 16); return v; }
 static uint32_t sdf_pool_min_batch() { static const uint32_t v = env_lanes("RPT_SDF_POOL_MIN_BATCH", 32); return v; }
@@ -394,15 +399,25 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
     rp.seed = seed;
     rp.tiles_x = (width + 15u) / 16u;
-    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : ((flags & RPT_RENDER_SDF_POOL_MARCH) ? 2u : (sdf_compact_wanted(flags) ? 3u : 1u));
+    // SDF scenes: 0 inline march, 1 round 2's three-room march kernel, 2 / 3 the A/B kernels, 4 the two-room march kernel (default)
+    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : ((flags & RPT_RENDER_SDF_POOL_MARCH) ? 2u : (sdf_compact_wanted(flags) ? 3u :
+                             ((flags & RPT_RENDER_SDF_THREE_ROOM_MARCH) ? 1u : 4u)));
     rp.sdf_compact_steps = sdf_compact_steps();
     rp.pool_shade_lanes = sdf_pool_shade_lanes();
     rp.pool_resolve_lanes = sdf_pool_resolve_lanes();
     rp.pool_min_batch = sdf_pool_min_batch();
     rp.pool_patience = sdf_pool_patience();
     rp.shade_threshold = shade_threshold();
+    // (small scenes' megakernel only; 16 and 24 are within noise of each other, +5.9 % over finishing un-voted)
+    rp.finish_threshold = finish_threshold();
     rp.compact = ((flags & RPT_RENDER_SMALL_COMPACT) || spp <= compact_max_spp()) ? 1u : 0u;
-    rp.march_min_lanes = sdf_march_min_lanes();
+    rp.march_min_lanes = sdf_march_min_lanes(rp.sdf_resumable_march == 4u);
+    {
+        static const char* mega = getenv("RPT_LARGE_MEGA");          // pair | plain: which megakernel large scenes with a grid take (A/B)
+        static const uint32_t refill = getenv("RPT_PAIR_REFILL_AT") ? ((uint32_t)atoi(getenv("RPT_PAIR_REFILL_AT")) & 63u) : 32u;
+        rp.large_pair_walk = (mega && mega[0] == 'p' && mega[1] == 'a') ? 1u : 0u;
+        rp.walk_refill_at = refill;
+    }
     if (flags & RPT_RENDER_RUSSIAN_ROULETTE) { scs.flags |= kSceneFlagRussianRoulette; scl.flags |= kSceneFlagRussianRoulette; }
     if (rp.rows_local == 0) return RPT_OK;
     const uint32_t tiles_y = (rp.rows_local + 15u) / 16u;

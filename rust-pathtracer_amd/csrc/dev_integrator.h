@@ -681,12 +681,12 @@ struct PathRegs {
     uint32_t medium;           // media kernels only (dev_media.h): 0, or 1 + the material whose Medium the path is in [| kMediumScatterNow]
 };
 
-// tracer.rs:44-57.  HASHED: `pixel` is already pcg_hash(pixel index) (the state-machine kernels keep that in LDS: left to
-// itself the compiler hoists the hash out of the sample loop into a register that then spills).
+// tracer.rs:44-57.  HASHED: `pixel` and `pixel_b` are the two hashes of the pixel index (dev_math.h, Rng::init; the state-machine
+// kernels keep them in LDS: left to itself the compiler hoists the hashes out of the sample loop into registers that then spill).
 template <bool HASHED = false, class S>
-RPT_DEV void path_begin(const S& sc, PathRegs& p, float px, float py, uint32_t fkey, uint32_t pixel)
+RPT_DEV void path_begin(const S& sc, PathRegs& p, float px, float py, FrameKey fkey, uint32_t pixel, uint32_t pixel_b = 0u)
 {
-    if (HASHED) p.rng.init_hashed(fkey, pixel);
+    if (HASHED) p.rng.init_hashed(fkey, pixel, pixel_b);
     else p.rng.init(fkey, pixel);
     float offx = p.rng.gen();
     float offy = p.rng.gen();
@@ -883,7 +883,7 @@ RPT_DEV bool path_bounce(const S& sc, PathRegs& p)
 
 // One pixel-sample start to end (the nested-loop form; kept for the A/B kernel).
 template <class S>
-RPT_DEV v3 trace_sample(const S& sc, float px, float py, uint32_t fkey, uint32_t pixel_index)
+RPT_DEV v3 trace_sample(const S& sc, float px, float py, FrameKey fkey, uint32_t pixel_index)
 {
     PathRegs p;
     path_begin(sc, p, px, py, fkey, pixel_index);

@@ -76,8 +76,12 @@ RPT_DEV float clampf(float x, float lo, float hi)
 RPT_DEV float rem2(float a) { return a - 2.0f * __builtin_truncf(a * 0.5f); }
 
 // ---- RNG --------------------------------------------------------------------
-// Counter-based replacement for rand::thread_rng (tracer.rs:44): PCG hash of
-// (path key + draw counter); u32 -> f32 as rand 0.8.5 Standard: (u >> 8) * 2^-24.
+// Replacement for rand::thread_rng (tracer.rs:44), which cannot be seeded: every path owns a PCG stream — PCG-RXS-M-XS-32
+// (O'Neill 2014): a 32-bit LCG whose increment selects the stream, with the RXS-M-XS output permutation — started from a
+// 63-bit key (state, increment) hashed from (seed, frame, pixel); u32 -> f32 as rand 0.8.5 Standard: (u >> 8) * 2^-24.
+// Round 2 drew pcg_hash(key + counter) from a 32-bit key: paths with nearby keys read overlapping windows of ONE sequence,
+// and (seed, frame) was folded to 32 bits per frame.  Now two paths share draws only if state AND increment coincide.  The cost
+// per draw is the same two multiplies (pcg_hash IS one LCG step + the permutation).
 RPT_DEV uint32_t pcg_hash(uint32_t v)
 {
     uint32_t state = v * 747796405u + 2891336453u;
@@ -90,31 +94,53 @@ __host__ __device__ inline uint32_t pcg_hash_hd(uint32_t v)
     uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
     return (word >> 22u) ^ word;
 }
-__host__ __device__ inline uint32_t frame_key_hd(uint64_t seed, uint64_t frame)
+// (seed, frame) -> two independently folded words: 64 bits of key per frame
+struct FrameKey {
+    uint32_t k0, k1;
+};
+__host__ __device__ inline FrameKey frame_key_hd(uint64_t seed, uint64_t frame)
 {
+    FrameKey fk;
     uint32_t k = pcg_hash_hd((uint32_t)(seed >> 32));
     k = pcg_hash_hd(k ^ (uint32_t)seed);
     k = pcg_hash_hd(k ^ (uint32_t)(frame >> 32));
-    k = pcg_hash_hd(k ^ (uint32_t)frame);
-    return k;
+    fk.k0 = pcg_hash_hd(k ^ (uint32_t)frame);
+    uint32_t j = pcg_hash_hd((uint32_t)(seed >> 32) ^ 0x85EBCA6Bu);
+    j = pcg_hash_hd(j ^ (uint32_t)seed);
+    j = pcg_hash_hd(j ^ (uint32_t)(frame >> 32));
+    fk.k1 = pcg_hash_hd(j ^ (uint32_t)frame);
+    return fk;
 }
 
 struct Rng {
-    uint32_t key;
-    uint32_t counter;
-    RPT_DEV void init(uint32_t fkey, uint32_t pixel_index)
+    uint32_t state;
+    uint32_t inc;              // odd: the stream
+    // a = pcg_hash(pixel index), b = pcg_hash(a): computed once per pixel by the state-machine kernels
+    RPT_DEV void init_hashed(FrameKey fk, uint32_t a, uint32_t b)
     {
-        key = pcg_hash(pcg_hash(pixel_index) ^ fkey);
-        counter = 0;
+        state = pcg_hash(a ^ fk.k0);
+        inc = pcg_hash(b ^ fk.k1) | 1u;
     }
-    // the same with pcg_hash(pixel_index) computed once per pixel by the caller
-    RPT_DEV void init_hashed(uint32_t fkey, uint32_t pixel_hash)
+    RPT_DEV void init(FrameKey fk, uint32_t pixel_index)
     {
-        key = pcg_hash(pixel_hash ^ fkey);
-        counter = 0;
+        const uint32_t a = pcg_hash(pixel_index);
+        init_hashed(fk, a, pcg_hash(a));
     }
-    RPT_DEV uint32_t next_u32() { return pcg_hash(key + counter++); }
+    RPT_DEV uint32_t next_u32()
+    {
+        state = state * 747796405u + inc;
+        uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+        return (word >> 22u) ^ word;
+    }
     RPT_DEV float gen() { return (float)(next_u32() >> 8) * (1.0f / 16777216.0f); }
 };
+
+// test probes: how many draws lie between two states of one stream (at most `limit`)
+RPT_DEV uint32_t rng_draws_between(Rng from, const Rng& to, uint32_t limit = 64u)
+{
+    uint32_t n = 0u;
+    while (from.state != to.state && n < limit) { (void)from.next_u32(); ++n; }
+    return n;
+}
 
 }  // namespace rptdev

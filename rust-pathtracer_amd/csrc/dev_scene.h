@@ -131,6 +131,7 @@ struct RenderParams {
     uint64_t seed;
     uint32_t tiles_x;          // ceil(width / 16)
     uint32_t shade_threshold;  // lanes that must be waiting before a wave runs the shading block
+    uint32_t finish_threshold; // ... and before it runs the finishing block (background, blend, next camera path) instead of the fuller room
     uint32_t march_min_lanes;      // SDF scenes: a wave keeps marching while at least this many lanes are marching
     uint32_t sdf_resumable_march;  // SDF scenes: 0 march inside closest_hit / any_hit, 1 as a scheduling state of the lane (dev_sdf_path.h),
                                    // 2 through the workgroup's march pool (dev_sdf_pool.h), 3 the compacting kernel (paths in LDS)
@@ -139,6 +140,8 @@ struct RenderParams {
     uint32_t pool_min_batch;       // ... serves the queue when it can fill this many lanes with jobs ...
     uint32_t pool_patience;        // ... and after this many idle passes does whatever there is to do
     uint32_t sdf_compact_steps;    // SDF scenes, compacting kernel: march iterations per pass
+    uint32_t large_pair_walk;      // large scenes with a grid: the megakernel that walks a bounce's two rays in one loop (kernels.hip, render_large_pair_kernel)
+    uint32_t walk_refill_at;       // ... its idle lanes set up their next ray when at most this many lanes still walk
     uint32_t compact;              // small scenes: the kernel that re-deals its workgroup's paths before every stage (few samples per launch)
 };
 

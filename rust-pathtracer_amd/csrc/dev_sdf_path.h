@@ -98,4 +98,43 @@ RPT_DEV bool march_begin_shadow(const SceneSmallSdf& sc, PathRegs& p, v3 fhp, v3
     return true;
 }
 
+// ---- two rooms instead of three (render_sdf_march2_kernel) -------------------------------------------------------------
+// The shadow ray of next-event estimation is marched one bounce LATE, right before the next path ray, the way the wavefront
+// form of large scenes walks its shadow rays (dev_wavefront.h): SHADE computes the light sample's contribution as if the
+// light were visible and parks it; once the shadow march has answered, it is added — or not — before anything else touches
+// the radiance, so the additions and their order are the reference's.  A bounce is then ONE block (finish closest_hit,
+// shade, set up the next ray) between marches, not RESOLVE -> march -> SHADE: two waiting rooms for a 64-lane wave instead of
+// three, and next-event estimation is sampled once instead of twice (the three-room kernel replays it to find the shadow ray).
+struct SdfDeferredQuery {
+    SdfMarchResult r;          // the path ray's march
+    AnalyticPre a;
+    float4* sh_o;              // this lane's slots in LDS: shadow origin (w: max_dist), direction, the parked contribution
+    float4* sh_d;
+    float4* gain;
+    RPT_DEV bool geom(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) const
+    {
+        return closest_geom_small<true>(sc, &sc.sdf, ray, ps, g, e, &r, &a);
+    }
+    // any_hit_small<true> taken apart: the analytic primitives now, the SDF object's march later
+    RPT_DEV bool any(const SceneSmallSdf& sc, const RayD& shadow, float max_dist, v3 th, bool& pending) const
+    {
+        pending = false;
+        if (any_hit_analytic(sc, shadow, max_dist)) return true;
+        const bool finite = (__builtin_fabsf(th.x) < __builtin_inff()) && (__builtin_fabsf(th.y) < __builtin_inff()) &&
+                            (__builtin_fabsf(th.z) < __builtin_inff());
+        if (!finite) {
+            // "add nothing" and "add 0 x throughput" differ for this lane: answer on the spot (rare)
+            const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
+            float t;
+            const bool h = sdf_march(sc.sdf, shadow, sdf_shadow_t_useful(sc, max_dist), t);
+            return h && (!use_max || t < max_dist);
+        }
+        pending = true;
+        *sh_o = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, max_dist);
+        *sh_d = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, 0.0f);
+        return false;
+    }
+    RPT_DEV void park(v3 c) const { *gain = make_float4(c.x, c.y, c.z, 0.0f); }
+};
+
 }  // namespace rptdev

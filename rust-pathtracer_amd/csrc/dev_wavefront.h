@@ -40,7 +40,7 @@ struct WfBuffers {
     float4* sh_d;              //           direction; w: bits of "occluded" (written by WALK)
     float4* c_lit;             //           the parked next-event contribution
     float4* prev;              //           radiance of the pixel's previous sample while its last shadow ray is out (ctl.w bit 3)
-    uint4* ctl;                //           rng key, rng counter, bounce, sample << 8 | previous parked << 3 | shadow pending << 2 | status
+    uint4* ctl;                //           rng state, rng increment, bounce, sample << 8 | previous parked << 3 | shadow pending << 2 | status
     uint32_t* closest;         // [n_seg * 64] slots whose path ray needs a grid walk, per segment
     uint32_t* shadow;          // [n_seg * 64] slots whose shadow ray needs a grid walk
     uint32_t* cnt_closest;     // [n_seg] entries in each segment
@@ -125,6 +125,129 @@ RPT_DEV bool path_shade_deferred(const S& sc, PathRegs& p, const GeomHit& g, Sha
 {
     sr.pending = false;
     return path_shade_full(sc, DeferredQuery{&sr}, p, g);
+}
+
+// One cell of grid_closest_sphere / grid_any_sphere (dev_scene_large.h) for the ray a lane is walking; true: the walk is over.
+// The cell's list, four entries per trip: the loads go out together and the discriminants are computed branch-free.  A candidate
+// (the line meets the sphere: few) is parked — hit_sphere's tca and radius2 - d2 — and its square-root half runs once per cell for
+// all lanes that have one, not per entry for one lane in twenty.  Acceptance is order-independent (nearest t, lowest index on
+// ties; "any" for shadow rays), so neither batching nor parking changes the result.
+//   shadow walks: `occluded` is raised on a hit (within max_dist when the scene honours it); path walks: dist / best are updated.
+RPT_DEV bool walk_cell(const SceneLarge& sc, const RayD& ray, GridWalk& g, uint32_t& k0, uint32_t& k1, uint32_t& guard, bool shadow, bool use_max,
+                       float max_dist, float& dist, uint32_t& best, bool& occluded)
+{
+    const float t_exit = grid_cell_exit(g);
+    grid_step(sc, g);
+    uint32_t n0 = 0, n1 = 0;
+    if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), n0, n1);
+    bool done = false;
+    float c_tca0 = 0.0f, c_rd0 = 0.0f, c_tca1 = 0.0f, c_rd1 = 0.0f;
+    uint32_t c_k0 = 0u, c_k1 = 0u, nc = 0u;
+    auto resolve = [&](float tca, float rd, uint32_t kk) {              // hit_sphere's second half + acceptance
+        const float thc = __builtin_sqrtf(rd);
+        float t0 = tca - thc;
+        float t1 = tca + thc;
+        if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
+        bool ok = true;
+        if (t0 < 0.0f) {
+            t0 = t1;
+            if (t0 < 0.0f) ok = false;
+        }
+        if (ok) {
+            if (shadow) {
+                if (!use_max || t0 < max_dist) done = true;
+            } else {
+                const uint32_t idx = sc.cell_items[kk];
+                if (idx != 0u && (t0 < dist || (t0 == dist && idx < best))) { dist = t0; best = idx; }
+            }
+        }
+    };
+    for (uint32_t k = k0; k < k1; k += 4u) {
+        float4 sp[4];
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            sp[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (k + i < k1) sp[i] = sc.cell_spheres[k + i];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; ++i) {
+            const v3 l = mk3(sp[i].x, sp[i].y, sp[i].z) - ray.o;        // hit_sphere's first half
+            const float tca = dot3(l, ray.d);
+            const float d2 = dot3(l, l) - tca * tca;
+            const float radius2 = sp[i].w * sp[i].w;
+            const bool cand = (k + i < k1) && !(d2 > radius2);
+            const float rd = radius2 - d2;
+            if (cand) {
+                if (nc == 0u) { c_tca0 = tca; c_rd0 = rd; c_k0 = k + i; nc = 1u; }
+                else if (nc == 1u) { c_tca1 = tca; c_rd1 = rd; c_k1 = k + i; nc = 2u; }
+                else resolve(tca, rd, k + i);                           // a third candidate in one cell: at once
+            }
+        }
+    }
+    if (nc >= 1u) resolve(c_tca0, c_rd0, c_k0);
+    if (nc >= 2u) resolve(c_tca1, c_rd1, c_k1);
+    if (shadow) {
+        if (done) occluded = true;
+        done = done || (t_exit > g.t_end) || (use_max && t_exit > max_dist);
+    } else {
+        done = (best != 0xFFFFFFFFu && dist <= t_exit) || (t_exit > g.t_end);
+    }
+    guard -= 1u;
+    done = done || !g.alive || guard == 0u;
+    k0 = n0; k1 = n1;
+    return done;
+}
+
+// The two grid walks of a bounce in ONE loop of the wave (render_large_pair_kernel): every lane walks its parked shadow ray
+// (if it has one) and then its path ray (if it has one); a lane that finishes a walk waits until at most `refill_at` lanes are
+// still walking, then all idle lanes with a ray left set theirs up together.  Inside the megakernel a wave otherwise leaves each
+// walk when its LONGEST walk ends, shadow walks and path walks separately (19.5 % of the lanes active, profiles/r2/block_profile_c5.txt);
+// back to back in one loop the wave waits for the longest SUM, and idle lanes refill.
+//   shadow: in has_shadow / sh / sh_max, out occluded (by the grid walk; the planes, oversize spheres and the reach test were the caller's)
+//   path:   in has_path (closest_before_walk returned true), dist / best in-out
+RPT_DEV void grid_walk_pair(const SceneLarge& sc, bool has_shadow, const RayD& sh, float sh_max, bool& occluded, bool has_path, const RayD& path,
+                            float& dist, uint32_t& best, uint32_t refill_at)
+{
+    const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
+    occluded = false;
+    uint32_t next = has_shadow ? 0u : (has_path ? 1u : 2u);         // the lane's next ray: 0 shadow, 1 path, 2 none
+    bool has = false, shadow = false;
+    uint32_t k0 = 0, k1 = 0, guard = 0;
+    RayD ray{mk3(0.0f, 0.0f, 0.0f), mk3(0.0f, 0.0f, 0.0f)};
+    GridWalk g;
+    g.alive = false;
+    for (;;) {
+        uint32_t n_has = (uint32_t)__popcll(__ballot(has));
+        uint64_t m_more = __ballot(!has && next < 2u);
+        if (m_more != 0ull && n_has <= refill_at) {
+            RPT_PROF(PB_GRID_BEGIN);
+            if (!has && next < 2u) {
+                shadow = next == 0u;
+                ray = shadow ? sh : path;
+                next = (shadow && has_path) ? 1u : 2u;
+                g = grid_begin(sc, ray);
+                if (g.alive) {
+                    has = true;
+                    cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
+                    guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u;
+                }                                                   // else: the ray misses the grid, nothing to walk
+            }
+            m_more = __ballot(!has && next < 2u);
+        }
+        n_has = (uint32_t)__popcll(__ballot(has));
+        if (n_has == 0u) {
+            if (m_more == 0ull) break;
+            continue;                                               // rays that missed the grid: set up the lanes' next ones
+        }
+        do {
+            if (has) {
+                RPT_PROF(PB_GRID_CELL);
+                if (walk_cell(sc, ray, g, k0, k1, guard, shadow, use_max, sh_max, dist, best, occluded)) has = false;
+            }
+            n_has = (uint32_t)__popcll(__ballot(has));
+            m_more = __ballot(!has && next < 2u);
+        } while (n_has != 0u && (m_more == 0ull || n_has > refill_at));
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -213,74 +336,12 @@ RPT_DEV void wf_walk_body(const SceneLarge& sc, const WfBuffers& wb, uint32_t re
         do {
             if (has) {                                              // one cell of grid_closest_sphere / grid_any_sphere
                 RPT_PROF(PB_WF_CELL);
-                const float t_exit = grid_cell_exit(g);
-                grid_step(sc, g);
-                uint32_t n0 = 0, n1 = 0;
-                if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), n0, n1);
-                bool done = false;
-                // The cell's list, four entries per trip: the loads go out together and the discriminants are computed
-                // branch-free.  A candidate (the line meets the sphere: few) is parked — hit_sphere's tca and radius2 - d2 —
-                // and its square-root half runs once per cell for all lanes that have one, not per entry for one lane in
-                // twenty.  Acceptance is order-independent (nearest t, lowest index on ties; "any" for shadow rays), so
-                // neither batching nor parking changes the result.
-                float c_tca0 = 0.0f, c_rd0 = 0.0f, c_tca1 = 0.0f, c_rd1 = 0.0f;
-                uint32_t c_k0 = 0u, c_k1 = 0u, nc = 0u;
-                auto resolve = [&](float tca, float rd, uint32_t kk) {              // hit_sphere's second half + acceptance
-                    const float thc = __builtin_sqrtf(rd);
-                    float t0 = tca - thc;
-                    float t1 = tca + thc;
-                    if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
-                    bool ok = true;
-                    if (t0 < 0.0f) {
-                        t0 = t1;
-                        if (t0 < 0.0f) ok = false;
-                    }
-                    if (ok) {
-                        if (shadow) {
-                            if (!use_max || t0 < max_dist) done = true;
-                        } else {
-                            const uint32_t idx = sc.cell_items[kk];
-                            if (idx != 0u && (t0 < dist || (t0 == dist && idx < best))) { dist = t0; best = idx; }
-                        }
-                    }
-                };
-                for (uint32_t k = k0; k < k1; k += 4u) {
-                    float4 sp[4];
-#pragma unroll
-                    for (uint32_t i = 0; i < 4u; ++i) {
-                        sp[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        if (k + i < k1) sp[i] = sc.cell_spheres[k + i];
-                    }
-#pragma unroll
-                    for (uint32_t i = 0; i < 4u; ++i) {
-                        const v3 l = mk3(sp[i].x, sp[i].y, sp[i].z) - ray.o;        // hit_sphere's first half
-                        const float tca = dot3(l, ray.d);
-                        const float d2 = dot3(l, l) - tca * tca;
-                        const float radius2 = sp[i].w * sp[i].w;
-                        const bool cand = (k + i < k1) && !(d2 > radius2);
-                        const float rd = radius2 - d2;
-                        if (cand) {
-                            if (nc == 0u) { c_tca0 = tca; c_rd0 = rd; c_k0 = k + i; nc = 1u; }
-                            else if (nc == 1u) { c_tca1 = tca; c_rd1 = rd; c_k1 = k + i; nc = 2u; }
-                            else resolve(tca, rd, k + i);                           // a third candidate in one cell: at once
-                        }
-                    }
-                }
-                if (nc >= 1u) resolve(c_tca0, c_rd0, c_k0);
-                if (nc >= 2u) resolve(c_tca1, c_rd1, c_k1);
-                if (shadow) {
-                    if (done) wb.sh_d[slot].w = rpt_u2f(1u);        // occluded
-                    done = done || (t_exit > g.t_end) || (use_max && t_exit > max_dist);
-                } else {
-                    done = (best != 0xFFFFFFFFu && dist <= t_exit) || (t_exit > g.t_end);
-                }
-                guard -= 1u;
-                done = done || !g.alive || guard == 0u;
-                if (done) {
+                bool occluded = false;
+                if (walk_cell(sc, ray, g, k0, k1, guard, shadow, use_max, max_dist, dist, best, occluded)) {
                     if (!shadow) { wb.ray_o[slot].w = dist; wb.ray_d[slot].w = rpt_u2f(best); }
                     has = false;
                 }
-                k0 = n0; k1 = n1;
+                if (occluded) wb.sh_d[slot].w = rpt_u2f(1u);
             }
             n_has = (uint32_t)__popcll(__ballot(has));
         } while (n_has != 0u && (exhausted || n_has > refill_at));

@@ -109,7 +109,7 @@ RPT_DEV void render_nested_body(const S& sc, const RenderParams& rp)
     float4 acc = *pix;
     for (uint32_t s = 0; s < rp.spp; ++s) {
         const uint64_t frames = rp.frames_done + s;
-        const uint32_t fkey = frame_key_hd(rp.seed, frames);
+        const FrameKey fkey = frame_key_hd(rp.seed, frames);
         const float v = 1.0f / (float)(frames + 1);                 // tracer.rs:115
         const v3 rad = trace_sample(sc, ps.px, ps.py, fkey, ps.pixel_index);
         blend(acc, rad, v);
@@ -155,10 +155,10 @@ constexpr uint32_t kMaxSppPerLaunch = 512;
 // sample ends (once per ~2 bounces); in VGPRs the seven registers they would pin are what separates 4 from 5
 // resident waves per SIMD.
 struct LaneTables {
-    uint32_t* fkey;            // [kMaxSppPerLaunch] frame_key(seed, frames_done + s)
+    FrameKey* fkey;            // [kMaxSppPerLaunch] frame_key(seed, frames_done + s)
     float* weight;             // [kMaxSppPerLaunch] 1 / (frames_done + s + 1), tracer.rs:115
     float4* acc;               // [256] running mean, tracer.rs:105-117
-    float4* pix;               // [256] {coord.x, coord.y, bits(pcg_hash(pixel_index)), -}
+    float4* pix;               // [256] {coord.x, coord.y, bits(a), bits(b)}: a = pcg_hash(pixel_index), b = pcg_hash(a) (Rng::init)
 };
 
 // Fills the tables and this lane's slots.  False: the lane has no pixel, or the scene has max_depth == 0 (no bounce
@@ -185,17 +185,25 @@ RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderPa
     if (!ps.valid) return false;
     float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
     lt.acc[threadIdx.x] = *pixel;
-    lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(pcg_hash(ps.pixel_index)), 0.0f);
+    const uint32_t pix_a = pcg_hash(ps.pixel_index);
+    lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(pix_a), rpt_u2f(pcg_hash(pix_a)));
     return true;
 }
 
-enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u };
+enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u, ST_MISS = 4u };
 
+// Three blocks, two waiting rooms.  TRACE (closest_hit's geometry pass + the emitter exit) runs at once for every lane that has a
+// ray; afterwards each live lane waits in one of two rooms: SHADE (a surface was hit) or FINISH (the path is over: the
+// background of a miss still to be added, blend into the pixel's running mean, the pixel's next camera path).  Per pass the wave
+// runs ONE room: SHADE when `shade_threshold` lanes wait there; otherwise FINISH when `finish_threshold` lanes wait there;
+// otherwise the fuller of the two (nobody can trace while both wait).  Round 2 ran FINISH un-voted at the top of every pass,
+// with 34 % of the lanes, and the background inside TRACE with 46 % (profiles/r2/block_profile_c2.txt); replayed over the oracle's
+// path events (tools/sched_sim2.py, sim_finish_room) thresholds 56 / 24 cost 5 % less than that.
 template <class S>
 RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
 {
     RPT_PROF_INIT();
-    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
+    __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
@@ -209,7 +217,71 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     g.code = 0u;
     {
         const float4 c = s_pix[tid];
-        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
+    }
+
+    for (;;) {
+        RPT_PROF(PB_PASS);
+        if (state == ST_TRACE) {
+            RPT_PROF(PB_TRACE);
+            const uint32_t what = path_trace_geom_split(sc, DirectQuery{}, p, g);
+            state = (what == 2u) ? ST_SHADE : ((what == 0u) ? ST_MISS : ST_FINISH);
+        }
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == ST_SHADE));
+        const uint32_t n_fin = (uint32_t)__popcll(__ballot(state >= ST_FINISH));
+        if ((n_shade | n_fin) == 0u) break;
+        if (n_shade >= rp.shade_threshold || (n_fin < rp.finish_threshold && n_shade >= n_fin)) {
+            if (state == ST_SHADE) {
+                RPT_PROF(PB_SHADE);
+                state = path_shade_full(sc, DirectQuery{}, p, g) ? ST_FINISH : ST_TRACE;
+            }
+        } else if (state >= ST_FINISH) {
+            // one site for the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
+            if (state == ST_MISS) {
+                RPT_PROF(PB_BACKGROUND);
+                p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
+            }
+            RPT_PROF(PB_FINISH);
+            float4 acc = s_acc[tid];
+            blend(acc, p.radiance, s_weight[s]);
+            s_acc[tid] = acc;
+            s += 1;
+            if (s >= rp.spp) {
+                state = ST_DONE;
+            } else {
+                const float4 c = s_pix[tid];
+                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
+                state = ST_TRACE;
+            }
+        }
+    }
+    RPT_PROF_FLUSH();
+    *pixel_address_again(rp) = s_acc[tid];
+}
+
+// The same kernel with FINISH un-voted at the top of every pass and the background inside TRACE (round 2's schedule): what large
+// scenes and the inline-march SDF form keep — there TRACE carries the grid walks / sphere marches, a lane parked in a finishing room
+// is a lane that does not walk, and the three-room loop above measured 2-4 % SLOWER (10 k spheres, 2048^2 x 32 spp: 1 675 vs
+// 1 611-1 648 Msamples/s at finishing thresholds 1-64; profiles/r3/experiments/).
+template <class S>
+RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& rp)
+{
+    RPT_PROF_INIT();
+    __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
+    __shared__ float s_weight[kMaxSppPerLaunch];
+    __shared__ float4 s_acc[256];
+    __shared__ float4 s_pix[256];
+    const uint32_t tid = threadIdx.x;
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+
+    uint32_t s = 0;
+    uint32_t state = ST_TRACE;
+    PathRegs p;
+    GeomHit g;                                                      // what a lane waiting for SHADE parks: one dword
+    g.code = 0u;
+    {
+        const float4 c = s_pix[tid];
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
     }
 
     for (;;) {
@@ -226,7 +298,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
                 state = ST_DONE;
             } else {
                 const float4 c = s_pix[tid];
-                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
                 state = ST_TRACE;
             }
         }
@@ -271,13 +343,17 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 #ifndef RPT_LARGE_WAVES_PER_SIMD
 #define RPT_LARGE_WAVES_PER_SIMD 6
 #endif
-__global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
 #ifndef RPT_NO_MEDIA_KERNELS
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_regen_body(sc, rp); }
-__global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_regen_body(sc, rp); }
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_regen_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
+#endif
+
+#ifdef RPT_AB_KERNELS
+#include "ab/kernel_large_pair.h"
 #endif
 
 // Large scenes as a wavefront (dev_wavefront.h): WALK(k) walks the rays SHADE(k-1) listed, SHADE(k) does the rest of the bounce
@@ -315,7 +391,7 @@ enum : uint32_t { WFF_PENDING = 4u, WFF_PARK = 8u, WFF_NEWRAY = 16u, WFF_MISS = 
 
 struct WfRecords {
     float f[14][256];          // ray o, d; throughput; radiance; hit_dist; scatter pdf
-    uint32_t u[5][256];        // rng key, counter; bounce; GeomHit; sample << 8 | flags | status
+    uint32_t u[5][256];        // rng state, increment; bounce; GeomHit; sample << 8 | flags | status
 };
 
 // PathRegs.bounce and .medium share a dword wherever a path is stored (bounce <= 4096, medium < 2^16); kernels without media
@@ -337,7 +413,7 @@ RPT_DEV void wf_rec_put(WfRecords& r, uint32_t i, const PathRegs& p, uint32_t gc
     r.f[6][i] = p.throughput.x; r.f[7][i] = p.throughput.y; r.f[8][i] = p.throughput.z;
     r.f[9][i] = p.radiance.x; r.f[10][i] = p.radiance.y; r.f[11][i] = p.radiance.z;
     r.f[12][i] = p.ps.hit_dist; r.f[13][i] = p.ps.scatter_pdf;
-    r.u[0][i] = p.rng.key; r.u[1][i] = p.rng.counter; r.u[2][i] = pack_bounce<MEDIA>(p); r.u[3][i] = gcode; r.u[4][i] = ctl;
+    r.u[0][i] = p.rng.state; r.u[1][i] = p.rng.inc; r.u[2][i] = pack_bounce<MEDIA>(p); r.u[3][i] = gcode; r.u[4][i] = ctl;
 }
 
 template <bool MEDIA = false>
@@ -348,7 +424,7 @@ RPT_DEV void wf_rec_get(const WfRecords& r, uint32_t i, PathRegs& p, uint32_t& g
     p.throughput = mk3(r.f[6][i], r.f[7][i], r.f[8][i]);
     p.radiance = mk3(r.f[9][i], r.f[10][i], r.f[11][i]);
     p.ps.hit_dist = r.f[12][i]; p.ps.scatter_pdf = r.f[13][i];
-    p.rng.key = r.u[0][i]; p.rng.counter = r.u[1][i]; unpack_bounce<MEDIA>(r.u[2][i], p); gcode = r.u[3][i]; ctl = r.u[4][i];
+    p.rng.state = r.u[0][i]; p.rng.inc = r.u[1][i]; unpack_bounce<MEDIA>(r.u[2][i], p); gcode = r.u[3][i]; ctl = r.u[4][i];
 }
 
 // append `value` to a workgroup list in LDS for the lanes that `want` (one LDS atomic per wave)
@@ -396,7 +472,7 @@ RPT_DEV void wf_shade_body(const S& sc, const RenderParams& rp, const WfBuffers&
             if (first) {
                 p.ray.o = p.ray.d = p.throughput = p.radiance = mk3(0.0f, 0.0f, 0.0f);
                 p.ps.hit_dist = 0.0f; p.ps.scatter_pdf = 0.0f;
-                p.rng.key = 0u; p.rng.counter = 0u; p.bounce = 0u; p.medium = 0u;
+                p.rng.state = 0u; p.rng.inc = 1u; p.bounce = 0u; p.medium = 0u;
                 ctl = WF_WALKING;                                   // sample 0, nothing to blend: F starts its camera path
                 to_fin = true;
             } else {
@@ -404,7 +480,7 @@ RPT_DEV void wf_shade_body(const S& sc, const RenderParams& rp, const WfBuffers&
                 p.ray.o = mk3(a.x, a.y, a.z); p.ray.d = mk3(b.x, b.y, b.z);
                 p.throughput = mk3(t.x, t.y, t.z); p.ps.hit_dist = t.w;
                 p.radiance = mk3(r.x, r.y, r.z); p.ps.scatter_pdf = r.w;
-                p.rng.key = c.x; p.rng.counter = c.y; unpack_bounce<M>(c.z, p);
+                p.rng.state = c.x; p.rng.inc = c.y; unpack_bounce<M>(c.z, p);
                 const uint32_t s = c.w >> 8;
                 const uint32_t status = c.w & 3u;
                 // last bounce's light sample: visible unless its walk found an occluder
@@ -526,7 +602,7 @@ RPT_DEV void wf_shade_body(const S& sc, const RenderParams& rp, const WfBuffers&
         bool walk_closest = false;
         if (ctl & WFF_NEWRAY) walk_closest = closest_before_walk(sc, p.ray, dist, best);
         keep = (ctl & 3u) != WF_DONE;
-        wb.ctl[slot] = make_uint4(p.rng.key, p.rng.counter, pack_bounce<M>(p), ctl & ~(WFF_NEWRAY | WFF_MISS | WFF_BLEND));
+        wb.ctl[slot] = make_uint4(p.rng.state, p.rng.inc, pack_bounce<M>(p), ctl & ~(WFF_NEWRAY | WFF_MISS | WFF_BLEND));
         if (keep) {
             wb.ray_o[slot] = make_float4(p.ray.o.x, p.ray.o.y, p.ray.o.z, dist);
             wb.ray_d[slot] = make_float4(p.ray.d.x, p.ray.d.y, p.ray.d.z, rpt_u2f(best));
@@ -705,7 +781,7 @@ template <class S>
 RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& rp)
 {
     RPT_PROF_INIT();
-    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
+    __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
@@ -722,7 +798,7 @@ RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& rp)
     MarchRegs m;
     {
         const float4 c = s_pix[tid];
-        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
         march_begin_primary(sc, p, m);
     }
 
@@ -738,7 +814,7 @@ RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& rp)
                 state = SM_DONE;
             } else {
                 const float4 c = s_pix[tid];
-                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
                 march_begin_primary(sc, p, m);
                 state = SM_MARCH_P;
             }
@@ -806,6 +882,140 @@ __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
 #endif
 
+// SDF scenes, two rooms (dev_sdf_path.h, SdfDeferredQuery).  Per lane:
+//   [MARCH_S: the parked shadow ray of the bounce just shaded] -> MARCH_P: the path ray -> WAIT -> one block: add the parked light
+//   sample if its ray got through; finish closest_hit; miss / emitter / path over -> blend, the pixel's next sample; surface ->
+//   material, light sample (parked), BSDF, next ray -> the marches again.
+// Per wave each pass either marches (while at least `march_min_lanes` lanes are marching, or nobody waits) or runs the block
+// for the lanes that wait.
+enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u };
+
+template <class S>
+RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
+{
+    RPT_PROF_INIT();
+    __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
+    __shared__ float s_weight[kMaxSppPerLaunch];
+    __shared__ float4 s_acc[256];
+    __shared__ float4 s_pix[256];
+    __shared__ float4 s_sho[256], s_shd[256], s_gain[256];          // the parked shadow ray and light sample of each lane
+    const uint32_t tid = threadIdx.x;
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+
+    uint32_t s = 0;
+    uint32_t state = S2_MARCH_P;
+    PathRegs p;
+    MarchRegs m;
+    v3 mo;                                                          // origin of the march in flight
+    bool pending = false;                                           // a light sample is parked, its shadow ray not answered yet
+    bool lit = false;                                               // ... answered: it got through
+    bool ending = false;                                            // the path is over once the parked sample is resolved
+    float np_tu = 0.0f;                                             // the path ray's march while the shadow ray is marched first:
+    uint32_t np_acc = 0u;                                           // t_useful and the accepted analytic primitives
+    {
+        const float4 c = s_pix[tid];
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
+        march_begin_primary(sc, p, m);
+        mo = p.ray.o;
+    }
+    const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
+
+    for (;;) {
+        RPT_PROF(PB_PASS);
+        const uint32_t n_march = (uint32_t)__popcll(__ballot(state <= S2_MARCH_P));
+        const uint32_t n_wait = (uint32_t)__popcll(__ballot(state == S2_WAIT));
+        if (n_march == 0u && n_wait == 0u) break;
+        if (n_march >= rp.march_min_lanes || n_wait == 0u) {
+            for (;;) {
+                if (state <= S2_MARCH_P) {
+                    RPT_PROF(PB_CLOSEST);                           // (block profile: one march step of the wave)
+                    if (march_step(sc.sdf, mo, m)) {
+                        if (state == S2_MARCH_S) {
+                            lit = !(m.hit && (!use_max || m.t < s_sho[tid].w));      // any_hit_small's SDF term
+                            if (ending) state = S2_WAIT;
+                            else {
+                                // the path ray's march, prepared by the block (march_begin_primary's analytic part is ~400
+                                // instructions: it must not run here, for the one lane of the wave whose shadow march just ended)
+                                march_begin(m, p.ray.d, np_tu);
+                                m.accepted = np_acc;
+                                mo = p.ray.o;
+                                state = S2_MARCH_P;
+                            }
+                        } else {
+                            state = S2_WAIT;
+                        }
+                    }
+                }
+                const uint32_t left = (uint32_t)__popcll(__ballot(state <= S2_MARCH_P));
+                if (left == 0u || left < rp.march_min_lanes) break;
+            }
+        } else if (state == S2_WAIT) {
+            RPT_PROF(PB_SHADE);
+            if (pending) {                                          // last bounce's light sample: visible unless its march hit the object
+                if (lit) { const float4 gn = s_gain[tid]; p.radiance = p.radiance + mk3(gn.x, gn.y, gn.z); }
+                pending = false;
+            }
+            bool over = ending;
+            ending = false;
+            if (!over) {
+                GeomHit g;
+                g.code = 0u;
+                const SdfDeferredQuery q{{m.hit, m.t}, march_analytic(m), &s_sho[tid], &s_shd[tid], &s_gain[tid]};
+                const uint32_t what = path_trace_geom_split(sc, q, p, g);
+                if (what == 0u) { p.radiance = p.radiance + background(sc, p.ray) * p.throughput; over = true; }
+                else if (what == 1u) over = true;
+                else {
+                    // (pending comes back through the parked ray: the query marks it in the slot's direction.w)
+                    s_shd[tid].w = 1.0f;
+                    over = path_shade_full(sc, q, p, g);
+                    pending = s_shd[tid].w == 0.0f;
+                }
+            }
+            // what comes next for this lane: [the parked shadow ray] then the path's ray (or the end of the path)
+            bool new_ray = !over;
+            ending = pending && over;
+            if (over && !pending) {                                 // blend, next sample of the pixel (or retire)
+                RPT_PROF(PB_FINISH);
+                float4 acc = s_acc[tid];
+                blend(acc, p.radiance, s_weight[s]);
+                s_acc[tid] = acc;
+                s += 1;
+                if (s >= rp.spp) {
+                    state = S2_DONE;
+                } else {
+                    const float4 c = s_pix[tid];
+                    path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
+                    new_ray = true;
+                }
+            }
+            if (new_ray) {                                          // march_begin_primary's analytic part, once, for every lane of the block
+                AnalyticHit ah;
+                analytic_closest(sc, p.ray, ah);
+                np_tu = sdf_primary_t_useful(sc, ah);
+                np_acc = ah.accepted;
+            }
+            if (pending) {
+                const float4 so = s_sho[tid], sd = s_shd[tid];
+                mo = mk3(so.x, so.y, so.z);
+                march_begin(m, mk3(sd.x, sd.y, sd.z), sdf_shadow_t_useful(sc, so.w));
+                state = S2_MARCH_S;
+            } else if (new_ray) {
+                march_begin(m, p.ray.d, np_tu);
+                m.accepted = np_acc;
+                mo = p.ray.o;
+                state = S2_MARCH_P;
+            }
+        }
+    }
+    RPT_PROF_FLUSH();
+    *pixel_address_again(rp) = s_acc[tid];
+}
+
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body(sc, rp); }
+#ifndef RPT_NO_MEDIA_KERNELS
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march2_body(sc, rp); }
+#endif
+
 #ifdef RPT_AB_KERNELS
 // SDF scenes, workgroup-wide march pool (dev_sdf_pool.h): the lane states are those of the march kernel above, but a
 // lane in MARCH_P / MARCH_S has SUBMITTED its march and only polls for the answer; the marching itself is done by
@@ -814,7 +1024,7 @@ __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_
 RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& rp)
 {
     RPT_PROF_INIT();
-    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
+    __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
@@ -835,7 +1045,7 @@ RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& r
     uint32_t patience = 0;
     {
         const float4 c = s_pix[tid];
-        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
         pool_begin_primary(pool, sc, p, m);
     }
 
@@ -853,7 +1063,7 @@ RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& r
                 state = SM_DONE;
             } else {
                 const float4 c = s_pix[tid];
-                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
                 pool_begin_primary(pool, sc, p, m);
                 state = SM_MARCH_P;
             }
@@ -1073,15 +1283,15 @@ __global__ __launch_bounds__(256) void RPT_K(probe_fn_kernel)(uint32_t fn, const
         const DevLight L{rpt_f2u(r[0]), r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11], r[12], r[13], r[14]};
         const ProbeLightScene sc{r[18], rpt_f2u(r[19])};
         Rng rng;
-        rng.init(rpt_f2u(r[20]), rpt_f2u(r[21]));
-        rng.counter = rpt_f2u(r[22]);
-        const uint32_t c0 = rng.counter;
+        rng.state = rpt_f2u(r[20]);
+        rng.inc = rpt_f2u(r[21]) | 1u;
+        const Rng rng0 = rng;
         LightSample ls;
         sample_light(sc, L, mk3(r[15], r[16], r[17]), ls, rng);
         o[0] = ls.normal.x; o[1] = ls.normal.y; o[2] = ls.normal.z;
         o[3] = ls.emission.x; o[4] = ls.emission.y; o[5] = ls.emission.z;
         o[6] = ls.direction.x; o[7] = ls.direction.y; o[8] = ls.direction.z;
-        o[9] = ls.dist; o[10] = ls.pdf; o[11] = (float)(rng.counter - c0);
+        o[9] = ls.dist; o[10] = ls.pdf; o[11] = (float)rng_draws_between(rng0, rng);
         break;
     }
     case RPT_PROBE_FN_DISNEY_EVAL: {
@@ -1102,13 +1312,13 @@ __global__ __launch_bounds__(256) void RPT_K(probe_fn_kernel)(uint32_t fn, const
         const v3 v = mk3(r[18], r[19], r[20]), nn = mk3(r[21], r[22], r[23]);
         v3 l = mk3(r[24], r[25], r[26]);
         Rng rng;
-        rng.init(rpt_f2u(r[27]), rpt_f2u(r[28]));
-        rng.counter = rpt_f2u(r[29]);
-        const uint32_t c0 = rng.counter;
+        rng.state = rpt_f2u(r[27]);
+        rng.inc = rpt_f2u(r[28]) | 1u;
+        const Rng rng0 = rng;
         const ShadeFrame fr = make_frame(m, eta, v, nn);
         float pdf;
         const v3 f = disney_sample(m, eta, fr, nn, l, pdf, rng);
-        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = l.x; o[4] = l.y; o[5] = l.z; o[6] = pdf; o[7] = (float)(rng.counter - c0);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = l.x; o[4] = l.y; o[5] = l.z; o[6] = pdf; o[7] = (float)rng_draws_between(rng0, rng);
         break;
     }
     default: break;
@@ -1168,6 +1378,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
         if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_media_kernel), tiles, wg, 0, st, mscl, rp);
         else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_media_kernel), tiles, wg, 0, st, mscl, rp);
         else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_media_kernel), tiles, wg, 0, st, mscs, rp);
+        else if (has_sdf && rp.sdf_resumable_march == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, mscs, rp);
         else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_media_kernel), tiles, wg, 0, st, mscs, rp);
         else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_media_kernel), tiles, wg, 0, st, mscs, rp);
         else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_media_kernel), tiles, wg, 0, st, msc, rp);
@@ -1179,6 +1390,9 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #endif
     }
     if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), tiles, wg, 0, st, scl, rp);
+#ifdef RPT_AB_KERNELS
+    else if (large && rp.large_pair_walk && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_pair_kernel), tiles, wg, 0, st, scl, rp);
+#endif
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), tiles, wg, 0, st, scl, rp);
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), tiles, wg, 0, st, scs, rp);
 #ifdef RPT_AB_KERNELS
@@ -1187,6 +1401,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #ifdef RPT_AB_KERNELS
     else if (has_sdf && rp.sdf_resumable_march == 3u && scs_dev) hipLaunchKernelGGL(RPT_K(render_sdf_compact_kernel), tiles, wg, 0, st, scs_dev, rp);
 #endif
+    else if (has_sdf && rp.sdf_resumable_march == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_kernel), tiles, wg, 0, st, scs, rp);
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), tiles, wg, 0, st, scs, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), tiles, wg, 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);

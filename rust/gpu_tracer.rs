@@ -80,6 +80,7 @@ pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x40;
 pub const RPT_RENDER_LARGE_MEGAKERNEL: u32 = 0x80;
 pub const RPT_RENDER_SMALL_COMPACT: u32 = 0x100;
 pub const RPT_RENDER_SDF_COMPACT: u32 = 0x200;
+pub const RPT_RENDER_SDF_THREE_ROOM_MARCH: u32 = 0x400;
 
 impl RptSceneDesc {
     /// All zeros (no primitives, no SDF object): the starting point of every `describe()`.

@@ -93,7 +93,8 @@ def test_sdf_object_full_of_fog_matches_oracle_in_every_sdf_form(rpt, oracle):
     s.materials[1] = rpt.Material(rgb=(1.0, 0.6, 0.3), roughness=0.1, spec_trans=1.0, ior=1.4, medium=dict(type="absorb", density=2.0, color=(1.0, 0.4, 0.1)))
     w, h, spp = 80, 60, 3
     want = oracle.render(s.describe(), w, h, spp, seed=4)
-    for name, flags in (("march kernel", 0), ("inline march", A.RPT_RENDER_SDF_INLINE_MARCH), ("nested loops", A.RPT_RENDER_NESTED_LOOPS)):
+    for name, flags in (("march kernel (two rooms)", 0), ("march kernel (three rooms)", A.RPT_RENDER_SDF_THREE_ROOM_MARCH),
+                        ("inline march", A.RPT_RENDER_SDF_INLINE_MARCH), ("nested loops", A.RPT_RENDER_NESTED_LOOPS)):
         t = rpt.Tracer(s, device=0, seed=4)
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)

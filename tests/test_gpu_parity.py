@@ -361,7 +361,7 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
         s.any_hit_uses_max_dist = use_max
         t = rpt.Tracer(s, device=0, seed=9)
         want = oracle.render(s.describe(), w, h, spp, seed=9)
-        for flags in (0, rpt._abi.RPT_RENDER_SDF_INLINE_MARCH, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+        for flags in (0, rpt._abi.RPT_RENDER_SDF_THREE_ROOM_MARCH, rpt._abi.RPT_RENDER_SDF_INLINE_MARCH, rpt._abi.RPT_RENDER_NESTED_LOOPS):
             t.flags = flags
             buf = rpt.ColorBuffer(w, h)
             t.render_n(buf, spp)
@@ -607,7 +607,7 @@ def test_random_sdf_scenes_match_oracle(rpt, oracle, seed):
     w, h, spp = int(rng.integers(8, 90)), int(rng.integers(8, 60)), int(rng.integers(1, 4))
     want = oracle.render(s.describe(), w, h, spp, seed=seed)
     t = rpt.Tracer(s, device=0, seed=seed)
-    for flags in (0, A.RPT_RENDER_SDF_INLINE_MARCH, A.RPT_RENDER_NESTED_LOOPS):
+    for flags in (0, A.RPT_RENDER_SDF_THREE_ROOM_MARCH, A.RPT_RENDER_SDF_INLINE_MARCH, A.RPT_RENDER_NESTED_LOOPS):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)

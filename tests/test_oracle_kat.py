@@ -196,9 +196,42 @@ def test_rng_golden_and_float_conversion(oracle):
         state = (v * 747796405 + 2891336453) & 0xFFFFFFFF
         word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
         return ((word >> 22) ^ word) & 0xFFFFFFFF
-    k = pcg(0); k = pcg(k ^ 1); k = pcg(k ^ 0); k = pcg(k ^ 0)             # frame_key(seed=1, frame=0)
-    key = pcg(pcg(0) ^ k)                                                 # pixel 0
-    assert int(got[0]) == pcg(key) and int(got[5]) == pcg((key + 5) & 0xFFFFFFFF)
+    k = pcg(0); k = pcg(k ^ 1); k = pcg(k ^ 0); k0 = pcg(k ^ 0)            # frame_key(seed=1, frame=0): two folds
+    j = pcg(0 ^ 0x85EBCA6B); j = pcg(j ^ 1); j = pcg(j ^ 0); k1 = pcg(j ^ 0)
+    a = pcg(0); b = pcg(a)                                                # pixel 0
+    state, inc = pcg(a ^ k0), pcg(b ^ k1) | 1
+    # PCG-RXS-M-XS-32 with the path's own increment: an LCG step, then the output permutation
+    def step(st):
+        st = (st * 747796405 + inc) & 0xFFFFFFFF
+        word = (((st >> ((st >> 28) + 4)) ^ st) * 277803737) & 0xFFFFFFFF
+        return st, ((word >> 22) ^ word) & 0xFFFFFFFF
+    for i in range(16):
+        state, out = step(state)
+        assert int(got[i]) == out, i
+
+
+def test_rng_streams_of_neighbouring_paths_do_not_overlap(oracle):
+    """Round 2's generator drew pcg_hash(key + counter): two paths whose 32-bit keys differed by less than a path's ~40 draws read
+    overlapping windows of ONE sequence (about 5e-8 of all path pairs; ~1e10 pairs per full-HD frame).  Per-path streams
+    share draws only when state AND increment coincide.  Over 200 000 paths x 48 draws — the pixels of a frame, consecutive
+    frames, two seeds — no 4-draw window of one path may show up in another."""
+    seen = {}
+    clashes = 0
+    paths = [(seed, frame, pixel) for seed in (1, 2) for frame in range(20) for pixel in range(5000)]
+    for seed, frame, pixel in paths:
+        d = oracle.rng_u32(seed, frame, pixel, 48)
+        key = (int(d[8]), int(d[9]), int(d[10]), int(d[11]))                # one window in the middle of the stream ...
+        seen[key] = (seed, frame, pixel)
+    for seed, frame, pixel in paths[::7]:
+        d = oracle.rng_u32(seed, frame, pixel, 48)
+        for o in range(0, 44):                                              # ... looked for at every offset of every 7th path
+            if o == 8:
+                continue
+            k = (int(d[o]), int(d[o + 1]), int(d[o + 2]), int(d[o + 3]))
+            if k in seen and seen[k] != (seed, frame, pixel):
+                clashes += 1
+    assert clashes == 0
+    assert len(seen) == len(paths)
 
 
 @pytest.mark.parametrize("name", ["analytical_64x48_spp4_seed1", "analytical_32x24_spp16_seed7"])

@@ -1,0 +1,28 @@
+"""One-line timings for A/B runs of library variants (RPT_LIB) and knobs (RPT_* environment): which = c2 | c2s (32 spp) | c4 | c5 (2048^2 x 32,
+megakernel) | c5w (2048^2 x 8, wavefront).   python tools/ab_time.py c2 [reps]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import conftest, torch
+rpt = conftest.load_package()
+from rust_pathtracer_amd import scenes
+which = sys.argv[1] if len(sys.argv) > 1 else "c2"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+A = rpt._abi
+cfg = {"c2": (rpt.AnalyticalScene, 1920, 1080, 256, 0), "c2s": (rpt.AnalyticalScene, 1920, 1080, 32, 0), "c4": (scenes.sdf_scene, 1920, 1080, 64, 0),
+       "c5": (lambda: scenes.random_spheres_scene(10000, 16), 2048, 2048, 32, A.RPT_RENDER_LARGE_MEGAKERNEL),
+       "c5w": (lambda: scenes.random_spheres_scene(10000, 16), 2048, 2048, 8, A.RPT_RENDER_LARGE_WAVEFRONT)}[which]
+t = rpt.Tracer(cfg[0](), device=0, seed=1)
+t.flags = cfg[4]
+w, h, spp = cfg[1:4]
+buf = rpt.DeviceColorBuffer(w, h)
+t.render_n(buf, spp); torch.cuda.synchronize()
+ms = []
+for _ in range(reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); t.render_n(buf, spp); e1.record(); e1.synchronize()
+    ms.append(e0.elapsed_time(e1))
+best = min(ms)
+import hashlib
+digest = hashlib.sha1(buf.pixels.cpu().numpy().tobytes()).hexdigest()[:10]
+print("%-4s %dx%d x %3d spp: best %.3f ms (median %.3f) -> %8.1f Msamples/s  image %s  [%s]" % (which, w, h, spp, best, sorted(ms)[len(ms) // 2], w * h * spp / best / 1e3, digest,
+      " ".join("%s=%s" % (k, os.path.basename(v)) for k, v in sorted(os.environ.items()) if k.startswith("RPT_"))), flush=True)

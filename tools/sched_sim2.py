@@ -114,6 +114,50 @@ def sim_rooms(pixels, variant, thr=56, thr2=40):
     return T
 
 
+def sim_finish_room(pixels, thr=56, thr_f=40):
+    """TRACE | SHADE | FINISH: a path that ends (miss: background still to be added; emitter; pdf <= 0; depth) waits in a third
+    room; background + blend + the pixel's next camera path run when thr_f lanes wait there, or nobody can trace and it is the
+    fuller room (round 3: the verdict's "vote-defer FINISH the way SHADE is deferred")."""
+    T = T2()
+    n = len(pixels)
+    si = [0] * n; bi = [0] * n
+    st = ["T"] * n
+    def cur(l): return pixels[l][si[l]][bi[l]]
+    while True:
+        tr = [l for l in range(n) if st[l] == "T"]
+        if tr:
+            T.run("closest", len(tr))
+            for l in tr:
+                k = cur(l)[0]
+                st[l] = "H" if k == "H" else ("B" if k == "M" else "F")
+        T.run("vote", 64)
+        go = [l for l in range(n) if st[l] == "T"]
+        h = [l for l in range(n) if st[l] == "H"]
+        f = [l for l in range(n) if st[l] in "BF"]
+        if not go and not h and not f:
+            break
+        # after TRACE every live lane waits in one of the two rooms: SHADE at its threshold, else FINISH at its own, else the fuller
+        run_shade = len(h) >= thr or (len(f) < thr_f and len(h) >= len(f))
+        if run_shade and h:
+            T.run("surface", len(h)); T.run("frame", len(h)); T.run("nee", len(h))
+            T.run("anyhit", sum(1 for l in h if cur(l)[1] in "sv"))
+            T.run("eval", sum(1 for l in h if cur(l)[1] == "v"))
+            T.run("evalcc", sum(1 for l in h if cur(l)[1] == "v" and cur(l)[4]))
+            T.run("rest", len(h)); T.run("common", len(h))
+            for a in "DCS": T.run(a, sum(1 for l in h if cur(l)[2] == a))
+            for l in h:
+                if cur(l)[3]: st[l] = "F"
+                else:
+                    bi[l] += 1; st[l] = "T"
+        else:
+            T.run("background", sum(1 for l in f if st[l] == "B"))
+            T.run("finish", len(f))
+            for l in f:
+                si[l] += 1; bi[l] = 0
+                st[l] = "T" if si[l] < len(pixels[l]) else "X"
+    return T
+
+
 def sim_two_rooms_k(pixels, k, thr=56, swap_cost=0.6):
     """The shipped two rooms, but every lane owns k pixels (= k paths): one path in the working registers, the others
     parked (a parked path is its PathRegs + one dword: 18 VGPRs).  In a pass a lane takes part with any one of its paths
@@ -173,6 +217,8 @@ if __name__ == "__main__":
     rng = np.random.default_rng(5)
     tiles = [(int(rng.integers(0, 1920 // 32)) * 32, int(rng.integers(0, 1080 // 32)) * 32) for _ in range(ntiles)]
     variants = [("two", 56, 0), ("two", 64, 0), ("coat", 56, 16), ("coat", 56, 32), ("coat", 48, 24), ("coat", 56, 48), ("three", 0, 24), ("three", 0, 40), ("three", 0, 56), ("chain", 56, 0), ("chain", 40, 0)]
+    fvariants = [(56, 1), (56, 8), (56, 16), (56, 24), (56, 32), (56, 48), (56, 65), (48, 24), (40, 24), (48, 16), (64, 24), (64, 65), (40, 65)]
+    fres = {v: T2() for v in fvariants}
     res = {v: T2() for v in variants}
     kres = {k_: [T2(), 0.0] for k_ in (1, 2, 4)}
     ns = 0
@@ -185,6 +231,8 @@ if __name__ == "__main__":
                 wave = [grid[wy * 8 + y][wx * 8 + x] for y in range(8) for x in range(8)]
                 for v in variants:
                     res[v].add(sim_rooms(wave, v[0], v[1], v[2]))
+                for v in fvariants:
+                    fres[v].add(sim_finish_room(wave, v[0], v[1]))
         for k_ in kres:
             for wy in range(32 // (8 * k_)):
                 for wx in range(4):
@@ -196,6 +244,10 @@ if __name__ == "__main__":
         t = T.time() + extra
         print("two rooms, %d paths per lane: cost/sample %.1f (%.3fx of shipped) useful %.1f%%  execs/sample: closest %.2f head %.2f" % (
             k_, 64 * t / ns, base / t, 100 * T.useful() / t, 64 * T.e["closest"] / ns, 64 * T.e["surface"] / ns))
+    for v in fvariants:
+        T = fres[v]
+        print("finish room thr=%d/%d   cost/sample %.1f  (%.3fx of shipped)  useful %.1f%%   execs/sample: closest %.2f head %.2f finish %.2f" % (
+            v[0], v[1], 64 * T.time() / ns, base / T.time(), 100 * T.useful() / T.time(), 64 * T.e["closest"] / ns, 64 * T.e["surface"] / ns, 64 * T.e["finish"] / ns))
     for v in variants:
         T = res[v]
         print("%-18s cost/sample %.1f  (%.3fx of shipped)  useful %.1f%%   execs/sample: closest %.2f head %.2f lobes %.2f" % (
