@@ -17,7 +17,7 @@ template <class S>
 RPT_DEV void render_large_pair_body(const S& sc, const RenderParams& rp)
 {
     RPT_PROF_INIT();
-    __shared__ uint32_t s_fkey[kMaxSppPerLaunch];
+    __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
@@ -34,7 +34,7 @@ RPT_DEV void render_large_pair_body(const S& sc, const RenderParams& rp)
     bool ending = false;                                            // the path is over once the parked sample is resolved
     {
         const float4 c = s_pix[tid];
-        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z));
+        path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
     }
 
     for (;;) {
@@ -101,7 +101,7 @@ RPT_DEV void render_large_pair_body(const S& sc, const RenderParams& rp)
                 state = ST_DONE;
             } else {
                 const float4 c = s_pix[tid];
-                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z));
+                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
                 state = ST_TRACE;
             }
         }

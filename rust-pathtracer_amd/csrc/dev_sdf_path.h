@@ -105,12 +105,13 @@ RPT_DEV bool march_begin_shadow(const SceneSmallSdf& sc, PathRegs& p, v3 fhp, v3
 // the radiance, so the additions and their order are the reference's.  A bounce is then ONE block (finish closest_hit,
 // shade, set up the next ray) between marches, not RESOLVE -> march -> SHADE: two waiting rooms for a 64-lane wave instead of
 // three, and next-event estimation is sampled once instead of twice (the three-room kernel replays it to find the shadow ray).
+// Each lane's parked shadow ray (o.w: max_dist; d.w: 0 once a ray is parked) and light sample.  File-scope LDS: a query object
+// that carried three pointers to its lane's slots kept six VGPRs alive through the whole shading block.
+__shared__ float4 g_sdf_sho[256], g_sdf_shd[256], g_sdf_gain[256];
+
 struct SdfDeferredQuery {
     SdfMarchResult r;          // the path ray's march
     AnalyticPre a;
-    float4* sh_o;              // this lane's slots in LDS: shadow origin (w: max_dist), direction, the parked contribution
-    float4* sh_d;
-    float4* gain;
     RPT_DEV bool geom(const SceneSmallSdf& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e) const
     {
         return closest_geom_small<true>(sc, &sc.sdf, ray, ps, g, e, &r, &a);
@@ -130,11 +131,11 @@ struct SdfDeferredQuery {
             return h && (!use_max || t < max_dist);
         }
         pending = true;
-        *sh_o = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, max_dist);
-        *sh_d = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, 0.0f);
+        g_sdf_sho[threadIdx.x] = make_float4(shadow.o.x, shadow.o.y, shadow.o.z, max_dist);
+        g_sdf_shd[threadIdx.x] = make_float4(shadow.d.x, shadow.d.y, shadow.d.z, 0.0f);
         return false;
     }
-    RPT_DEV void park(v3 c) const { *gain = make_float4(c.x, c.y, c.z, 0.0f); }
+    RPT_DEV void park(v3 c) const { g_sdf_gain[threadIdx.x] = make_float4(c.x, c.y, c.z, 0.0f); }
 };
 
 }  // namespace rptdev

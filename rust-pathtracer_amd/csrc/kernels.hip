@@ -898,7 +898,9 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
-    __shared__ float4 s_sho[256], s_shd[256], s_gain[256];          // the parked shadow ray and light sample of each lane
+    float4* const s_sho = g_sdf_sho;                                // the parked shadow ray and light sample of each lane (dev_sdf_path.h)
+    float4* const s_shd = g_sdf_shd;
+    float4* const s_gain = g_sdf_gain;
     const uint32_t tid = threadIdx.x;
     if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
 
@@ -960,7 +962,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
             if (!over) {
                 GeomHit g;
                 g.code = 0u;
-                const SdfDeferredQuery q{{m.hit, m.t}, march_analytic(m), &s_sho[tid], &s_shd[tid], &s_gain[tid]};
+                const SdfDeferredQuery q{{m.hit, m.t}, march_analytic(m)};
                 const uint32_t what = path_trace_geom_split(sc, q, p, g);
                 if (what == 0u) { p.radiance = p.radiance + background(sc, p.ray) * p.throughput; over = true; }
                 else if (what == 1u) over = true;

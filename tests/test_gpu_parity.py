@@ -448,6 +448,15 @@ def _oracle_rows(oracle, desc, w, h, spp, rows, seed=1):
     return out
 
 
+def _nan_pixels_are_the_oracles_too(oracle, desc, img, w, h, spp, seed=1, limit=4):
+    """The reference has no NaN guards: over 5e8 samples a few hit a 0/0 of the BSDF code and poison their
+    pixel.  Such pixels must be rare, and NaN in the oracle's frame as well (their whole rows are compared, bit for bit)."""
+    bad = np.argwhere(np.isnan(img).any(axis=2))
+    assert len(bad) <= 1e-5 * w * h, "%d NaN pixels" % len(bad)
+    for r in sorted({int(b[0]) for b in bad})[:limit]:
+        assert_bit_identical(img[r], _oracle_rows(oracle, desc, w, h, spp, (r,), seed)[r], "row %d (has a NaN pixel)" % r)
+
+
 def test_full_size_config2_rows_match_oracle(rpt, torch_cuda, tracer, oracle):
     """BASELINE.json configs[1] at FULL size: AnalyticalScene 1920x1080 x 256 spp on the GPU; the oracle
     recomputes complete rows through the sky, the spheres and the floor and they must be bit-identical.
@@ -459,7 +468,8 @@ def test_full_size_config2_rows_match_oracle(rpt, torch_cuda, tracer, oracle):
     tracer.render_n(buf, spp)
     torch.cuda.synchronize()
     img = buf.pixels.cpu().numpy()
-    assert not np.isnan(img).any() and np.all(img[..., 3] == 1.0)
+    assert np.all(img[..., 3] == 1.0)
+    _nan_pixels_are_the_oracles_too(oracle, oracle.scene_analytical(), img, w, h, spp)
     for r, want in _oracle_rows(oracle, oracle.scene_analytical(), w, h, spp, (37, 541, 1003)).items():
         assert_bit_identical(img[r], want, "c2 row %d" % r)
     # tiling independence + determinism at full size (checksums over the whole frame)
@@ -627,7 +637,7 @@ def test_full_size_config4_sdf_rows_match_oracle(rpt, torch_cuda, oracle):
     t.render_n(buf, spp)
     torch_cuda.cuda.synchronize()
     img = buf.pixels.cpu().numpy()
-    assert not np.isnan(img).any()
+    _nan_pixels_are_the_oracles_too(oracle, s.describe(), img, w, h, spp)
     for r, want in _oracle_rows(oracle, s.describe(), w, h, spp, (150, 620, 1000)).items():
         assert_bit_identical(img[r], want, "c4 row %d" % r)
     t.close()
