@@ -481,7 +481,8 @@ int rpt_synchronize(rpt_ctx* ctx, void* stream);
  * leaf functions with the oracle bit for bit.  Not part of the drop-in surface.  */
 enum {
     RPT_PROBE_SIN = 0, RPT_PROBE_COS = 1, RPT_PROBE_LOG2 = 2, RPT_PROBE_POW = 3,
-    RPT_PROBE_DIV = 4, RPT_PROBE_SQRT = 5, RPT_PROBE_RNG = 6, RPT_PROBE_EXP = 7, RPT_PROBE_LOG = 8
+    RPT_PROBE_DIV = 4, RPT_PROBE_SQRT = 5, RPT_PROBE_RNG = 6, RPT_PROBE_EXP = 7, RPT_PROBE_LOG = 8,
+    RPT_PROBE_DIV3 = 9                /* three quotients by one denominator, the library's shared-reciprocal form: see kernels.hip */
 };
 int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b_dev,
                    float* out_dev, uint64_t n, void* stream);

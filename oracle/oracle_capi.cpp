@@ -400,6 +400,12 @@ void oracle_math(uint32_t fn, const float* a, const float* b, float* out, uint64
         case 5: out[i] = std::sqrt(a[i]); break;
         case 7: out[i] = raw(f_exp(a[i])); break;           // RPT_PROBE_EXP
         case 8: out[i] = raw(f_ln(a[i])); break;            // RPT_PROBE_LOG
+        case 9: {                                           // RPT_PROBE_DIV3: the same quotients, IEEE divides
+            const float x = a[i], d = b[i];
+            const float qx = (i & 4u) ? x / d : x / d, qy = (i & 4u) ? (0.5f * d) / d : (-d) / d, qz = (i & 4u) ? 0.0f / d : (0.75f * x) / d;
+            out[i] = (i % 3u == 0u) ? qx : ((i % 3u == 1u) ? qy : qz);
+            break;
+        }
         case 100: out[i] = raw(f_tan(a[i])); break;         // host only (the camera's fov)
         default: out[i] = 0.0f;
         }

@@ -57,7 +57,7 @@ RPT_RENDER_SDF_COMPACT = 1 << 9
 RPT_RENDER_SDF_THREE_ROOM_MARCH = 1 << 10
 
 (RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG, RPT_PROBE_EXP,
- RPT_PROBE_LOG) = range(9)
+ RPT_PROBE_LOG, RPT_PROBE_DIV3) = range(10)
 (RPT_PROBE_FN_GEN_RAY, RPT_PROBE_FN_HIT_SPHERE, RPT_PROBE_FN_HIT_PLANE, RPT_PROBE_FN_SAMPLE_LIGHT, RPT_PROBE_FN_DISNEY_EVAL,
  RPT_PROBE_FN_DISNEY_SAMPLE, RPT_PROBE_FN_COUNT) = range(7)
 RPT_PROBE_IN_STRIDE = 32

@@ -1317,7 +1317,7 @@ int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint6
 int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b_dev, float* out_dev, uint64_t n, void* stream)
 {
     if (!ctx) { set_err(nullptr, "rpt_probe_math: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
-    if (!a_dev || !b_dev || !out_dev || fn > RPT_PROBE_LOG) { set_err(ctx, "rpt_probe_math: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    if (!a_dev || !b_dev || !out_dev || fn > RPT_PROBE_DIV3) { set_err(ctx, "rpt_probe_math: invalid argument"); return RPT_ERR_INVALID_ARG; }
     if (n == 0) return RPT_OK;
     RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, rptlaunch::probe_math(fn, a_dev, b_dev, out_dev, n, (hipStream_t)stream));

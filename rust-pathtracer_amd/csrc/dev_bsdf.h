@@ -29,14 +29,14 @@ RPT_DEV void mat_finalize(Mat& m)                                   // material.
     m.roughness = rmax(m.roughness, 0.01f);
     m.clearcoat_roughness = mixf(0.1f, 0.001f, m.clearcoat_gloss);
     float aspect = __builtin_sqrtf(1.0f - m.anisotropic * 0.9f);
-    m.ax = rmax(m.roughness / aspect, 0.001f);
+    m.ax = rmax(fdiv(m.roughness, aspect), 0.001f);
     m.ay = rmax(m.roughness * aspect, 0.001f);
 }
 
 RPT_DEV float power_heuristic(float a, float b)                     // tracer.rs:223
 {
     float t = a * a;
-    return t / (b * b + t);
+    return fdiv(t, b * b + t);
 }
 
 RPT_DEV float gtr1(float ndoth, float a)                            // tracer.rs:233 (log2, sic)
@@ -44,7 +44,7 @@ RPT_DEV float gtr1(float ndoth, float a)                            // tracer.rs
     if (a >= 1.0f) return kInvPi;
     float a2 = a * a;
     float t = 1.0f + (a2 - 1.0f) * ndoth * ndoth;
-    return (a2 - 1.0f) / (kPi * rpt_log2f(a2) * t);
+    return fdiv(a2 - 1.0f, kPi * rpt_log2f(a2) * t);
 }
 
 RPT_DEV v3 sample_gtr1(float rgh, float r1)                         // tracer.rs:242 (r2 is unused there)
@@ -52,7 +52,7 @@ RPT_DEV v3 sample_gtr1(float rgh, float r1)                         // tracer.rs
     float a = rmax(0.001f, rgh);
     float a2 = a * a;
     float phi = r1 * kTwoPi;
-    float cos_theta = __builtin_sqrtf((1.0f - rpt_powf(a2, 1.0f - r1)) / (1.0f - a2));
+    float cos_theta = __builtin_sqrtf(fdiv(1.0f - rpt_powf(a2, 1.0f - r1), 1.0f - a2));
     float sin_theta = clamp01(__builtin_sqrtf(1.0f - (cos_theta * cos_theta)));
     float sin_phi, cos_phi;
     rpt_sincosf(phi, &sin_phi, &cos_phi);
@@ -64,7 +64,7 @@ RPT_DEV v3 sample_ggxvndf(v3 v, float ax, float ay, float r1, float r2)   // tra
     v3 vh = norm3(mk3(ax * v.x, ay * v.y, v.z));
     float lensq = vh.x * vh.x + vh.y * vh.y;
     v3 t_1 = mk3(1.0f, 0.0f, 0.0f);
-    if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), 1.0f / __builtin_sqrtf(lensq));
+    if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), fdiv(1.0f, __builtin_sqrtf(lensq)));
     v3 t_2 = cross3(vh, t_1);
     float r = __builtin_sqrtf(r1);
     float phi = (2.0f * kPi) * r2;
@@ -82,7 +82,7 @@ RPT_DEV float smithg(float ndotv, float alphag)                     // tracer.rs
 {
     float a = alphag * alphag;
     float b = ndotv * ndotv;
-    return (2.0f * ndotv) / (ndotv + __builtin_sqrtf(a + b - a * b));
+    return fdiv(2.0f * ndotv, ndotv + __builtin_sqrtf(a + b - a * b));
 }
 
 RPT_DEV float luminance(v3 c)                                       // tracer.rs:284
@@ -99,10 +99,10 @@ RPT_DEV float schlick_fresnel(float u)                              // tracer.rs
 
 RPT_DEV float gtr2aniso(float ndoth, float hdotx, float hdoty, float ax, float ay)   // tracer.rs:294
 {
-    float a = hdotx / ax;
-    float b = hdoty / ay;
+    float a = fdiv(hdotx, ax);
+    float b = fdiv(hdoty, ay);
     float c = a * a + b * b + ndoth * ndoth;
-    return 1.0f / (kPi * ax * ay * c * c);
+    return fdiv(1.0f, kPi * ax * ay * c * c);
 }
 
 RPT_DEV float smithganiso(float ndotv, float vdotx, float vdoty, float ax, float ay)   // tracer.rs:301
@@ -110,7 +110,7 @@ RPT_DEV float smithganiso(float ndotv, float vdotx, float vdoty, float ax, float
     float a = vdotx * ax;
     float b = vdoty * ay;
     float c = ndotv;
-    return (2.0f * ndotv) / (ndotv + __builtin_sqrtf(a * a + b * b + c * c));
+    return fdiv(2.0f * ndotv, ndotv + __builtin_sqrtf(a * a + b * b + c * c));
 }
 
 RPT_DEV float dielectric_fresnel(float cos_theta_i, float eta)      // tracer.rs:308
@@ -118,8 +118,8 @@ RPT_DEV float dielectric_fresnel(float cos_theta_i, float eta)      // tracer.rs
     float sin_theta_tsq = eta * eta * (1.0f - cos_theta_i * cos_theta_i);
     if (sin_theta_tsq > 1.0f) return 1.0f;
     float cos_theta_t = __builtin_sqrtf(rmax(1.0f - sin_theta_tsq, 0.0f));
-    float rs = (eta * cos_theta_t - cos_theta_i) / (eta * cos_theta_t + cos_theta_i);
-    float rp = (eta * cos_theta_i - cos_theta_t) / (eta * cos_theta_i + cos_theta_t);
+    float rs = fdiv(eta * cos_theta_t - cos_theta_i, eta * cos_theta_t + cos_theta_i);
+    float rp = fdiv(eta * cos_theta_i - cos_theta_t, eta * cos_theta_i + cos_theta_t);
     return 0.5f * (rs * rs + rp * rp);
 }
 
@@ -141,7 +141,7 @@ RPT_DEV void get_spec_color(const Mat& m, float eta, v3& spec_col, v3& sheen_col
     float lum = luminance(m.rgb);
     v3 ctint = mk3(1.0f, 1.0f, 1.0f);
     if (lum > 0.0f) ctint = divs3(m.rgb, lum);
-    float f0 = (1.0f - eta) / (1.0f + eta);
+    float f0 = fdiv(1.0f - eta, 1.0f + eta);
     spec_col = mix3((f0 * f0) * mix3(mk3(1.0f, 1.0f, 1.0f), ctint, m.specular_tint), m.rgb, m.metallic);
     sheen_col = mix3(mk3(1.0f, 1.0f, 1.0f), ctint, m.sheen_tint);
 }
@@ -165,7 +165,7 @@ RPT_DEV v3 eval_diffuse(const Mat& m, v3 c_sheen, v3 v, v3 l, v3 h, float& pdf) 
     float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
     float fss90 = ldh * ldh * m.roughness;
     float fss = mixf(1.0f, fss90, fl) * mixf(1.0f, fss90, fv);
-    float ss = 1.25f * (fss * (1.0f / (l.z + v.z) - 0.5f) + 0.5f);
+    float ss = 1.25f * (fss * (fdiv(1.0f, l.z + v.z) - 0.5f) + 0.5f);
     v3 fsheen = (fh * m.sheen) * c_sheen;
     pdf = l.z * kInvPi;
     return ((1.0f - m.metallic) * (1.0f - m.spec_trans)) * ((kInvPi * mixf(fd, ss, m.subsurface)) * m.rgb + fsheen);
@@ -180,7 +180,7 @@ RPT_DEV v3 eval_spec_reflection(const Mat& m, float eta, v3 spec_col, v3 v, v3 l
     float d = gtr2aniso(h.z, h.x, h.y, m.ax, m.ay);
     float g1 = smithganiso(__builtin_fabsf(v.z), v.x, v.y, m.ax, m.ay);
     float g2 = g1 * smithganiso(__builtin_fabsf(l.z), l.x, l.y, m.ax, m.ay);
-    pdf = g1 * d / (4.0f * v.z);
+    pdf = fdiv(g1 * d, 4.0f * v.z);
     return divs3((d * g2) * f, 4.0f * l.z * v.z);
 }
 
@@ -196,10 +196,10 @@ RPT_DEV v3 eval_spec_refraction(const Mat& m, float eta, v3 v, v3 l, v3 h, float
     float denom = ldh + vdh * eta;
     denom *= denom;
     float eta2 = eta * eta;
-    float jacobian = __builtin_fabsf(ldh) / denom;
-    pdf = g1 * rmax(0.0f, vdh) * d * jacobian / v.z;
-    float s = (1.0f - m.metallic) * m.spec_trans * (1.0f - f) * d * g2 * __builtin_fabsf(vdh) * jacobian * eta2 /
-              __builtin_fabsf(l.z * v.z);
+    float jacobian = fdiv(__builtin_fabsf(ldh), denom);
+    pdf = fdiv(g1 * rmax(0.0f, vdh) * d * jacobian, v.z);
+    float s = fdiv((1.0f - m.metallic) * m.spec_trans * (1.0f - f) * d * g2 * __builtin_fabsf(vdh) * jacobian * eta2,
+                   __builtin_fabsf(l.z * v.z));
     return s * mk3(rpt_powf(m.rgb.x, 0.5f), rpt_powf(m.rgb.y, 0.5f), rpt_powf(m.rgb.z, 0.5f));
 }
 
@@ -212,9 +212,9 @@ RPT_DEV v3 eval_clearcoat(const Mat& m, v3 v, v3 l, v3 h, float& pdf)   // trace
     float f = mixf(0.04f, 1.0f, fh);
     float d = gtr1(h.z, m.clearcoat_roughness);
     float g = smithg(l.z, 0.25f) * smithg(v.z, 0.25f);
-    float jacobian = 1.0f / (4.0f * vdh);
+    float jacobian = fdiv(1.0f, 4.0f * vdh);
     pdf = d * h.z * jacobian;
-    return (m.clearcoat * f * d * g / (4.0f * l.z * v.z)) * mk3(0.25f, 0.25f, 0.25f);
+    return fdiv(m.clearcoat * f * d * g, 4.0f * l.z * v.z) * mk3(0.25f, 0.25f, 0.25f);
 }
 
 struct LobeWeights {
@@ -230,10 +230,11 @@ RPT_DEV LobeWeights get_lobe_probabilities(const Mat& m, v3 spec_col, float appr
     w.spec_refract = (1.0f - approx_fresnel) * (1.0f - m.metallic) * m.spec_trans * lum;
     w.clearcoat = 0.25f * m.clearcoat * (1.0f - m.metallic);
     float total = w.diffuse + w.spec_reflect + w.spec_refract + w.clearcoat;
-    w.diffuse /= total;
-    w.spec_reflect /= total;
-    w.spec_refract /= total;
-    w.clearcoat /= total;
+    const v3 w3 = divs3(mk3(w.diffuse, w.spec_reflect, w.spec_refract), total);      // (four quotients by one total)
+    w.diffuse = w3.x;
+    w.spec_reflect = w3.y;
+    w.spec_refract = w3.z;
+    w.clearcoat = fdiv(w.clearcoat, total);
     return w;
 }
 
@@ -309,7 +310,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
 
     const float lo = is_d ? 0.0f : (is_c ? cdf0 : cdf1);
     const float hi = is_d ? cdf0 : (is_c ? cdf1 : 1.0f);
-    r1 = (r1 - lo) / (hi - lo);                                     // tracer.rs:502, 511, 521
+    r1 = fdiv(r1 - lo, hi - lo);                                    // tracer.rs:502, 511, 521
     const float phi = kTwoPi * (is_c ? r1 : r2);                    // tracer.rs:329, 247, 267
     float sn, cs;
     rpt_sincosf(phi, &sn, &cs);
@@ -331,7 +332,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
         RPT_PROF(PB_LOBE_CLEARCOAT);
         float a = rmax(0.001f, m.clearcoat_roughness);              // sample_gtr1, tracer.rs:242 (r2 is unused there)
         float a2 = a * a;
-        float cos_theta = __builtin_sqrtf((1.0f - rpt_powf(a2, 1.0f - r1)) / (1.0f - a2));
+        float cos_theta = __builtin_sqrtf(fdiv(1.0f - rpt_powf(a2, 1.0f - r1), 1.0f - a2));
         float sin_theta = clamp01(__builtin_sqrtf(1.0f - (cos_theta * cos_theta)));
         v3 h = mk3(sin_theta * cs, sin_theta * sn, cos_theta);
         if (h.z < 0.0f) h = -h;
@@ -342,7 +343,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
         v3 vh = norm3(mk3(m.ax * v.x, m.ay * v.y, v.z));            // sample_ggxvndf, tracer.rs:256
         float lensq = vh.x * vh.x + vh.y * vh.y;
         v3 t_1 = mk3(1.0f, 0.0f, 0.0f);
-        if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), 1.0f / __builtin_sqrtf(lensq));
+        if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), fdiv(1.0f, __builtin_sqrtf(lensq)));
         v3 t_2 = cross3(vh, t_1);
         float t1 = rs * cs;
         float t2 = rs * sn;
@@ -399,22 +400,22 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
             }
             const float n_v = is_c ? v.z : __builtin_fabsf(v.z);
             const float n_l = is_c ? l.z : __builtin_fabsf(l.z);
-            const float g_v = (2.0f * n_v) / (n_v + __builtin_sqrtf(e_v));
-            const float g_l = (2.0f * n_l) / (n_l + __builtin_sqrtf(e_l));
+            const float g_v = fdiv(2.0f * n_v, n_v + __builtin_sqrtf(e_v));
+            const float g_l = fdiv(2.0f * n_l, n_l + __builtin_sqrtf(e_l));
             const float g = g_v * g_l;                              // clearcoat: smithg(l) * smithg(v); specular: g1 * smithganiso(l)
             // pdf: clearcoat d * h.z * (1 / (4 vdh)); specular (g1 * d) / (4 v.z)
-            const float q = (is_c ? 1.0f : g_v * d) / (4.0f * (is_c ? vdh : v.z));
+            const float q = fdiv(is_c ? 1.0f : g_v * d, 4.0f * (is_c ? vdh : v.z));
             pdf = is_c ? (d * h.z * q) : q;
             const float den = 4.0f * l.z * v.z;
             // value: clearcoat (clearcoat * F * d * g / den) * 0.25; specular ((d * g) * F) / den per channel
             const float dg = d * g;
             const float numx = is_c ? (m.clearcoat * fcol.x * d * g) : (dg * fcol.x);
-            const float qx = numx / den;
+            const v3 q3 = divs3(mk3(numx, dg * fcol.y, dg * fcol.z), den);          // (the clearcoat arm uses the first quotient only)
             if (is_c) {
-                const float c = qx * 0.25f;
+                const float c = q3.x * 0.25f;
                 f = mk3(c, c, c);
             } else {
-                f = mk3(qx, (dg * fcol.y) / den, (dg * fcol.z) / den);
+                f = q3;
             }
         }
         if (is_c) {

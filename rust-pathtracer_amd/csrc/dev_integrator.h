@@ -51,7 +51,7 @@ RPT_DEV bool hit_plane(const RayD& ray, const DevPlane& p, float& t)
     v3 n = mk3(p.nx, p.ny, p.nz);
     float denom = dot3(n, ray.d);
     if (__builtin_fabsf(denom) > p.min_denom) {
-        float tt = dot3(mk3(p.px, p.py, p.pz) - ray.o, n) / denom;
+        float tt = fdiv(dot3(mk3(p.px, p.py, p.pz) - ray.o, n), denom);
         if (tt >= 0.0f && (!(p.max_t > 0.0f) || tt <= p.max_t)) { t = tt; return true; }
     }
     return false;
@@ -77,8 +77,8 @@ RPT_DEV void apply_patch(Mat& m, const DevMaterial& p, bool on, v3 dir)
     if (p.mask & RPT_MAT_IOR) m.ior = on ? p.ior : m.ior;
     if (p.proc_kind == RPT_PROC_CHECKER_DIR) {                      // analytical.rs:107-115
         if (on) {
-            float x = dir.x / dir.y * p.proc_params[0] + p.proc_params[1];
-            float y = dir.z / dir.y * p.proc_params[0] + p.proc_params[1];
+            float x = fdiv(dir.x, dir.y) * p.proc_params[0] + p.proc_params[1];
+            float y = fdiv(dir.z, dir.y) * p.proc_params[0] + p.proc_params[1];
             float x1 = rem2(__builtin_floorf(x));
             float y1 = rem2(__builtin_floorf(y));
             float c = (rem2(x1 + y1) < 1.0f) ? p.proc_params[2] : p.proc_params[3];
@@ -238,7 +238,7 @@ RPT_DEV bool light_intersect(const DevLight& L, uint32_t scene_flags, const RayD
                 ldist = t;
                 v3 hit_point = ray.o + t * ray.d;
                 float cos_theta = dot3(-ray.d, norm3(hit_point - pos));
-                e.light_pdf = (ldist * ldist) / (L.area * cos_theta * 0.5f);
+                e.light_pdf = fdiv(ldist * ldist, L.area * cos_theta * 0.5f);
                 e.light_emission = mk3(L.ex, L.ey, L.ez);
                 e.is_emitter = true;
                 ps.hit_dist = t;
@@ -250,10 +250,10 @@ RPT_DEV bool light_intersect(const DevLight& L, uint32_t scene_flags, const RayD
         const v3 n = norm3(cross3(u, v));
         if (dot3(n, ray.d) > 0.0f) return false;                    // back side: invisible
         const float plane_w = dot3(n, pos);
-        const v3 uu = scale3(u, 1.0f / dot3(u, u));
-        const v3 vv = scale3(v, 1.0f / dot3(v, v));
+        const v3 uu = scale3(u, fdiv(1.0f, dot3(u, u)));
+        const v3 vv = scale3(v, fdiv(1.0f, dot3(v, v)));
         const float dt = dot3(ray.d, n);
-        const float t = (plane_w - dot3(n, ray.o)) / dt;
+        const float t = fdiv(plane_w - dot3(n, ray.o), dt);
         if (t >= 0.0f) {
             const v3 vi = (ray.o + t * ray.d) - pos;
             const float a1 = dot3(uu, vi);
@@ -263,7 +263,7 @@ RPT_DEV bool light_intersect(const DevLight& L, uint32_t scene_flags, const RayD
                     if (t < ldist) {
                         ldist = t;
                         const float cos_theta = dot3(-ray.d, n);
-                        e.light_pdf = (ldist * ldist) / (L.area * cos_theta);
+                        e.light_pdf = fdiv(ldist * ldist, L.area * cos_theta);
                         e.light_emission = mk3(L.ex, L.ey, L.ez);
                         e.is_emitter = true;
                         ps.hit_dist = t;
@@ -518,7 +518,7 @@ RPT_DEV void sample_light(const S& sc, const DevLight& L, v3 scatter_pos, LightS
             ls.direction = divs3(ls.direction, ls.dist);
             ls.normal = norm3(cross3(u, v));
             ls.emission = sc.n_lights_f * mk3(L.ex, L.ey, L.ez);
-            ls.pdf = dist_sq / (L.area * __builtin_fabsf(dot3(ls.normal, ls.direction)));
+            ls.pdf = fdiv(dist_sq, L.area * __builtin_fabsf(dot3(ls.normal, ls.direction)));
         } else {                                                    // RPT_LIGHT_DISTANT: no draws
             ls.direction = norm3(position);
             ls.normal = norm3(scatter_pos - position);
@@ -549,7 +549,7 @@ RPT_DEV void sample_light(const S& sc, const DevLight& L, v3 scatter_pos, LightS
     ls.direction = divs3(ls.direction, ls.dist);
     ls.normal = norm3(surface_pos - lpos);
     ls.emission = sc.n_lights_f * mk3(L.ex, L.ey, L.ez);
-    ls.pdf = dist_sq / (L.area * 0.5f * __builtin_fabsf(dot3(ls.normal, ls.direction)));
+    ls.pdf = fdiv(dist_sq, L.area * 0.5f * __builtin_fabsf(dot3(ls.normal, ls.direction)));
 }
 
 // Scene::light_at (analytical.rs:148-150) for a per-lane index: a select chain over the
@@ -729,7 +729,7 @@ RPT_DEV uint32_t path_trace_geom_split(const S& sc, const Q& q, PathRegs& p, Geo
                 p.radiance = p.radiance + scale3(scale3(md.color, seg), md.density) * p.throughput;
             } else if (md.type == RPT_MEDIUM_SCATTER) {
                 const float r = p.rng.gen();
-                const float d = rmin(-rpt_logf(r) / md.density, seg);
+                const float d = rmin(fdiv(-rpt_logf(r), md.density), seg);
                 if (d < seg) {                                      // a scatter event before the segment's end: SHADE does the rest
                     p.throughput = p.throughput * md.color;
                     p.ray.o = p.ray.o + d * p.ray.d;
@@ -832,7 +832,7 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
         RPT_PROF(PB_FINALIZE);
         hit_material(sc, p.ray, g, mat);
         mat_finalize(mat);
-        eta = (ndd < 0.0f) ? (1.0f / mat.ior) : mat.ior;
+        eta = (ndd < 0.0f) ? fdiv(1.0f, mat.ior) : mat.ior;
         p.radiance = p.radiance + mat.emission * p.throughput;
     }
     const v3 fhp = cold ? mk3(cold->x, cold->y, cold->z) : (p.ray.o + p.ps.hit_dist * p.ray.d);

@@ -31,11 +31,79 @@ RPT_DEV v3 splat3(float s) { return v3{s, s, s}; }                       // F3::
 RPT_DEV v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }   // fx.rs:437
 RPT_DEV v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }   // fx.rs:453
 RPT_DEV v3 operator*(v3 a, v3 b) { return v3{a.x * b.x, a.y * b.y, a.z * b.z}; }   // fx.rs:469
-RPT_DEV v3 operator/(v3 a, v3 b) { return v3{a.x / b.x, a.y / b.y, a.z / b.z}; }   // fx.rs:485
+RPT_DEV float fdiv(float n, float d);
+RPT_DEV v3 operator/(v3 a, v3 b) { return v3{fdiv(a.x, b.x), fdiv(a.y, b.y), fdiv(a.z, b.z)}; }   // fx.rs:485
 RPT_DEV v3 operator*(float s, v3 a) { return v3{s * a.x, s * a.y, s * a.z}; }      // fx.rs:477 (f32 * F3)
 RPT_DEV v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }                        // fx.rs:509
 RPT_DEV v3 scale3(v3 a, float f) { return v3{a.x * f, a.y * f, a.z * f}; }         // F3::mult_f, fx.rs:346
-RPT_DEV v3 divs3(v3 a, float d) { return v3{a.x / d, a.y / d, a.z / d}; }          // a / F3::new_x(d)
+// ---- division ------------------------------------------------------------------------------------------------
+// The reference divides (fx.rs:307-313: normalize is THREE divides by the length; F3 / F3 is component-wise), and results are
+// compared bit for bit, so every quotient here must be the correctly rounded one.  hipcc's expansion of `a / b` is a chain of ten
+// dependent instructions (v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup) and the megakernel is bound by exactly these
+// chains (profiles/NOTES.md).  The SHORT sequence below
+//     r0 = v_rcp_f32(d);  r = fma(fma(-d, r0, 1), r0, r0);  q0 = n * r;  q = fma(fma(-d, q0, n), r, q0);  v_div_fixup(q, d, n)
+// — one Newton step on the reciprocal, shared by every numerator of one denominator, and ONE Markstein correction of the quotient —
+// returns the correctly rounded quotient for EVERY pair of significands: tools/proofs/div_exhaustive.hip compares it with hipcc's
+// divide on all 2^23 x 2^23 pairs on gfx950 (7.0e13 quotients, 0 mismatches, 40 s of one MI355X; profiles/r3/proofs/).  Every step
+// commutes exactly with scaling by powers of two and with the operands' signs as long as no intermediate leaves the normal range:
+// |d|, |n| in [2^-61, 2^60) keeps r, q0, the residual (>= 2^-46 |n|) and q (2^-121 .. 2^121) normal.  Zeros, infinities and NaNs take
+// the short path too: v_div_fixup answers them without looking at q, exactly as it does at the end of hipcc's sequence (and supplies
+// IEEE's sign of a zero quotient).  Finite operands outside that range — denormals included — take hipcc's divide in the lanes
+// concerned (a wave vote: practically never taken).
+// v_frexp_exp_i32_f32: floor(log2 |x|) + 1 for finite non-zero x (denormals included), 0 for zero, infinity and NaN — which
+// therefore pass the range test and are answered by v_div_fixup exactly as they are at the end of hipcc's own sequence.
+RPT_DEV int div_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }
+RPT_DEV bool div_exps_ok(int lo, int hi) { return lo >= -60 && hi <= 60; }
+RPT_DEV float div_rcp(float d)                                      // the shared half: 1 / d to within what the correction needs
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+}
+RPT_DEV float div_with_rcp(float n, float d, float r)
+{
+    const float q0 = n * r;
+    return __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0), d, n);
+}
+#ifdef RPT_PLAIN_DIVIDES                                            // A/B build: hipcc's divide everywhere
+RPT_DEV float fdiv(float n, float d) { return n / d; }
+RPT_DEV v3 divs3(v3 a, float d) { return v3{a.x / d, a.y / d, a.z / d}; }
+RPT_DEV v3 divs3_norm(v3 a, float len) { return divs3(a, len); }
+#else
+// (A single quotient gains nothing in instructions — 7 + 6 of guard against hipcc's 11 — only in chain depth: c2 is the same with
+// either form, the large-scene kernel 1 % faster with this one; profiles/r3/experiments/short_division.txt.)
+RPT_DEV float fdiv(float n, float d)
+{
+#ifdef RPT_SCALAR_DIVIDES_PLAIN
+    return n / d;
+#endif
+    float q = div_with_rcp(n, d, div_rcp(d));
+    const int en = div_exp(n), ed = div_exp(d);
+    const bool ok = div_exps_ok(en < ed ? en : ed, en < ed ? ed : en);
+    if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) q = n / d; }
+    return q;
+}
+RPT_DEV int imin3(int a, int b, int c) { int m = a < b ? a : b; return m < c ? m : c; }
+RPT_DEV int imax3(int a, int b, int c) { int m = a > b ? a : b; return m > c ? m : c; }
+RPT_DEV v3 divs3(v3 a, float d)                                     // a / F3::new_x(d): three quotients, one reciprocal
+{
+    const float r = div_rcp(d);
+    v3 q = v3{div_with_rcp(a.x, d, r), div_with_rcp(a.y, d, r), div_with_rcp(a.z, d, r)};
+    const int ex = div_exp(a.x), ey = div_exp(a.y), ez = div_exp(a.z), ed = div_exp(d);
+    const bool ok = div_exps_ok(imin3(ex, ey, ez), imax3(ex, ey, ez)) && div_exps_ok(ed, ed);
+    if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) q = v3{a.x / d, a.y / d, a.z / d}; }
+    return q;
+}
+// normalize: the numerators cannot exceed the length, which spares the upper test
+RPT_DEV v3 divs3_norm(v3 a, float len)
+{
+    const float r = div_rcp(len);
+    v3 q = v3{div_with_rcp(a.x, len, r), div_with_rcp(a.y, len, r), div_with_rcp(a.z, len, r)};
+    const int ed = div_exp(len);
+    const bool ok = div_exps_ok(imin3(div_exp(a.x), div_exp(a.y), div_exp(a.z)), 0) && div_exps_ok(ed, ed);
+    if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) q = v3{a.x / len, a.y / len, a.z / len}; }
+    return q;
+}
+#endif
 
 RPT_DEV float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       // fx.rs:335
 RPT_DEV v3 cross3(v3 a, v3 b)                                                      // fx.rs:339
@@ -43,7 +111,7 @@ RPT_DEV v3 cross3(v3 a, v3 b)                                                   
     return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
 RPT_DEV float len3(v3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }   // fx.rs:331
-RPT_DEV v3 norm3(v3 a) { float l = len3(a); return v3{a.x / l, a.y / l, a.z / l}; }      // fx.rs:307 (three divides)
+RPT_DEV v3 norm3(v3 a) { return divs3_norm(a, len3(a)); }                                    // fx.rs:307 (three divides by the length)
 RPT_DEV v3 mix3(v3 a, v3 b, float v)                                               // math.rs:34
 {
     return v3{(1.0f - v) * a.x + b.x * v, (1.0f - v) * a.y + b.y * v, (1.0f - v) * a.z + b.z * v};

@@ -337,11 +337,12 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 #else
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
 #endif
-// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).  6 waves per SIMD: the grid walk
-// waits on dependent loads 43 % of its time (profiles/r2/c5), and one more wave hides more of that than the extra spills cost
-// (10 k spheres, 2048^2 x 8 spp: 4 waves 1 165, 5: 1 387, 6: 1 454, 7: 1 372, 8: 1 200 Msamples/s).
+// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).  7 waves per SIMD: the grid walk
+// waits on dependent loads 40 % of its time (profiles/r3/c5_megakernel), and one more wave hides more of that than the extra spills
+// cost (10 k spheres, 2048^2 x 32 spp, with dev_math.h's short division: 5 waves 1 660, 6: 1 664, 7: 1 689 Msamples/s; round 2, hipcc's
+// divide, 2048^2 x 8: 4: 1 165, 5: 1 387, 6: 1 454, 7: 1 372, 8: 1 200).
 #ifndef RPT_LARGE_WAVES_PER_SIMD
-#define RPT_LARGE_WAVES_PER_SIMD 6
+#define RPT_LARGE_WAVES_PER_SIMD 7
 #endif
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
@@ -1225,7 +1226,12 @@ __global__ __launch_bounds__(256) void RPT_K(probe_math_kernel)(uint32_t fn, con
     case RPT_PROBE_COS: r = rpt_cosf(a[i]); break;
     case RPT_PROBE_LOG2: r = rpt_log2f(a[i]); break;
     case RPT_PROBE_POW: r = rpt_powf(a[i], b[i]); break;
-    case RPT_PROBE_DIV: r = a[i] / b[i]; break;
+    case RPT_PROBE_DIV: r = fdiv(a[i], b[i]); break;                 // the library's divide (dev_math.h), not hipcc's
+    case RPT_PROBE_DIV3: {                                            // three quotients by one denominator: divs3 / normalize's form
+        const v3 q = (i & 4u) ? divs3_norm(mk3(a[i], 0.5f * b[i], 0.0f), b[i]) : divs3(mk3(a[i], -b[i], 0.75f * a[i]), b[i]);
+        r = (i % 3u == 0u) ? q.x : ((i % 3u == 1u) ? q.y : q.z);
+        break;
+    }
     case RPT_PROBE_SQRT: r = __builtin_sqrtf(a[i]); break;
     case RPT_PROBE_EXP: r = rpt_expf(a[i]); break;
     case RPT_PROBE_LOG: r = rpt_logf(a[i]); break;

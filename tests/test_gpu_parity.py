@@ -101,6 +101,31 @@ def test_probe_div_sqrt_are_correctly_rounded(rpt, torch_cuda, tracer, oracle):
     assert_bit_identical(_probe(rpt, torch_cuda, tracer, 5, np.abs(a2)), oracle.math(5, np.abs(a2)), "sqrt (moderate range)")
 
 
+def test_probe_library_divide_is_the_ieee_divide(rpt, torch_cuda, tracer, oracle):
+    """The library divides through a shorter sequence than hipcc's (dev_math.h: one refined reciprocal shared by the numerators of
+    one denominator, one correction; proven on all significand pairs by tools/proofs/div_exhaustive.hip) inside a guarded exponent
+    range, and through hipcc's divide outside it.  Here: every kind of operand at the seams — all bit patterns, exponents around
+    the guard's limits (2^-61, 2^60), denormals, zeros of both signs, infinities, NaNs, numerators far smaller than the denominator —
+    single quotients (RPT_PROBE_DIV) and the three-quotient forms of divs3 / normalize (RPT_PROBE_DIV3)."""
+    A = rpt._abi
+    rng = np.random.default_rng(33)
+    n = 2_000_000
+    def mixed(k):
+        mant = rng.integers(0, 2 ** 23, size=k, dtype=np.uint64)
+        sign = rng.integers(0, 2, size=k, dtype=np.uint64) << 31
+        seam = rng.choice(np.array([1, 2, 60, 64, 65, 66, 67, 68, 69, 126, 127, 128, 185, 186, 187, 188, 189, 190, 253, 254], dtype=np.uint64), size=k)
+        return (sign | (seam << 23) | mant).astype(np.uint32).view(np.float32)
+    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-39, 1.0, -1.0, 3.0, 1e30, 1e-30, 2.0 ** -61, 2.0 ** 60, 2.0 ** 59.5], dtype=np.float32)
+    grid_a, grid_b = np.meshgrid(specials, specials)
+    for a, b, what in ((_random_floats(rng, n), _random_floats(rng, n), "all bit patterns"),
+                       (mixed(n), mixed(n), "exponents at the guard's seams"),
+                       (rng.uniform(-4, 4, n).astype(np.float32), rng.uniform(-4, 4, n).astype(np.float32), "moderate range"),
+                       (mixed(n), rng.uniform(0.1, 10, n).astype(np.float32), "seam numerators, ordinary denominators"),
+                       (grid_a.ravel().copy(), grid_b.ravel().copy(), "special values, all pairs")):
+        assert_bit_identical(_probe(rpt, torch_cuda, tracer, A.RPT_PROBE_DIV, a, b), oracle.math(4, a, b), "fdiv, " + what)
+        assert_bit_identical(_probe(rpt, torch_cuda, tracer, A.RPT_PROBE_DIV3, a, b), oracle.math(9, a, b), "divs3, " + what)
+
+
 def test_probe_rng_first_draw(rpt, torch_cuda, tracer, oracle):
     n = 4096
     seed, frame = 1, 7

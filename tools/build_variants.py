@@ -44,6 +44,11 @@ VARIANTS = {
     "compact8": ["-DRPT_COMPACT_WAVES_PER_SIMD=8"],
     # BASELINE.json's "scene/material/light tables staged in LDS": the headline kernel reading its tables from LDS instead of SGPRs
     "scene_in_lds": ["-DRPT_AB_KERNELS", "-DRPT_SCENE_IN_LDS"],
+    "plain_divides": ["-DRPT_PLAIN_DIVIDES"],
+    "scalar_plain": ["-DRPT_SCALAR_DIVIDES_PLAIN"],
+    "large_w5": ["-DRPT_LARGE_WAVES_PER_SIMD=5"],
+    "large_w7": ["-DRPT_LARGE_WAVES_PER_SIMD=7"],
+    "large_w5_sp": ["-DRPT_LARGE_WAVES_PER_SIMD=5", "-DRPT_SCALAR_DIVIDES_PLAIN"],
     "sdf_w4": ["-DRPT_SDF_WAVES_PER_SIMD=4"],
     "sdf_w6": ["-DRPT_SDF_WAVES_PER_SIMD=6"],
     "pair_w4": ["-DRPT_LARGE_PAIR_WAVES_PER_SIMD=4"],

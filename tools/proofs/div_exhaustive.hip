@@ -1,0 +1,67 @@
+// Exhaustive check of the short division sequence against the correctly rounded divide, over ALL pairs of significands.
+//
+//   r0 = v_rcp_f32(d);  r = fma(fma(-d, r0, 1), r0, r0);          (one Newton step on the reciprocal, shared by every numerator)
+//   q0 = n * r;  q = v_div_fixup(fma(fma(-d, q0, n), r, q0), d, n)  (one Markstein correction of the quotient; the fix-up only acts on
+//                                                                   zeros, infinities and NaNs — and must leave everything else alone)
+//
+// For operands whose exponents are far from the ends of the range (no intermediate over- or underflows; dev_math.h guards that)
+// every step commutes exactly with scaling n and d by powers of two, and with their signs, so it is enough to compare the 2^23 x 2^23
+// significand pairs n, d in [1, 2): 7.0e13 divisions, about a minute of one MI355X.
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off tools/proofs/div_exhaustive.hip -o tools/proofs/div_exhaustive
+//   tools/proofs/div_exhaustive [first_d_block] [n_d_blocks]      (d significands in blocks of 2^17; 64 blocks = all)
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+
+__global__ __launch_bounds__(256) void check(uint32_t d_first, unsigned long long* mismatches, uint32_t* examples)
+{
+    const uint32_t dm = d_first + blockIdx.x * 256u + threadIdx.x;             // d's 23 significand bits
+    const float d = u2f(0x3F800000u | dm);
+    float r = __builtin_amdgcn_rcpf(d);
+    r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+    uint32_t bad = 0;
+    for (uint32_t nm = 0; nm < (1u << 23); ++nm) {
+        const float n = u2f(0x3F800000u | nm);
+        const float q0 = n * r;
+        const float q = __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0), d, n);
+        const float ref = n / d;                                               // hipcc's correctly rounded expansion
+        if (f2u(q) != f2u(ref)) {
+            if (bad == 0) {
+                const unsigned long long k = atomicAdd(mismatches + 1, 1ull);  // distinct d with a mismatch
+                if (k < 64) { examples[2 * k] = f2u(n); examples[2 * k + 1] = f2u(d); }
+            }
+            ++bad;
+        }
+    }
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+int main(int argc, char** argv)
+{
+    const uint32_t first = argc > 1 ? (uint32_t)atoi(argv[1]) : 0u, count = argc > 2 ? (uint32_t)atoi(argv[2]) : 64u;
+    unsigned long long* mm;
+    uint32_t* ex;
+    hipMalloc(&mm, 16);
+    hipMalloc(&ex, 64 * 8);
+    hipMemset(mm, 0, 16);
+    hipMemset(ex, 0, 64 * 8);
+    for (uint32_t b = first; b < first + count && b < 64u; ++b) {
+        hipLaunchKernelGGL(check, dim3((1u << 17) / 256u), dim3(256), 0, 0, b << 17, mm, ex);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 2; }
+        unsigned long long h[2];
+        hipMemcpy(h, mm, 16, hipMemcpyDeviceToHost);
+        printf("d block %2u / 64 done: %llu mismatching pairs so far, in %llu denominators\n", b + 1, h[0], h[1]);
+        fflush(stdout);
+    }
+    unsigned long long h[2];
+    uint32_t e[128];
+    hipMemcpy(h, mm, 16, hipMemcpyDeviceToHost);
+    hipMemcpy(e, ex, sizeof(e), hipMemcpyDeviceToHost);
+    for (unsigned long long k = 0; k < h[1] && k < 8; ++k) printf("  example: n = %08x  d = %08x\n", e[2 * k], e[2 * k + 1]);
+    printf("RESULT %u d-blocks of 2^17 x 2^23 numerators: %llu mismatches\n", count, h[0]);
+    return h[0] ? 1 : 0;
+}
