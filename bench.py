@@ -34,7 +34,7 @@ FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 GPU_CLOCK_HZ = 2.4e9           # the same table's engine clock (the PMC passes measured 2.37e9 under this kernel)
 C2 = (1920, 1080, 256)         # BASELINE.json configs[1]
 C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
-TRAFFIC_JSON = os.path.join("profiles", "r2", "c2_bench", "traffic.json")
+TRAFFIC_JSON = os.path.join("profiles", "r3", "c2_bench_final", "traffic.json")
 
 
 def weak_frame(n_gpus):

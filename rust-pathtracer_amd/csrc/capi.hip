@@ -188,10 +188,10 @@ static uint32_t env_lanes(const char* name, long dflt)
 // Scheduling knobs (they change when work runs, never its result): lanes that must be waiting before a wave
 // runs a block.
 static uint32_t shade_threshold() { static const uint32_t v = env_lanes("RPT_SHADE_THRESHOLD", 56); return v; }
-static uint32_t finish_threshold() { static const uint32_t v = env_lanes("RPT_FINISH_THRESHOLD", 16); return v; }
+static uint32_t finish_threshold() { static const uint32_t v = env_lanes("RPT_FINISH_THRESHOLD", 24); return v; }
 static uint32_t sdf_march_min_lanes(bool two_rooms)
 {
-    static const uint32_t two = env_lanes("RPT_SDF_MARCH_MIN_LANES", 12), three = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8);
+    static const uint32_t two = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8), three = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8);
     return two_rooms ? two : three;
 }
 static uint32_t sdf_pool_shade_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_SHADE_LANES", 48); return v; }
@@ -408,7 +408,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     rp.pool_min_batch = sdf_pool_min_batch();
     rp.pool_patience = sdf_pool_patience();
     rp.shade_threshold = shade_threshold();
-    // (small scenes' megakernel only; 16 and 24 are within noise of each other, +5.9 % over finishing un-voted)
+    // (small scenes' megakernel only; 8 ... 48 are within 2 % of each other, +5.9 % over finishing un-voted)
     rp.finish_threshold = finish_threshold();
     rp.compact = ((flags & RPT_RENDER_SMALL_COMPACT) || spp <= compact_max_spp()) ? 1u : 0u;
     rp.march_min_lanes = sdf_march_min_lanes(rp.sdf_resumable_march == 4u);

@@ -28,7 +28,7 @@ RPT_DEV void mat_finalize(Mat& m)                                   // material.
 {
     m.roughness = rmax(m.roughness, 0.01f);
     m.clearcoat_roughness = mixf(0.1f, 0.001f, m.clearcoat_gloss);
-    float aspect = __builtin_sqrtf(1.0f - m.anisotropic * 0.9f);
+    float aspect = fsqrt(1.0f - m.anisotropic * 0.9f);
     m.ax = rmax(fdiv(m.roughness, aspect), 0.001f);
     m.ay = rmax(m.roughness * aspect, 0.001f);
 }
@@ -52,8 +52,8 @@ RPT_DEV v3 sample_gtr1(float rgh, float r1)                         // tracer.rs
     float a = rmax(0.001f, rgh);
     float a2 = a * a;
     float phi = r1 * kTwoPi;
-    float cos_theta = __builtin_sqrtf(fdiv(1.0f - rpt_powf(a2, 1.0f - r1), 1.0f - a2));
-    float sin_theta = clamp01(__builtin_sqrtf(1.0f - (cos_theta * cos_theta)));
+    float cos_theta = fsqrt(fdiv(1.0f - rpt_powf(a2, 1.0f - r1), 1.0f - a2));
+    float sin_theta = clamp01(fsqrt(1.0f - (cos_theta * cos_theta)));
     float sin_phi, cos_phi;
     rpt_sincosf(phi, &sin_phi, &cos_phi);
     return mk3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
@@ -64,17 +64,17 @@ RPT_DEV v3 sample_ggxvndf(v3 v, float ax, float ay, float r1, float r2)   // tra
     v3 vh = norm3(mk3(ax * v.x, ay * v.y, v.z));
     float lensq = vh.x * vh.x + vh.y * vh.y;
     v3 t_1 = mk3(1.0f, 0.0f, 0.0f);
-    if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), fdiv(1.0f, __builtin_sqrtf(lensq)));
+    if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), fdiv(1.0f, fsqrt(lensq)));
     v3 t_2 = cross3(vh, t_1);
-    float r = __builtin_sqrtf(r1);
+    float r = fsqrt(r1);
     float phi = (2.0f * kPi) * r2;
     float sn, cs;
     rpt_sincosf(phi, &sn, &cs);
     float t1 = r * cs;
     float t2 = r * sn;
     float s = 0.5f * (1.0f + vh.z);
-    t2 = (1.0f - s) * __builtin_sqrtf(1.0f - t1 * t1) + s * t2;
-    v3 nh = t1 * t_1 + t2 * t_2 + __builtin_sqrtf(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
+    t2 = (1.0f - s) * fsqrt(1.0f - t1 * t1) + s * t2;
+    v3 nh = t1 * t_1 + t2 * t_2 + fsqrt(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
     return norm3(mk3(ax * nh.x, ay * nh.y, rmax(0.0f, nh.z)));
 }
 
@@ -82,7 +82,7 @@ RPT_DEV float smithg(float ndotv, float alphag)                     // tracer.rs
 {
     float a = alphag * alphag;
     float b = ndotv * ndotv;
-    return fdiv(2.0f * ndotv, ndotv + __builtin_sqrtf(a + b - a * b));
+    return fdiv(2.0f * ndotv, ndotv + fsqrt(a + b - a * b));
 }
 
 RPT_DEV float luminance(v3 c)                                       // tracer.rs:284
@@ -110,14 +110,14 @@ RPT_DEV float smithganiso(float ndotv, float vdotx, float vdoty, float ax, float
     float a = vdotx * ax;
     float b = vdoty * ay;
     float c = ndotv;
-    return fdiv(2.0f * ndotv, ndotv + __builtin_sqrtf(a * a + b * b + c * c));
+    return fdiv(2.0f * ndotv, ndotv + fsqrt(a * a + b * b + c * c));
 }
 
 RPT_DEV float dielectric_fresnel(float cos_theta_i, float eta)      // tracer.rs:308
 {
     float sin_theta_tsq = eta * eta * (1.0f - cos_theta_i * cos_theta_i);
     if (sin_theta_tsq > 1.0f) return 1.0f;
-    float cos_theta_t = __builtin_sqrtf(rmax(1.0f - sin_theta_tsq, 0.0f));
+    float cos_theta_t = fsqrt(rmax(1.0f - sin_theta_tsq, 0.0f));
     float rs = fdiv(eta * cos_theta_t - cos_theta_i, eta * cos_theta_t + cos_theta_i);
     float rp = fdiv(eta * cos_theta_i - cos_theta_t, eta * cos_theta_i + cos_theta_t);
     return 0.5f * (rs * rs + rp * rp);
@@ -125,14 +125,14 @@ RPT_DEV float dielectric_fresnel(float cos_theta_i, float eta)      // tracer.rs
 
 RPT_DEV v3 cosine_sample_hemisphere(float r1, float r2)             // tracer.rs:324
 {
-    float r = __builtin_sqrtf(r1);
+    float r = fsqrt(r1);
     float phi = kTwoPi * r2;
     float sn, cs;
     rpt_sincosf(phi, &sn, &cs);
     v3 dir;
     dir.x = r * cs;
     dir.y = r * sn;
-    dir.z = __builtin_sqrtf(rmax(0.0f, 1.0f - dir.x * dir.x - dir.y * dir.y));
+    dir.z = fsqrt(rmax(0.0f, 1.0f - dir.x * dir.x - dir.y * dir.y));
     return dir;
 }
 
@@ -253,7 +253,7 @@ RPT_DEV v3 refract3(v3 i, v3 n, float eta)                                      
     float ndi = dot3(n, i);
     float k = 1.0f - eta * eta * (1.0f - ndi * ndi);
     if (k < 0.0f) return mk3(0.0f, 0.0f, 0.0f);
-    return eta * i - (eta * ndi + __builtin_sqrtf(k)) * n;
+    return eta * i - (eta * ndi + fsqrt(k)) * n;
 }
 
 // What disney_sample (tracer.rs:449-486) and disney_eval (tracer.rs:559-591) both
@@ -314,7 +314,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
     const float phi = kTwoPi * (is_c ? r1 : r2);                    // tracer.rs:329, 247, 267
     float sn, cs;
     rpt_sincosf(phi, &sn, &cs);
-    const float rs = __builtin_sqrtf(r1);                           // tracer.rs:327, 266
+    const float rs = fsqrt(r1);                           // tracer.rs:327, 266
 
     v3 pre;                    // what the arm normalises: l + v (diffuse), reflect / refract(-v, h) (the others)
     v3 other;                  // the arm's other vector: l (diffuse), h (the others)
@@ -325,15 +325,15 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
         v3 l;                                                       // cosine_sample_hemisphere, tracer.rs:324
         l.x = rs * cs;
         l.y = rs * sn;
-        l.z = __builtin_sqrtf(rmax(0.0f, 1.0f - l.x * l.x - l.y * l.y));
+        l.z = fsqrt(rmax(0.0f, 1.0f - l.x * l.x - l.y * l.y));
         pre = l + v;
         other = l;
     } else if (is_c) {
         RPT_PROF(PB_LOBE_CLEARCOAT);
         float a = rmax(0.001f, m.clearcoat_roughness);              // sample_gtr1, tracer.rs:242 (r2 is unused there)
         float a2 = a * a;
-        float cos_theta = __builtin_sqrtf(fdiv(1.0f - rpt_powf(a2, 1.0f - r1), 1.0f - a2));
-        float sin_theta = clamp01(__builtin_sqrtf(1.0f - (cos_theta * cos_theta)));
+        float cos_theta = fsqrt(fdiv(1.0f - rpt_powf(a2, 1.0f - r1), 1.0f - a2));
+        float sin_theta = clamp01(fsqrt(1.0f - (cos_theta * cos_theta)));
         v3 h = mk3(sin_theta * cs, sin_theta * sn, cos_theta);
         if (h.z < 0.0f) h = -h;
         pre = reflect3(-v, h);
@@ -343,13 +343,13 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
         v3 vh = norm3(mk3(m.ax * v.x, m.ay * v.y, v.z));            // sample_ggxvndf, tracer.rs:256
         float lensq = vh.x * vh.x + vh.y * vh.y;
         v3 t_1 = mk3(1.0f, 0.0f, 0.0f);
-        if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), fdiv(1.0f, __builtin_sqrtf(lensq)));
+        if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), fdiv(1.0f, fsqrt(lensq)));
         v3 t_2 = cross3(vh, t_1);
         float t1 = rs * cs;
         float t2 = rs * sn;
         float s = 0.5f * (1.0f + vh.z);
-        t2 = (1.0f - s) * __builtin_sqrtf(1.0f - t1 * t1) + s * t2;
-        v3 nh = t1 * t_1 + t2 * t_2 + __builtin_sqrtf(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
+        t2 = (1.0f - s) * fsqrt(1.0f - t1 * t1) + s * t2;
+        v3 nh = t1 * t_1 + t2 * t_2 + fsqrt(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
         v3 h = norm3(mk3(m.ax * nh.x, m.ay * nh.y, rmax(0.0f, nh.z)));
         if (h.z < 0.0f) h = -h;
         float fresnel = disney_fresnel(m, eta, dot3(l_io, h), dot3(v, h));
@@ -400,8 +400,8 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
             }
             const float n_v = is_c ? v.z : __builtin_fabsf(v.z);
             const float n_l = is_c ? l.z : __builtin_fabsf(l.z);
-            const float g_v = fdiv(2.0f * n_v, n_v + __builtin_sqrtf(e_v));
-            const float g_l = fdiv(2.0f * n_l, n_l + __builtin_sqrtf(e_l));
+            const float g_v = fdiv(2.0f * n_v, n_v + fsqrt(e_v));
+            const float g_l = fdiv(2.0f * n_l, n_l + fsqrt(e_l));
             const float g = g_v * g_l;                              // clearcoat: smithg(l) * smithg(v); specular: g1 * smithganiso(l)
             // pdf: clearcoat d * h.z * (1 / (4 vdh)); specular (g1 * d) / (4 v.z)
             const float q = fdiv(is_c ? 1.0f : g_v * d, 4.0f * (is_c ? vdh : v.z));

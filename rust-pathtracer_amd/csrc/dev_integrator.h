@@ -33,7 +33,7 @@ RPT_DEV bool hit_sphere(const RayD& ray, v3 center, float radius, float& t)
     float d2 = dot3(l, l) - tca * tca;
     float radius2 = radius * radius;
     if (d2 > radius2) return false;
-    float thc = __builtin_sqrtf(radius2 - d2);
+    float thc = fsqrt(radius2 - d2);
     float t0 = tca - thc;
     float t1 = tca + thc;
     if (t0 > t1) { float tmp = t0; t0 = t1; t1 = tmp; }
@@ -92,8 +92,8 @@ RPT_DEV float sdf_prim(const DevSdfPrim& pr, v3 p)
 {
     v3 q = p - mk3(pr.cx, pr.cy, pr.cz);
     if (pr.kind == RPT_SDF_TORUS_Y) {
-        float qx = __builtin_sqrtf(q.x * q.x + q.z * q.z) - pr.p0;
-        return __builtin_sqrtf(qx * qx + q.y * q.y) - pr.p1;
+        float qx = fsqrt(q.x * q.x + q.z * q.z) - pr.p0;
+        return fsqrt(qx * qx + q.y * q.y) - pr.p1;
     }
     return len3(q) - pr.p0;
 }
@@ -533,7 +533,7 @@ RPT_DEV void sample_light(const S& sc, const DevLight& L, v3 scatter_pos, LightS
     v3 lpos = mk3(L.px, L.py, L.pz);
     v3 c2s = scatter_pos - lpos;
     float dist_to_center = len3(c2s);
-    float r = __builtin_sqrtf(rmax(0.0f, 1.0f - r1 * r1));          // uniform_sample_hemisphere
+    float r = fsqrt(rmax(0.0f, 1.0f - r1 * r1));          // uniform_sample_hemisphere
     float phi = kTwoPi * r2;
     float sn, cs;
     rpt_sincosf(phi, &sn, &cs);

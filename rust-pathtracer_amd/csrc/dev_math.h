@@ -105,12 +105,32 @@ RPT_DEV v3 divs3_norm(v3 a, float len)
 }
 #endif
 
+// ---- square root ---------------------------------------------------------------------------------------------
+// The same idea for f32::sqrt.  hipcc's correctly rounded sqrtf scales tiny arguments, takes v_sqrt_f32 (1 ulp), tests both neighbours
+// with an fma each and fixes zeros / infinities up: ~14 instructions, ~9 deep.  Inside [2^-60, 2^61)
+//     s0 = v_sqrt_f32(x);  h = 0.5 * v_rsq_f32(x);  s = fma(fma(-s0, s0, x), h, s0)
+// — one correction by the residual — is the correctly rounded root for EVERY input: tools/proofs/sqrt_exhaustive.hip compares it
+// with hipcc's sqrtf on all 121 * 2^23 floats of that range on gfx950 (0 mismatches; the variant with v_rcp_f32(s0) has 60).  Everything
+// else — zeros, negatives, infinities, NaNs, denormals, the far ends of the range — takes hipcc's sqrtf in the lanes concerned.
+#ifdef RPT_PLAIN_SQRT                                               // A/B build
+RPT_DEV float fsqrt(float x) { return __builtin_sqrtf(x); }
+#else
+RPT_DEV float fsqrt(float x)
+{
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    float s = __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * __builtin_amdgcn_rsqf(x), s0);
+    const bool ok = ((rpt_f2u(x) >> 23) - 67u) <= 120u;             // positive, 2^-60 <= x < 2^61
+    if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) s = __builtin_sqrtf(x); }
+    return s;
+}
+#endif
+
 RPT_DEV float dot3(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }       // fx.rs:335
 RPT_DEV v3 cross3(v3 a, v3 b)                                                      // fx.rs:339
 {
     return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
 }
-RPT_DEV float len3(v3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }   // fx.rs:331
+RPT_DEV float len3(v3 a) { return fsqrt(a.x * a.x + a.y * a.y + a.z * a.z); }   // fx.rs:331
 RPT_DEV v3 norm3(v3 a) { return divs3_norm(a, len3(a)); }                                    // fx.rs:307 (three divides by the length)
 RPT_DEV v3 mix3(v3 a, v3 b, float v)                                               // math.rs:34
 {

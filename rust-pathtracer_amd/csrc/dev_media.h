@@ -39,7 +39,7 @@ RPT_DEV float rmin(float self, float other)
 RPT_DEV float phase_hg(float cos_theta, float g)
 {
     const float denom = 1.0f + g * g + 2.0f * g * cos_theta;
-    return fdiv(kInv4Pi * (1.0f - g * g), denom * __builtin_sqrtf(denom));
+    return fdiv(kInv4Pi * (1.0f - g * g), denom * fsqrt(denom));
 }
 
 RPT_DEV v3 sample_hg(v3 v, float g, float r1, float r2)
@@ -51,7 +51,7 @@ RPT_DEV v3 sample_hg(v3 v, float g, float r1, float r2)
         cos_theta = fdiv(-(1.0f + g * g - sqr_term * sqr_term), 2.0f * g);
     }
     const float phi = r1 * kTwoPi;
-    const float sin_theta = clamp01(__builtin_sqrtf(1.0f - (cos_theta * cos_theta)));
+    const float sin_theta = clamp01(fsqrt(1.0f - (cos_theta * cos_theta)));
     float sin_phi, cos_phi;
     rpt_sincosf(phi, &sin_phi, &cos_phi);
     v3 t, b;

@@ -285,7 +285,7 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
         uint32_t c_k = 0u;
         bool parked = false;
         auto resolve = [&](float tca, float rd, uint32_t kk) {
-            const float thc = __builtin_sqrtf(rd);
+            const float thc = fsqrt(rd);
             float t0 = tca - thc;
             float t1 = tca + thc;
             if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }

@@ -144,7 +144,7 @@ RPT_DEV bool walk_cell(const SceneLarge& sc, const RayD& ray, GridWalk& g, uint3
     float c_tca0 = 0.0f, c_rd0 = 0.0f, c_tca1 = 0.0f, c_rd1 = 0.0f;
     uint32_t c_k0 = 0u, c_k1 = 0u, nc = 0u;
     auto resolve = [&](float tca, float rd, uint32_t kk) {              // hit_sphere's second half + acceptance
-        const float thc = __builtin_sqrtf(rd);
+        const float thc = fsqrt(rd);
         float t0 = tca - thc;
         float t1 = tca + thc;
         if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }

@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(256) void RPT_K(probe_math_kernel)(uint32_t fn, con
         r = (i % 3u == 0u) ? q.x : ((i % 3u == 1u) ? q.y : q.z);
         break;
     }
-    case RPT_PROBE_SQRT: r = __builtin_sqrtf(a[i]); break;
+    case RPT_PROBE_SQRT: r = fsqrt(a[i]); break;                     // the library's square root (dev_math.h)
     case RPT_PROBE_EXP: r = rpt_expf(a[i]); break;
     case RPT_PROBE_LOG: r = rpt_logf(a[i]); break;
     case RPT_PROBE_RNG: {                                            // a = seed bits, b = frame bits, i = pixel; first draw

@@ -124,6 +124,9 @@ def test_probe_library_divide_is_the_ieee_divide(rpt, torch_cuda, tracer, oracle
                        (grid_a.ravel().copy(), grid_b.ravel().copy(), "special values, all pairs")):
         assert_bit_identical(_probe(rpt, torch_cuda, tracer, A.RPT_PROBE_DIV, a, b), oracle.math(4, a, b), "fdiv, " + what)
         assert_bit_identical(_probe(rpt, torch_cuda, tracer, A.RPT_PROBE_DIV3, a, b), oracle.math(9, a, b), "divs3, " + what)
+        # the library's square root (same construction: tools/proofs/sqrt_exhaustive.hip) on the same operands
+        assert_bit_identical(_probe(rpt, torch_cuda, tracer, A.RPT_PROBE_SQRT, a), oracle.math(5, a), "fsqrt, " + what)
+        assert_bit_identical(_probe(rpt, torch_cuda, tracer, A.RPT_PROBE_SQRT, np.abs(b)), oracle.math(5, np.abs(b)), "fsqrt of |b|, " + what)
 
 
 def test_probe_rng_first_draw(rpt, torch_cuda, tracer, oracle):

@@ -45,6 +45,7 @@ VARIANTS = {
     # BASELINE.json's "scene/material/light tables staged in LDS": the headline kernel reading its tables from LDS instead of SGPRs
     "scene_in_lds": ["-DRPT_AB_KERNELS", "-DRPT_SCENE_IN_LDS"],
     "plain_divides": ["-DRPT_PLAIN_DIVIDES"],
+    "plain_sqrt": ["-DRPT_PLAIN_SQRT"],
     "scalar_plain": ["-DRPT_SCALAR_DIVIDES_PLAIN"],
     "large_w5": ["-DRPT_LARGE_WAVES_PER_SIMD=5"],
     "large_w7": ["-DRPT_LARGE_WAVES_PER_SIMD=7"],
