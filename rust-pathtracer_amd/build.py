@@ -15,7 +15,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpt_hip.so")
 SOURCES = ["kernels.hip", "kernels_fast.hip", "denoise.hip", "capi.hip"]
 # kernels_fast.hip: the same kernels with relaxed arithmetic (RPT_RENDER_FAST_MATH); every other file is strict
-EXTRA_FLAGS = {"kernels_fast.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"]}
+EXTRA_FLAGS = {"kernels_fast.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"],
+               # the denoiser's taps are independent multiply / add sequences: packed f32 instructions halve their issue slots there
+               # (the path kernels lose from SLP: it pins register pairs)
+               "denoise.hip": ["-fslp-vectorize"]}
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
 # fused operations are the explicit fma calls of rpt_strict_math.h.
 # -mllvm -disable-machine-licm: MachineLICM hoists the materialisation of ~70 literal constants (the

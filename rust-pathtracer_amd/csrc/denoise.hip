@@ -2,9 +2,9 @@
 // Readme.md:14): an edge-avoiding a-trous filter over the colour buffer, in a compressed colour space.  A separate HBM pass
 // over a ColorBuffer, not part of the render path.  Specification and parity oracle: oracle/rpt_oracle.hpp, denoise().
 //
-// Roofline: HBM.  Every iteration reads and writes the buffer once (16 B + 16 B per pixel); the nine taps of a pixel are
-// re-reads of lines its neighbours fetch (L1 / L2).  The first iteration compresses the colours (three correctly rounded
-// divides per pixel) once per LOADED pixel, through an 18 x 18 tile in LDS, instead of once per tap.
+// Roofline: HBM.  Every iteration reads and writes the buffer once (16 B + 16 B per pixel).  Iterations 0-2 (steps 1, 2, 4) stage
+// their tile + halo in LDS and take the nine taps from there; the colours are compressed once per LOADED pixel in iteration 0.
+// Later iterations (steps 8 ...: the halo would be as large as the nine taps) read their taps through L1 / L2.
 #include <hip/hip_runtime.h>
 
 #include "dev_math.h"
@@ -39,27 +39,34 @@ RPT_DEV float dn_h(int d) { return d == 0 ? 0.5f : 0.25f; }
 RPT_DEV float4 dn_finish(const DnSum& s, v3 cp, bool last, float4 orig)
 {
     const bool ok = s.wsum > 0.0f;
-    const v3 o = mk3(ok ? s.acc.x / s.wsum : cp.x, ok ? s.acc.y / s.wsum : cp.y, ok ? s.acc.z / s.wsum : cp.z);
+    const v3 m = divs3(s.acc, s.wsum);                               // (dev_math.h: three quotients, one reciprocal — the IEEE quotients)
+    const v3 o = mk3(ok ? m.x : cp.x, ok ? m.y : cp.y, ok ? m.z : cp.z);
     if (!last) return make_float4(o.x, o.y, o.z, 0.0f);
     const float inf = __builtin_inff();
     const bool finite = (__builtin_fabsf(orig.x) < inf) && (__builtin_fabsf(orig.y) < inf) && (__builtin_fabsf(orig.z) < inf);
     if (!finite) return orig;
-    return make_float4(o.x / (1.0f - o.x), o.y / (1.0f - o.y), o.z / (1.0f - o.z), orig.w);
+    return make_float4(fdiv(o.x, 1.0f - o.x), fdiv(o.y, 1.0f - o.y), fdiv(o.z, 1.0f - o.z), orig.w);
 }
 
-// iteration 0 (step 1): c' = c / (1 + c) once per loaded pixel, through LDS
-__global__ __launch_bounds__(256) void denoise_first_kernel(const float4* __restrict__ in, float4* __restrict__ out, uint32_t w, uint32_t h,
-                                                            float k, uint32_t last)
+// Steps 1, 2 and 4 through LDS: the workgroup's 16 x 16 pixels plus a halo of STEP — (16 + 2 STEP)^2 loads for 256 pixels (1.3, 1.6,
+// 2.3 per pixel) instead of nine taps each from L1 / L2, which is what bounded the first version (2.5 TB/s of HBM-equivalent at both
+// 1080p and 4K: the taps' L2 traffic, not the arithmetic).  FIRST: the source is the caller's buffer and c' = c / (1 + c) is computed
+// once per LOADED pixel (three divides), not once per tap.
+template <int STEP, bool FIRST>
+__global__ __launch_bounds__(256) void denoise_tile_kernel(const float4* __restrict__ src, const float4* __restrict__ orig_in, float4* __restrict__ out,
+                                                           uint32_t w, uint32_t h, float k, uint32_t last)
 {
-    __shared__ float s_c[3][18 * 18];
+    constexpr int T = 16 + 2 * STEP;
+    __shared__ float s_c[3][T * T];
     const int x0 = (int)blockIdx.x * 16, y0 = (int)blockIdx.y * 16;
-    for (uint32_t e = threadIdx.x; e < 324u; e += 256u) {
-        const int lx = (int)(e % 18u), ly = (int)(e / 18u);
-        const int gx = x0 + lx - 1, gy = y0 + ly - 1;
+    for (uint32_t e = threadIdx.x; e < (uint32_t)(T * T); e += 256u) {
+        const int lx = (int)(e % (uint32_t)T), ly = (int)(e / (uint32_t)T);
+        const int gx = x0 + lx - STEP, gy = y0 + ly - STEP;
         float c0 = __builtin_nanf(""), c1 = c0, c2 = c0;              // outside the image: NaN, i.e. a tap that is skipped
         if (gx >= 0 && gy >= 0 && gx < (int)w && gy < (int)h) {
-            const float4 v = in[(size_t)gy * w + (size_t)gx];
-            c0 = v.x / (1.0f + v.x); c1 = v.y / (1.0f + v.y); c2 = v.z / (1.0f + v.z);
+            const float4 v = src[(size_t)gy * w + (size_t)gx];
+            if (FIRST) { c0 = fdiv(v.x, 1.0f + v.x); c1 = fdiv(v.y, 1.0f + v.y); c2 = fdiv(v.z, 1.0f + v.z); }
+            else { c0 = v.x; c1 = v.y; c2 = v.z; }
         }
         s_c[0][e] = c0; s_c[1][e] = c1; s_c[2][e] = c2;
     }
@@ -67,19 +74,19 @@ __global__ __launch_bounds__(256) void denoise_first_kernel(const float4* __rest
     const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
     const uint32_t x = (uint32_t)x0 + tx, y = (uint32_t)y0 + ty;
     if (x >= w || y >= h) return;
-    const uint32_t ce = (ty + 1u) * 18u + tx + 1u;
+    const int ce = (int)((ty + (uint32_t)STEP) * (uint32_t)T + tx + (uint32_t)STEP);
     const v3 cp = mk3(s_c[0][ce], s_c[1][ce], s_c[2][ce]);
     DnSum s{mk3(0.0f, 0.0f, 0.0f), 0.0f};
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
-            const uint32_t e = (uint32_t)((int)ce + dy * 18 + dx);
+            const int e = ce + dy * STEP * T + dx * STEP;
             dn_tap(s, cp, mk3(s_c[0][e], s_c[1][e], s_c[2][e]), dn_h(dy) * dn_h(dx), k);
         }
     const size_t p = (size_t)y * w + x;
     float4 orig = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (last) orig = in[p];
+    if (last) orig = orig_in[p];
     out[p] = dn_finish(s, cp, last != 0u, orig);
 }
 
@@ -123,8 +130,12 @@ hipError_t denoise(const float* in, float* out, float* scratch, uint32_t width, 
     for (uint32_t i = 0; i < iterations; ++i) {
         const bool last = i + 1u == iterations;
         float4* dst = (float4*)(((iterations - 1u - i) & 1u) ? scratch : out);
-        if (i == 0) hipLaunchKernelGGL(denoise_first_kernel, grid, wg, 0, st, (const float4*)in, dst, width, height, k, last ? 1u : 0u);
-        else hipLaunchKernelGGL(denoise_step_kernel, grid, wg, 0, st, cur, (const float4*)in, dst, width, height, 1 << i, k, last ? 1u : 0u);
+        const float4* orig = (const float4*)in;
+        const uint32_t l = last ? 1u : 0u;
+        if (i == 0) hipLaunchKernelGGL((denoise_tile_kernel<1, true>), grid, wg, 0, st, orig, orig, dst, width, height, k, l);
+        else if (i == 1) hipLaunchKernelGGL((denoise_tile_kernel<2, false>), grid, wg, 0, st, cur, orig, dst, width, height, k, l);
+        else if (i == 2) hipLaunchKernelGGL((denoise_tile_kernel<4, false>), grid, wg, 0, st, cur, orig, dst, width, height, k, l);
+        else hipLaunchKernelGGL(denoise_step_kernel, grid, wg, 0, st, cur, orig, dst, width, height, 1 << i, k, l);
         cur = dst;
         k = k * 4.0f;
     }
