@@ -435,7 +435,7 @@ def main():
         algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
         hbm = algo_bytes / avg_kernel_s / 1e9
         launches = -(-spp // 512)                 # the kernel's LDS tables hold 512 samples: longer batches are split
-        kernel = "render_small_regen_kernel" if spp > 2 else "render_small_compact_kernel"     # (capi.hip: RPT_COMPACT_MAX_SPP)
+        kernel = "render_small_regen_kernel" if spp > 1 else "render_small_compact_kernel"     # (capi.hip: RPT_COMPACT_MAX_SPP)
         roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels)
         roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
                             "rounded f32 divide or sqrt costs 12-15 VALU instructions on gfx950; kernel_ms = HIP events on the launch stream")

@@ -302,10 +302,10 @@ enum {
     RPT_RENDER_LARGE_WAVEFRONT = 1u << 6,
     RPT_RENDER_LARGE_MEGAKERNEL = 1u << 7,
     /* Small scenes without an SDF object: use the kernel that keeps the workgroup's 256 paths in LDS and re-deals them to its
-     * threads before every stage.  It is what a launch of ONE or TWO samples per pixel takes by default — the
-     * reference's own usage, where the megakernel has little to regenerate and its waves drain (+13..23 % at one sample) —
-     * and slower than the megakernel from three samples per launch up; the flag forces it at any sample count (A/B, tests).
-     * Same image bit for bit. */
+     * threads before every stage.  It is what a launch of ONE sample per pixel takes by default — the reference's
+     * own usage, one render() per redraw, where the megakernel has nothing to regenerate over and its waves drain (+4 % at 1080p,
+     * more on small frames) — and slower than the megakernel from two samples per launch up; the flag forces it at any sample
+     * count (A/B, tests).  Same image bit for bit. */
     RPT_RENDER_SMALL_COMPACT = 1u << 8,
     /* Scenes with an SDF object: the same idea with the sphere march as one of the stages (paths in LDS, marching paths
      * re-dealt every few iterations).  Same image bit for bit; measured SLOWER than the default march kernel (1.7 vs 2.4

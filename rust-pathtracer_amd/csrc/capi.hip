@@ -212,8 +212,9 @@ static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels, uint32_t spp)
     if (flags & RPT_RENDER_LARGE_MEGAKERNEL) return false;
     return tile_pixels >= kWavefrontMinPixels && spp <= kWavefrontMaxSpp;
 }
-// Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel)
-static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 2u; return v; }
+// Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel).
+// (1 since round 3: 1080p, 1 spp 7.12 vs 6.83 Gsamples/s for the megakernel, 2 spp 7.01 vs 7.39: profiles/r3/spp_curve.txt)
+static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 1u; return v; }
 // SDF scenes: RPT_SDF_FORM=compact|march overrides the flag (A/B runs of unmodified callers)
 static bool sdf_compact_wanted(uint32_t flags)
 {
