@@ -43,6 +43,11 @@ struct DevState {
     size_t wf_bytes = 0;
     float* dn = nullptr;              // the denoiser's intermediate buffer, grown on demand
     size_t dn_bytes = 0;
+    // `wf` and `dn` are scratch of the CONTEXT, while rpt_render_device / rpt_denoise_device run on whatever stream the caller
+    // passes: a use on another stream than the previous one waits for that one's event (same stream: ordered anyway)
+    hipEvent_t wf_done = nullptr, dn_done = nullptr;
+    hipStream_t wf_stream = nullptr, dn_stream = nullptr;
+    bool wf_used = false, dn_used = false;
     ncclComm_t comm = nullptr;
 };
 
@@ -265,6 +270,8 @@ static void free_dev(DevState& d)
     if (d.ev_begin) (void)hipEventDestroy(d.ev_begin);
     if (d.ev_end) (void)hipEventDestroy(d.ev_end);
     if (d.ev_ready) (void)hipEventDestroy(d.ev_ready);
+    if (d.wf_done) (void)hipEventDestroy(d.wf_done);
+    if (d.dn_done) (void)hipEventDestroy(d.dn_done);
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d = DevState();
 }
@@ -290,7 +297,9 @@ static int open_dev(DevState& d, int device_id, int rank, const char* who)
     DeviceGuard guard(device_id);
     if (guard.status != hipSuccess || hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&d.ev_begin) != hipSuccess || hipEventCreate(&d.ev_end) != hipSuccess ||
-        hipEventCreateWithFlags(&d.ev_ready, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&d.ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d.wf_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d.dn_done, hipEventDisableTiming) != hipSuccess) {
         set_err(nullptr, "%s: cannot create a stream on device %d", who, device_id);
         free_dev(d);
         return RPT_ERR_HIP;
@@ -481,6 +490,8 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         scs_dev = d.scene_small_dev;
     }
 
+    if (wavefront && d.wf_used && d.wf_stream != stream) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, d.wf_done, 0));   // the path buffers are the context's
+
     // The LDS tables of the regenerating kernel hold a bounded number of samples: larger batches are
     // split into consecutive launches (the running mean carries over in the framebuffer).
     const uint32_t max_chunk = rptlaunch::max_spp_per_launch();
@@ -493,6 +504,11 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         else if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
         else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev, ctx->media));
         done += chunk;
+    }
+    if (wavefront) {
+        RPT_HIP_CHECK(ctx, hipEventRecord(d.wf_done, stream));
+        d.wf_stream = stream;
+        d.wf_used = true;
     }
     return RPT_OK;
 }
@@ -1254,7 +1270,14 @@ int rpt_denoise_device(rpt_ctx* ctx, const float* pixels_dev, float* out_dev, ui
         RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.dn, bytes));
         d.dn_bytes = bytes;
     }
+    const bool uses_scratch = iterations > 1u;
+    if (uses_scratch && d.dn_used && d.dn_stream != (hipStream_t)stream) RPT_HIP_CHECK(ctx, hipStreamWaitEvent((hipStream_t)stream, d.dn_done, 0));
     RPT_HIP_CHECK(ctx, rptlaunch::denoise(pixels_dev, out_dev, d.dn, width, height, iterations, edge_k, (hipStream_t)stream));
+    if (uses_scratch) {
+        RPT_HIP_CHECK(ctx, hipEventRecord(d.dn_done, (hipStream_t)stream));
+        d.dn_stream = (hipStream_t)stream;
+        d.dn_used = true;
+    }
     return RPT_OK;
 }
 

@@ -97,3 +97,35 @@ def test_light_types_in_a_large_scene(rpt, oracle, torch_cuda):
     got = _render(rpt, torch_cuda, s, w, h, spp, seed=2)
     want = oracle.render(s.describe(), w, h, spp, seed=2)
     assert_bit_identical(got, want, "large scene with rectangular and distant lights")
+
+
+def test_context_scratch_is_ordered_across_streams(rpt, oracle):
+    """The wavefront form's path buffers and the denoiser's intermediate image belong to the CONTEXT, while rpt_render_device and
+    rpt_denoise_device run on whatever stream the caller passes: two launches on two streams, nothing ordering them on the
+    host side, must both come out right (the second waits on the device for the first one's event)."""
+    import torch
+    from rust_pathtracer_amd import scenes
+    from test_gpu_parity import assert_bit_identical
+    s = scenes.random_spheres_scene(n_spheres=400, n_lights=4)
+    w, h, spp = 96, 64, 3
+    t = rpt.Tracer(s, device=0, seed=5)
+    t.flags = rpt._abi.RPT_RENDER_LARGE_WAVEFRONT
+    want = oracle.render(s.describe(), w, h, spp, seed=5)
+    bufs = [rpt.DeviceColorBuffer(w, h) for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    torch.cuda.synchronize()
+    for i, b in enumerate(bufs):
+        with torch.cuda.stream(streams[i % 2]):
+            t.render_n(b, spp)
+    torch.cuda.synchronize()
+    for i, b in enumerate(bufs):
+        assert_bit_identical(b.pixels.cpu().numpy(), want, "wavefront launch %d on stream %d" % (i, i % 2))
+    dn_want = oracle.denoise(want, w, h, 4, 2.0)
+    outs = []
+    for i in range(4):
+        with torch.cuda.stream(streams[i % 2]):
+            outs.append(bufs[i].denoise(4, 2.0))
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert_bit_identical(o.pixels.cpu().numpy(), dn_want, "denoise %d on stream %d" % (i, i % 2))
+    t.close()
