@@ -424,9 +424,14 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     rp.march_min_lanes = sdf_march_min_lanes(rp.sdf_resumable_march == 4u);
     {
         static const char* mega = getenv("RPT_LARGE_MEGA");          // pair | plain: which megakernel large scenes with a grid take (A/B)
-        static const uint32_t refill = getenv("RPT_PAIR_REFILL_AT") ? ((uint32_t)atoi(getenv("RPT_PAIR_REFILL_AT")) & 63u) : 32u;
+        static const uint32_t refill = getenv("RPT_PAIR_REFILL_AT") ? ((uint32_t)atoi(getenv("RPT_PAIR_REFILL_AT")) & 63u) : (mega && mega[0] == 'c' ? 12u : 32u);
+        static const uint32_t wait_at = getenv("RPT_CARRY_WAIT_AT") ? (uint32_t)atoi(getenv("RPT_CARRY_WAIT_AT")) : 48u;
+        static const uint32_t walk_min = getenv("RPT_CARRY_WALK_MIN") ? (uint32_t)atoi(getenv("RPT_CARRY_WALK_MIN")) : 8u;
         rp.large_pair_walk = (mega && mega[0] == 'p' && mega[1] == 'a') ? 1u : 0u;
+        rp.large_carry_walk = (mega && mega[0] == 'c') ? 1u : 0u;
         rp.walk_refill_at = refill;
+        rp.carry_wait_at = wait_at < 1u ? 1u : wait_at;
+        rp.carry_walk_min = walk_min;
     }
     if (flags & RPT_RENDER_RUSSIAN_ROULETTE) { scs.flags |= kSceneFlagRussianRoulette; scl.flags |= kSceneFlagRussianRoulette; }
     if (rp.rows_local == 0) return RPT_OK;

@@ -142,6 +142,9 @@ struct RenderParams {
     uint32_t sdf_compact_steps;    // SDF scenes, compacting kernel: march iterations per pass
     uint32_t large_pair_walk;      // large scenes with a grid: the megakernel that walks a bounce's two rays in one loop (kernels.hip, render_large_pair_kernel)
     uint32_t walk_refill_at;       // ... its idle lanes set up their next ray when at most this many lanes still walk
+    uint32_t large_carry_walk;     // large scenes with a grid: the megakernel whose walks are a scheduling state of the lane (kernel_large_carry.h)
+    uint32_t carry_wait_at;        // ... it leaves the walk loop for the block when this many lanes are through their walks ...
+    uint32_t carry_walk_min;       // ... or when fewer than this many still walk (and somebody waits)
     uint32_t compact;              // small scenes: the kernel that re-deals its workgroup's paths before every stage (few samples per launch)
 };
 

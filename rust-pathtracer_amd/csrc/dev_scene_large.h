@@ -43,6 +43,8 @@ struct SceneLarge {
     float gmin[3], gmax[3], cell_size[3], inv_cell_size[3];
     float gcenter[3];
     float safe_r2;                    // rays starting farther than sqrt(safe_r2) from gcenter use the brute-force loop
+    float near_r2;                    // rays starting within sqrt(near_r2) of gcenter use the second tier of cell lists (less padding:
+    uint32_t near_cell_off;           // shorter), cell_start[near_cell_off + c]; near_r2 < 0: there is none
     const uint32_t* cell_start;
     const uint32_t* cell_items;
     const float4* cell_spheres;       // spheres[cell_items[k]] stored at k: a cell's spheres are one dependent load away, not two
@@ -123,13 +125,24 @@ struct GridWalk {
     float tmx, tmy, tmz;       // t at which the ray leaves the current cell along each axis
     float tdx, tdy, tdz;
     float t_end;               // t at which the ray leaves the grid
+    uint32_t coff;             // the tier of cell lists this ray walks: 0 or near_cell_off (grid_tier)
     bool alive;
 };
+
+// The tier of cell lists that serves a ray: the padding a tier's lists carry against the reference's cancellation error grows
+// with the square of the farthest origin it serves, so origins near the grid (every bounce of a camera inside the scene) get
+// their own, far shorter lists.  (A NaN origin compares false: the far tier; grid_usable sends it to the brute-force loop anyway.)
+RPT_DEV uint32_t grid_tier(const SceneLarge& sc, const RayD& ray)
+{
+    const float dx = ray.o.x - sc.gcenter[0], dy = ray.o.y - sc.gcenter[1], dz = ray.o.z - sc.gcenter[2];
+    return ((dx * dx + dy * dy + dz * dz) <= sc.near_r2) ? sc.near_cell_off : 0u;
+}
 
 RPT_DEV GridWalk grid_begin(const SceneLarge& sc, const RayD& ray)
 {
     GridWalk g;
     g.alive = false;
+    g.coff = grid_tier(sc, ray);
     // slab test against the grid box, from t = 0
     float t0 = 0.0f, t1 = 3.40282347e+38f;
     const float o[3] = {ray.o.x, ray.o.y, ray.o.z};
@@ -196,7 +209,7 @@ RPT_DEV void cell_bounds(const SceneLarge& sc, uint32_t c, uint32_t& k0, uint32_
 
 RPT_DEV uint32_t grid_cell_index(const SceneLarge& sc, const GridWalk& g)
 {
-    return ((uint32_t)g.iz * sc.gn[1] + (uint32_t)g.iy) * sc.gn[0] + (uint32_t)g.ix;
+    return ((uint32_t)g.iz * sc.gn[1] + (uint32_t)g.iy) * sc.gn[0] + (uint32_t)g.ix + g.coff;
 }
 
 // t at which the ray leaves the current cell

@@ -64,6 +64,11 @@ struct HostGrid {
     uint32_t n[3];
     float gmin[3], gmax[3], cs[3], inv_cs[3];
     float center[3], safe_r2;
+    // Two tiers of lists over the same cells: [0, ncell] for ray origins within sqrt(safe_r2) of the centre, and — the padding grows
+    // with the square of the farthest origin served — [near_off, near_off + ncell] with far shorter lists for origins within
+    // sqrt(near_r2) (every bounce ray of a camera inside the scene).  near_r2 < 0: no near tier.
+    float near_r2 = -1.0f;
+    uint32_t near_off = 0;
     std::vector<uint32_t> cell_start, items;
     // Spheres far larger than the rest (the classic r = 1000 "ground sphere") would stretch the grid's box and be listed
     // in every cell: they stay out of the grid and every walk tests them up front, like sphere 0.  Ascending indices.
@@ -101,6 +106,21 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
             hi[a] = std::max(hi[a], (double)sph[i].center[a] + sph[i].radius);
         }
     }
+    // The box also holds every point at which the reference's test can still report a hit of one of these spheres (a line that
+    // passes sqrt(r^2 + d2_err) from the centre, see below): a ray that never enters the box has nothing to find.
+    {
+        double hd = 0.0;
+        for (int a = 0; a < 3; ++a) hd += 0.25 * (hi[a] - lo[a]) * (hi[a] - lo[a]);
+        const double max_l = 7.0 * std::sqrt(hd) * 1.05 + 2.0;      // (the padded box's own half-diagonal is a little larger)
+        for (uint32_t i = 0; i < count; ++i) {
+            if (skip[i]) continue;
+            const double r = sph[i].radius, reach = std::sqrt(r * r + 1.2e-6 * max_l * max_l);
+            for (int a = 0; a < 3; ++a) {
+                lo[a] = std::min(lo[a], (double)sph[i].center[a] - reach);
+                hi[a] = std::max(hi[a], (double)sph[i].center[a] + reach);
+            }
+        }
+    }
     double ext[3], vol = 1.0;
     for (int a = 0; a < 3; ++a) {
         double pad = 1e-3 * (hi[a] - lo[a]) + 1e-3;
@@ -127,40 +147,71 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
     half_diag = std::sqrt(half_diag);
     const double safe_r = 6.0 * half_diag;
     g.safe_r2 = (float)(safe_r * safe_r);
-    const double max_l = safe_r + half_diag;                        // |sphere centre - ray origin| for usable rays
-    const double d2_err = 1.2e-6 * max_l * max_l;                   // bound on the f32 error of l.l - tca*tca
-    auto range = [&](const rpt_sphere& s, int a, int& c0, int& c1) {
-        const double r = s.radius;
-        const double pad = (std::sqrt(r * r + d2_err) - r) + 1e-3 * g.cs[a];
-        c0 = (int)std::floor(((double)s.center[a] - s.radius - pad - g.gmin[a]) / g.cs[a]);
-        c1 = (int)std::floor(((double)s.center[a] + s.radius + pad - g.gmin[a]) / g.cs[a]);
-        c0 = std::max(0, std::min((int)g.n[a] - 1, c0));
-        c1 = std::max(0, std::min((int)g.n[a] - 1, c1));
-    };
-    std::vector<size_t> counts(ncell + 1, 0);                       // size_t: the total is checked before it becomes an offset
-    for (uint32_t i = 0; i < count; ++i) {
-        if (skip[i]) continue;
-        int x0, x1, y0, y1, z0, z1;
-        range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
-        for (int z = z0; z <= z1; ++z)
-            for (int y = y0; y <= y1; ++y)
-                for (int x = x0; x <= x1; ++x) counts[((size_t)z * g.n[1] + y) * g.n[0] + x + 1] += 1;
-    }
-    for (size_t c = 0; c < ncell; ++c) counts[c + 1] += counts[c];  // counts -> exclusive prefix sums
-    if (counts[ncell] > 0x7FFFFFFFull) {
-        why = "the scene's spheres overlap too many grid cells (" + std::to_string(counts[ncell]) + " list entries; the limit is 2^31)";
-        return false;
-    }
-    g.cell_start.assign(counts.begin(), counts.end());
-    std::vector<uint32_t> cursor(g.cell_start.begin(), g.cell_start.end() - 1);
-    g.items.assign(g.cell_start[ncell], 0);
-    for (uint32_t i = 0; i < count; ++i) {                          // ascending sphere index within a cell
-        if (skip[i]) continue;
-        int x0, x1, y0, y1, z0, z1;
-        range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
-        for (int z = z0; z <= z1; ++z)
-            for (int y = y0; y <= y1; ++y)
-                for (int x = x0; x <= x1; ++x) g.items[cursor[((size_t)z * g.n[1] + y) * g.n[0] + x]++] = i;
+    const char* nr = getenv("RPT_GRID_NEAR_REACH");                // near tier's reach in half-diagonals (0: none)
+    const double near_r = (nr ? atof(nr) : 1.5) * half_diag;
+    const int n_tiers = near_r > 0.0 && near_r < safe_r ? 2 : 1;
+    g.cell_start.clear();
+    g.items.clear();
+    for (int tier = 0; tier < n_tiers; ++tier) {
+        const double max_l = (tier == 0 ? safe_r : near_r) + half_diag;     // |sphere centre - ray origin| for the rays this tier serves
+        const double d2_err = 1.2e-6 * max_l * max_l;                       // bound on the f32 error of l.l - tca*tca
+        auto range = [&](const rpt_sphere& s, int a, int& c0, int& c1) {
+            const double r = s.radius;
+            const double pad = (std::sqrt(r * r + d2_err) - r) + 1e-3 * g.cs[a];
+            c0 = (int)std::floor(((double)s.center[a] - s.radius - pad - g.gmin[a]) / g.cs[a]);
+            c1 = (int)std::floor(((double)s.center[a] + s.radius + pad - g.gmin[a]) / g.cs[a]);
+            c0 = std::max(0, std::min((int)g.n[a] - 1, c0));
+            c1 = std::max(0, std::min((int)g.n[a] - 1, c1));
+        };
+        // Within that box of cells the sphere is listed where the padded BALL reaches the cell (grown by the DDA's allowance): a
+        // reported hit point lies within sqrt(r^2 + d2_err) of the centre, so its cell is one of these.  (Border cells stand for
+        // everything outside the grid on their side — the box above is clamped — so they are kept as the box has them.)
+        auto touches = [&](const rpt_sphere& s, int x, int y, int z) {
+            static const bool ball = !(getenv("RPT_GRID_BOX_LISTS") && atoi(getenv("RPT_GRID_BOX_LISTS")) != 0);
+            if (!ball) return true;
+            const int c[3] = {x, y, z};
+            double d2 = 0.0;
+            for (int a = 0; a < 3; ++a) {
+                if (c[a] == 0 || c[a] == (int)g.n[a] - 1) continue;
+                const double lo_a = (double)g.gmin[a] + (c[a] - 1e-3) * (double)g.cs[a], hi_a = (double)g.gmin[a] + (c[a] + 1.0 + 1e-3) * (double)g.cs[a];
+                const double v = (double)s.center[a];
+                const double d = v < lo_a ? lo_a - v : (v > hi_a ? v - hi_a : 0.0);
+                d2 += d * d;
+            }
+            const double r = s.radius;
+            return d2 <= (r * r + d2_err) * (1.0 + 1e-9);
+        };
+        std::vector<size_t> counts(ncell + 1, 0);                   // size_t: the total is checked before it becomes an offset
+        for (uint32_t i = 0; i < count; ++i) {
+            if (skip[i]) continue;
+            int x0, x1, y0, y1, z0, z1;
+            range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x)
+                        if (touches(sph[i], x, y, z)) counts[((size_t)z * g.n[1] + y) * g.n[0] + x + 1] += 1;
+        }
+        const size_t first = g.items.size();                        // this tier's entries follow the previous tier's
+        counts[0] = first;
+        for (size_t c = 0; c < ncell; ++c) counts[c + 1] += counts[c];      // counts -> exclusive prefix sums (absolute offsets)
+        if (counts[ncell] > 0x7FFFFFFFull) {
+            why = "the scene's spheres overlap too many grid cells (" + std::to_string(counts[ncell]) + " list entries; the limit is 2^31)";
+            return false;
+        }
+        const size_t cs0 = g.cell_start.size();
+        g.cell_start.insert(g.cell_start.end(), counts.begin(), counts.end());
+        std::vector<uint32_t> cursor(g.cell_start.begin() + cs0, g.cell_start.end() - 1);
+        g.items.resize(counts[ncell], 0);
+        for (uint32_t i = 0; i < count; ++i) {                      // ascending sphere index within a cell
+            if (skip[i]) continue;
+            int x0, x1, y0, y1, z0, z1;
+            range(sph[i], 0, x0, x1); range(sph[i], 1, y0, y1); range(sph[i], 2, z0, z1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x)
+                        if (touches(sph[i], x, y, z)) g.items[cursor[((size_t)z * g.n[1] + y) * g.n[0] + x]++] = i;
+        }
+        if (tier == 1) { g.near_r2 = (float)(near_r * near_r); g.near_off = (uint32_t)cs0; }
     }
     return true;
 }
@@ -188,6 +239,8 @@ struct HostAccel {
             L.gcenter[a] = grid.center[a];
         }
         L.safe_r2 = grid.safe_r2;
+        L.near_r2 = grid.near_r2;
+        L.near_cell_off = grid.near_off;
         L.cell_start = reinterpret_cast<const uint32_t*>(base);
         L.cell_items = reinterpret_cast<const uint32_t*>(base + sz_cstart);
         L.cell_spheres = reinterpret_cast<const float4*>(base + sz_cstart + sz_items);

@@ -49,6 +49,8 @@ VARIANTS = {
     "scalar_plain": ["-DRPT_SCALAR_DIVIDES_PLAIN"],
     "large_w5": ["-DRPT_LARGE_WAVES_PER_SIMD=5"],
     "large_w7": ["-DRPT_LARGE_WAVES_PER_SIMD=7"],
+    "large_w6": ["-DRPT_LARGE_WAVES_PER_SIMD=6"],
+    "large_w8": ["-DRPT_LARGE_WAVES_PER_SIMD=8"],
     "large_w5_sp": ["-DRPT_LARGE_WAVES_PER_SIMD=5", "-DRPT_SCALAR_DIVIDES_PLAIN"],
     "sdf_w4": ["-DRPT_SDF_WAVES_PER_SIMD=4"],
     "sdf_w6": ["-DRPT_SDF_WAVES_PER_SIMD=6"],
