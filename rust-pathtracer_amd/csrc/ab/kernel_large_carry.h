@@ -1,4 +1,11 @@
-// kernel_large_carry.h — large scenes with a grid: the megakernel whose grid walks are a scheduling state of the lane.
+// A/B only (-DRPT_AB_KERNELS; RPT_LARGE_MEGA=carry): measured SLOWER than the shipped large-scene megakernel — 10 k spheres, 2048^2 x 32
+// spp: 1 217 Msamples/s (leave-for-the-block thresholds 32-56 lanes, refill votes 6-24: 1 021-1 166) against 1 862; every frame
+// bit-identical (profiles/r3/experiments/large_carry_walk.txt).  The schedule does what it was built for — a cell iteration runs with
+// 46-54 % of the lanes instead of 20 %, a sample takes 26-31 wave iterations instead of 69, the block runs 3.7 times per sample with
+// 70 % of the lanes — but an iteration costs 2.4x as much: the texture path (TA 75 % busy, TD 92 %, profiles/r3/c5_mem_counters/)
+// serves lanes, not waves, a fuller wave waits for the longest of more lists, and the state the block keeps alive costs 99 spilled
+// VGPRs whose traffic goes down the same path (+45 % L1 accesses per launch).
+// ab/kernel_large_carry.h — large scenes with a grid: the megakernel whose grid walks are a scheduling state of the lane.
 // Included by kernels.hip.
 //
 // render_large_regen_kernel walks inside closest_hit / any_hit: the wave leaves a walk when its LONGEST lane does, and walk
@@ -6,9 +13,10 @@
 // walk survives the loop that runs it:
 //   * WALK phase: ONE loop steps every walking lane one cell per iteration, shadow rays and path rays alike (walk_cell2: the
 //     specialised loops' cell body with the ray kind as a lane flag).  A bounce's two rays are walked back to back — the parked
-//     shadow ray of next-event estimation one bounce late, then the path ray (DeferredQuery, the wavefront form's own) — and a lane
-//     whose shadow walk ends sets up its path walk when at most `walk_refill_at` lanes still walk.
-//   * The wave leaves the loop as soon as `carry_wait_at` lanes are through both walks (or fewer than `carry_walk_min` still walk):
+//     shadow ray of next-event estimation one bounce late, then the path ray (DeferredQuery, the wavefront form's own) — and the lanes
+//     whose shadow walk has ended set up their path walks together: when `walk_refill_at` of them have gathered or fewer than
+//     `carry_walk_min` lanes still walk.
+//   * The wave leaves the loop as soon as `carry_wait_at` / 64 of its live lanes are through both walks:
 //     the stragglers PARK their walk in LDS (cell, the three exit parameters, t_end, nearest hit so far, guard: 8 dwords; the
 //     DDA increments are recomputed from the ray, three correctly rounded divides) and resume in the next WALK phase next to the
 //     fresh rays.  Nothing of a walk is live in registers across the block.
@@ -274,6 +282,3 @@ RPT_DEV void render_large_carry_body(const S& sc, const RenderParams& rp)
 }
 
 __global__ __launch_bounds__(256, RPT_LARGE_CARRY_WAVES_PER_SIMD) void RPT_K(render_large_carry_kernel)(const SceneLarge sc, const RenderParams rp) { render_large_carry_body(sc, rp); }
-#ifndef RPT_NO_MEDIA_KERNELS
-__global__ __launch_bounds__(256, RPT_LARGE_CARRY_WAVES_PER_SIMD) void RPT_K(render_large_carry_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_large_carry_body(sc, rp); }
-#endif

@@ -355,8 +355,8 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_rege
 
 #ifdef RPT_AB_KERNELS
 #include "ab/kernel_large_pair.h"
+#include "ab/kernel_large_carry.h"
 #endif
-#include "kernel_large_carry.h"
 
 // Large scenes as a wavefront (dev_wavefront.h): WALK(k) walks the rays SHADE(k-1) listed, SHADE(k) does the rest of the bounce
 // for every slot that still has work and lists the next rays.
@@ -1385,7 +1385,6 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
         const WithMedia<SceneSmallSdf> mscs(scs);
         const WithMedia<SceneLarge> mscl(scl);
         if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_media_kernel), tiles, wg, 0, st, mscl, rp);
-        else if (large && rp.large_carry_walk && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_carry_media_kernel), tiles, wg, 0, st, mscl, rp);
         else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_media_kernel), tiles, wg, 0, st, mscl, rp);
         else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_media_kernel), tiles, wg, 0, st, mscs, rp);
         else if (has_sdf && rp.sdf_resumable_march == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, mscs, rp);
@@ -1403,7 +1402,9 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #ifdef RPT_AB_KERNELS
     else if (large && rp.large_pair_walk && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_pair_kernel), tiles, wg, 0, st, scl, rp);
 #endif
+#ifdef RPT_AB_KERNELS
     else if (large && rp.large_carry_walk && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_carry_kernel), tiles, wg, 0, st, scl, rp);
+#endif
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), tiles, wg, 0, st, scl, rp);
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), tiles, wg, 0, st, scs, rp);
 #ifdef RPT_AB_KERNELS
