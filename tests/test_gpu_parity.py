@@ -344,6 +344,29 @@ def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
     t.close()
 
 
+@pytest.mark.parametrize("cam,look,reach", [((0.0, 60.0, 330.0), (0.0, 4.0, -60.0), None), ((250.0, 9.0, -60.0), (0.0, 5.0, -60.0), None),
+                                            ((0.0, 6.0, 14.0), (0.0, 2.0, -40.0), "0"), ((0.0, 6.0, 14.0), (0.0, 2.0, -40.0), "0.6")])
+def test_large_scene_both_tiers_of_cell_lists(rpt, oracle, cam, look, reach, monkeypatch):
+    """The grid keeps two tiers of cell lists (host_scene.h: less padding, shorter lists, for ray origins near the grid).  A camera
+    beyond the near tier's reach sends its primary rays through the far tier and every bounce through the near one; then the
+    benchmark's camera with the near tier switched off and with a reach that ends inside the scene (paths change tier as they
+    bounce).  All bit-identical to the oracle's ordered loop over every sphere, in both forms."""
+    from rust_pathtracer_amd import scenes
+    if reach is not None:
+        monkeypatch.setenv("RPT_GRID_NEAR_REACH", reach)              # read when the scene is uploaded
+    s = scenes.random_spheres_scene(n_spheres=1200, n_lights=9, seed=0x5EED0011)
+    s.camera = rpt.Pinhole(cam, look, 40.0)
+    w, h, spp = 112, 63, 3
+    t = rpt.Tracer(s, device=0, seed=7)
+    want = oracle.render(s.describe(), w, h, spp, seed=7)
+    for flags in (rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL, rpt._abi.RPT_RENDER_LARGE_WAVEFRONT):
+        t.flags = flags
+        buf = rpt.ColorBuffer(w, h)
+        t.render_n(buf, spp)
+        assert_bit_identical(buf.image(), want, "tiers cam=%s reach=%s flags=%d" % (cam, reach, flags))
+    t.close()
+
+
 @pytest.mark.parametrize("w,h,spp,depth,rr", [(70, 37, 5, 4, False), (33, 65, 3, 9, True), (200, 120, 2, 1, False), (64, 64, 40, 30, True)])
 def test_large_scene_wavefront_form_matches_oracle(rpt, oracle, w, h, spp, depth, rr):
     """The wavefront form of large scenes (include/rpt.h RPT_RENDER_LARGE_WAVEFRONT) over ragged tiles (sizes that are not

@@ -50,6 +50,8 @@ VARIANTS = {
     "large_w5": ["-DRPT_LARGE_WAVES_PER_SIMD=5"],
     "large_w7": ["-DRPT_LARGE_WAVES_PER_SIMD=7"],
     "large_w6": ["-DRPT_LARGE_WAVES_PER_SIMD=6"],
+    "slp": ["-fslp-vectorize"],
+    "no_max_ilp": ["-mllvm", "-amdgpu-sched-strategy=max-occupancy"],
     "large_w8": ["-DRPT_LARGE_WAVES_PER_SIMD=8"],
     "large_w5_sp": ["-DRPT_LARGE_WAVES_PER_SIMD=5", "-DRPT_SCALAR_DIVIDES_PLAIN"],
     "sdf_w4": ["-DRPT_SDF_WAVES_PER_SIMD=4"],

@@ -19,3 +19,5 @@ timed(rpt.AnalyticalScene(), 800, 600, 1, "c1 AnalyticalScene (one render() call
 timed(rpt.AnalyticalScene(), 1920, 1080, 256, "c2 AnalyticalScene")
 timed(scenes.sdf_scene(), 1920, 1080, 64, "c4 SDF sphere-march scene")
 timed(scenes.random_spheres_scene(10000, 16), 4096, 4096, 8, "c5 10k spheres + 16 lights (8 of 512 spp)")
+if len(sys.argv) > 1 and sys.argv[1] == "full":
+    timed(scenes.random_spheres_scene(10000, 16), 4096, 4096, 512, "c5 10k spheres + 16 lights (the full config)")
