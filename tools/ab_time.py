@@ -29,6 +29,7 @@ A = rpt._abi
 cfg = {"c2": (rpt.AnalyticalScene, 1920, 1080, 256, 0), "c2s": (rpt.AnalyticalScene, 1920, 1080, 32, 0), "c4": (scenes.sdf_scene, 1920, 1080, 64, 0),
        "c5": (lambda: scenes.random_spheres_scene(10000, 16), 2048, 2048, 32, A.RPT_RENDER_LARGE_MEGAKERNEL),
        "c5l": (lambda: scenes.random_spheres_scene(10000, 16), 1024, 1024, 256, A.RPT_RENDER_LARGE_MEGAKERNEL),
+       "c5x": (lambda: scenes.random_spheres_scene(10000, 16), 4096, 4096, 8, 0),
        "c5w": (lambda: scenes.random_spheres_scene(10000, 16), 2048, 2048, 8, A.RPT_RENDER_LARGE_WAVEFRONT)}[which]
 t = rpt.Tracer(cfg[0](), device=0, seed=1)
 t.flags = cfg[4]
