@@ -475,6 +475,42 @@ def test_grid_queries_equal_brute_force(rpt, torch_cuda, n_spheres, ground):
     t.close()
 
 
+@pytest.mark.parametrize("n_spheres", [800, 10000])
+def test_grid_queries_at_the_reach_of_each_tier(rpt, torch_cuda, n_spheres):
+    """The cell lists of a tier are padded for the FARTHEST origin the tier serves (host_scene.h): rays from just inside and just
+    outside the near tier's reach (1.5 half-diagonals of the grid box) and the far tier's (6), aimed to graze spheres all over the scene
+    — where the reference's f32 test is at its noisiest for that tier — must still be answered like the loop over all spheres."""
+    from rust_pathtracer_amd import scenes
+    torch = torch_cuda
+    s = scenes.random_spheres_scene(n_spheres=n_spheres, n_lights=4, seed=0x5EED0021)
+    t = rpt.Tracer(s, device=0, seed=5)
+    rng = np.random.default_rng(n_spheres + 1)
+    sph = np.array([list(c) + [r] for c, r, m in s.spheres], dtype=np.float64)
+    lo, hi = (sph[:, :3] - sph[:, 3:4]).min(0), (sph[:, :3] + sph[:, 3:4]).max(0)
+    centre, hd = 0.5 * (lo + hi), 0.5 * np.linalg.norm(hi - lo)
+    N = 400_000
+    shell = rng.choice([1.5 * 0.98, 1.5 * 0.999, 1.5 * 1.002, 1.5 * 1.03, 6.0 * 0.97, 6.0 * 0.999, 6.0 * 1.002], N)
+    u = rng.normal(size=(N, 3)); u /= np.linalg.norm(u, axis=1, keepdims=True)
+    o = centre + (shell * hd)[:, None] * u
+    pick = rng.integers(0, n_spheres, N)
+    to_c = sph[pick, :3] - o
+    dist = np.linalg.norm(to_c, axis=1, keepdims=True)
+    perp = np.cross(to_c, rng.normal(size=(N, 3))); perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    miss = sph[pick, 3:4] + rng.normal(scale=0.03, size=(N, 1)) * (1.0 + dist / 200.0)      # pass this far from the centre: grazing, in and out
+    d = to_c + perp * miss; d /= np.linalg.norm(d, axis=1, keepdims=True)
+    maxd = rng.uniform(0.5, 2.0, N) * dist[:, 0]
+    rays = torch.from_numpy(np.concatenate([o, d, maxd[:, None]], axis=1).astype(np.float32)).cuda()
+    res = []
+    for use_grid in (1, 0):
+        out = torch.zeros(N, 3, dtype=torch.int32, device="cuda")
+        rpt._lib.check(rpt.lib().rpt_probe_rays(t._h, rays.data_ptr(), out.data_ptr(), N, use_grid, None), t._h)
+        torch.cuda.synchronize()
+        res.append(out.cpu().numpy())
+    assert (res[1][:, 1] != -1).sum() > N // 10                     # grazing rays do hit
+    assert np.array_equal(res[0], res[1])
+    t.close()
+
+
 @pytest.mark.parametrize("where", ["first", "last"])
 def test_scene_with_a_giant_ground_sphere_matches_oracle(rpt, torch_cuda, oracle, where):
     from rust_pathtracer_amd import scenes
