@@ -337,12 +337,13 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 #else
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(sc, rp); }
 #endif
-// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).  7 waves per SIMD: the grid walk
-// waits on dependent loads 40 % of its time (profiles/r3/c5_megakernel), and one more wave hides more of that than the extra spills
-// cost (10 k spheres, 2048^2 x 32 spp, with dev_math.h's short division: 5 waves 1 660, 6: 1 664, 7: 1 689 Msamples/s; round 2, hipcc's
-// divide, 2048^2 x 8: 4: 1 165, 5: 1 387, 6: 1 454, 7: 1 372, 8: 1 200).
+// Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).  5 waves per SIMD: 96 VGPRs, 12 of them
+// spilled (44 B of scratch per lane).  With the two tiers of cell lists 5 / 6 / 7 waves run at 1 881 / 1 874 / 1 858 Msamples/s (10 k
+// spheres, 2048^2 x 32 spp) — and move 0.32 / 42 / 77 GB through HBM per launch: at 6 and 7 waves (80 / 72 VGPRs, 53 / 65 spilled) the
+// resident waves' scratch no longer fits the L2s (profiles/r3/c5_megakernel vs c5_megakernel_7waves).  (Before the tiers 7 waves were
+// 1.5 % ahead: 5: 1 660, 6: 1 664, 7: 1 689; round 2, hipcc's divide, 2048^2 x 8: 4: 1 165, 5: 1 387, 6: 1 454, 7: 1 372, 8: 1 200.)
 #ifndef RPT_LARGE_WAVES_PER_SIMD
-#define RPT_LARGE_WAVES_PER_SIMD 7
+#define RPT_LARGE_WAVES_PER_SIMD 5
 #endif
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
 // Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
