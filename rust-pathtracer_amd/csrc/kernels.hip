@@ -901,8 +901,10 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
-    float4* const s_sho = g_sdf_sho;                                // the parked shadow ray and light sample of each lane (dev_sdf_path.h)
-    float4* const s_shd = g_sdf_shd;
+    __shared__ float4 s_march[256];                                 // a lane's march between passes: t, t_useful, steps (bit 31: hit), accepted
+                                                                    // analytic primitives (of the path ray's march, also while the shadow ray is marched)
+    float4* const s_sho = g_sdf_sho;                                // the parked shadow ray and light sample of each lane (dev_sdf_path.h);
+    float4* const s_shd = g_sdf_shd;                                // gain.w: t_useful of the path ray's march while the shadow ray is marched first
     float4* const s_gain = g_sdf_gain;
     const uint32_t tid = threadIdx.x;
     if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
@@ -910,18 +912,15 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
     uint32_t s = 0;
     uint32_t state = S2_MARCH_P;
     PathRegs p;
-    MarchRegs m;
-    v3 mo;                                                          // origin of the march in flight
     bool pending = false;                                           // a light sample is parked, its shadow ray not answered yet
     bool lit = false;                                               // ... answered: it got through
     bool ending = false;                                            // the path is over once the parked sample is resolved
-    float np_tu = 0.0f;                                             // the path ray's march while the shadow ray is marched first:
-    uint32_t np_acc = 0u;                                           // t_useful and the accepted analytic primitives
     {
         const float4 c = s_pix[tid];
         path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
+        MarchRegs m;
         march_begin_primary(sc, p, m);
-        mo = p.ray.o;
+        s_march[tid] = make_float4(0.0f, m.t_useful, rpt_u2f(0u), rpt_u2f(m.accepted));
     }
     const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
 
@@ -931,6 +930,22 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
         const uint32_t n_wait = (uint32_t)__popcll(__ballot(state == S2_WAIT));
         if (n_march == 0u && n_wait == 0u) break;
         if (n_march >= rp.march_min_lanes || n_wait == 0u) {
+            // Nothing of a march is live in registers across the block: a marching lane takes its march from LDS here and puts it
+            // back behind the loop (direction and origin are the path's ray or the parked shadow ray).
+            const bool mine = state <= S2_MARCH_P;
+            MarchRegs m;
+            v3 mo = mk3(0.0f, 0.0f, 0.0f);
+            m.d = mk3(0.0f, 0.0f, 0.0f); m.t = 0.0f; m.t_useful = 0.0f; m.steps = 0u; m.accepted = 0u; m.hit = false;
+            if (mine) {
+                const float4 r = s_march[tid];
+                m.t = r.x; m.t_useful = r.y; m.steps = rpt_f2u(r.z); m.accepted = rpt_f2u(r.w);
+                if (state == S2_MARCH_S) {
+                    const float4 so = s_sho[tid], sd = s_shd[tid];
+                    mo = mk3(so.x, so.y, so.z); m.d = mk3(sd.x, sd.y, sd.z);
+                } else {
+                    mo = p.ray.o; m.d = p.ray.d;
+                }
+            }
             for (;;) {
                 if (state <= S2_MARCH_P) {
                     RPT_PROF(PB_CLOSEST);                           // (block profile: one march step of the wave)
@@ -941,8 +956,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
                             else {
                                 // the path ray's march, prepared by the block (march_begin_primary's analytic part is ~400
                                 // instructions: it must not run here, for the one lane of the wave whose shadow march just ended)
-                                march_begin(m, p.ray.d, np_tu);
-                                m.accepted = np_acc;
+                                march_begin(m, p.ray.d, s_gain[tid].w);     // (m.accepted is the path ray's already)
                                 mo = p.ray.o;
                                 state = S2_MARCH_P;
                             }
@@ -954,6 +968,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
                 const uint32_t left = (uint32_t)__popcll(__ballot(state <= S2_MARCH_P));
                 if (left == 0u || left < rp.march_min_lanes) break;
             }
+            if (mine) s_march[tid] = make_float4(m.t, m.t_useful, rpt_u2f(m.steps | (m.hit ? 0x80000000u : 0u)), rpt_u2f(m.accepted));
         } else if (state == S2_WAIT) {
             RPT_PROF(PB_SHADE);
             if (pending) {                                          // last bounce's light sample: visible unless its march hit the object
@@ -965,7 +980,8 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
             if (!over) {
                 GeomHit g;
                 g.code = 0u;
-                const SdfDeferredQuery q{{m.hit, m.t}, march_analytic(m)};
+                const float4 r = s_march[tid];                      // the finished march of the path's ray
+                const SdfDeferredQuery q{{(rpt_f2u(r.z) & 0x80000000u) != 0u, r.x}, AnalyticPre{r.y, rpt_f2u(r.w)}};
                 const uint32_t what = path_trace_geom_split(sc, q, p, g);
                 if (what == 0u) { p.radiance = p.radiance + background(sc, p.ray) * p.throughput; over = true; }
                 else if (what == 1u) over = true;
@@ -993,6 +1009,8 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
                     new_ray = true;
                 }
             }
+            float np_tu = 0.0f;                                     // the path ray's march: t_useful and the accepted analytic primitives
+            uint32_t np_acc = 0u;
             if (new_ray) {                                          // march_begin_primary's analytic part, once, for every lane of the block
                 AnalyticHit ah;
                 analytic_closest(sc, p.ray, ah);
@@ -1000,14 +1018,11 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
                 np_acc = ah.accepted;
             }
             if (pending) {
-                const float4 so = s_sho[tid], sd = s_shd[tid];
-                mo = mk3(so.x, so.y, so.z);
-                march_begin(m, mk3(sd.x, sd.y, sd.z), sdf_shadow_t_useful(sc, so.w));
+                s_march[tid] = make_float4(0.0f, sdf_shadow_t_useful(sc, s_sho[tid].w), rpt_u2f(0u), rpt_u2f(np_acc));
+                s_gain[tid].w = np_tu;
                 state = S2_MARCH_S;
             } else if (new_ray) {
-                march_begin(m, p.ray.d, np_tu);
-                m.accepted = np_acc;
-                mo = p.ray.o;
+                s_march[tid] = make_float4(0.0f, np_tu, rpt_u2f(0u), rpt_u2f(np_acc));
                 state = S2_MARCH_P;
             }
         }
