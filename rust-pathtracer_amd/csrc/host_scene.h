@@ -56,10 +56,10 @@ inline DevCamera make_camera(const rpt_camera& c, float width, float height)
 }
 
 // Uniform grid over the spheres of a large scene (dev_scene_large.h).  Cell size targets ~1 sphere
-// per cell.  Every sphere is listed in each cell its PADDED bounding box overlaps; the padding is the
-// distance outside the sphere at which the reference's f32 ray/sphere test (d2 = l.l - tca^2 <= r^2,
-// absolute error ~4e-7 |l|^2) can still report a hit, for ray origins within `safe_r` of the grid
-// centre, doubled for safety, plus 1e-3 cell sizes for the DDA's own rounding.
+// per cell.  Every sphere is listed in each cell its PADDED ball reaches; the padding is the distance
+// outside the sphere at which the reference's f32 ray/sphere test (d2 = l.l - tca^2 <= r^2: eleven
+// roundings of magnitude |l|^2, < 6.6e-7 |l|^2; 1.2e-6 |l|^2 is used) can still report a hit, for the
+// farthest ray origin the lists serve, plus 1e-3 cell sizes for the DDA's own rounding.
 struct HostGrid {
     uint32_t n[3];
     float gmin[3], gmax[3], cs[3], inv_cs[3];
