@@ -38,16 +38,16 @@ struct DevState {
     float* fb = nullptr;              // staging for the host-pointer API (this device's rows, or a whole image)
     size_t fb_bytes = 0;
     float* tile = nullptr;            // resident ColorBuffer rows of this rank: rows_padded x width RGBA f32
-    SceneSmallSdf* scene_small_dev = nullptr;   // the small scene in device memory, for the one kernel that reads it from there (SDF compact)
+    SceneSmallSdf* scene_small_dev = nullptr;   // the small scene in device memory, for the kernels that read it from there (SDF scenes with media; SDF compact)
     void* wf = nullptr;               // wavefront state of large scenes (dev_wavefront.h), grown on demand
     size_t wf_bytes = 0;
     float* dn = nullptr;              // the denoiser's intermediate buffer, grown on demand
     size_t dn_bytes = 0;
     // `wf` and `dn` are scratch of the CONTEXT, while rpt_render_device / rpt_denoise_device run on whatever stream the caller
     // passes: a use on another stream than the previous one waits for that one's event (same stream: ordered anyway)
-    hipEvent_t wf_done = nullptr, dn_done = nullptr;
-    hipStream_t wf_stream = nullptr, dn_stream = nullptr;
-    bool wf_used = false, dn_used = false;
+    hipEvent_t wf_done = nullptr, dn_done = nullptr, sc_done = nullptr;
+    hipStream_t wf_stream = nullptr, dn_stream = nullptr, sc_stream = nullptr;
+    bool wf_used = false, dn_used = false, sc_used = false;
     ncclComm_t comm = nullptr;
 };
 
@@ -271,6 +271,7 @@ static void free_dev(DevState& d)
     if (d.ev_end) (void)hipEventDestroy(d.ev_end);
     if (d.ev_ready) (void)hipEventDestroy(d.ev_ready);
     if (d.wf_done) (void)hipEventDestroy(d.wf_done);
+    if (d.sc_done) (void)hipEventDestroy(d.sc_done);
     if (d.dn_done) (void)hipEventDestroy(d.dn_done);
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d = DevState();
@@ -299,6 +300,7 @@ static int open_dev(DevState& d, int device_id, int rank, const char* who)
         hipEventCreate(&d.ev_begin) != hipSuccess || hipEventCreate(&d.ev_end) != hipSuccess ||
         hipEventCreateWithFlags(&d.ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.wf_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d.sc_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.dn_done, hipEventDisableTiming) != hipSuccess) {
         set_err(nullptr, "%s: cannot create a stream on device %d", who, device_id);
         free_dev(d);
@@ -488,9 +490,11 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     }
 
     const SceneSmallSdf* scs_dev = nullptr;
-    if (!ctx->large && scs.sdf.n_prims > 0 && rp.sdf_resumable_march == 3u && !nested) {
+    if (!ctx->large && scs.sdf.n_prims > 0 && ((rp.sdf_resumable_march == 3u && !nested) || ctx->media)) {
         // (a copy per launch: the camera in it depends on the frame size; pageable source, so the copy has left `scs` on return)
         if (!d.scene_small_dev) RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.scene_small_dev, sizeof(SceneSmallSdf)));
+        // (the context's one copy: a launch on another stream may still be reading the previous frame size's camera)
+        if (d.sc_used && d.sc_stream != stream) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, d.sc_done, 0));
         RPT_HIP_CHECK(ctx, hipMemcpyAsync(d.scene_small_dev, &scs, sizeof(SceneSmallSdf), hipMemcpyHostToDevice, stream));
         scs_dev = d.scene_small_dev;
     }
@@ -514,6 +518,11 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         RPT_HIP_CHECK(ctx, hipEventRecord(d.wf_done, stream));
         d.wf_stream = stream;
         d.wf_used = true;
+    }
+    if (scs_dev) {
+        RPT_HIP_CHECK(ctx, hipEventRecord(d.sc_done, stream));
+        d.sc_stream = stream;
+        d.sc_used = true;
     }
     return RPT_OK;
 }

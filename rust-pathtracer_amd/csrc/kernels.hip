@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_kernel)(const Sce
 // The same kernels for scenes with participating media (dev_scene.h WithMedia, dev_media.h): every form below has one.
 __global__ __launch_bounds__(256) void RPT_K(render_small_nested_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_nested_body(sc, rp); }
 __global__ __launch_bounds__(256) void RPT_K(render_large_nested_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_nested_body(sc, rp); }
-__global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_nested_body(sc, rp); }
+__global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_media_kernel)(const WithMedia<SceneSmallSdf>* __restrict__ sc, const RenderParams rp) { render_nested_body(*sc, rp); }
 #endif
 
 // The production megakernel.  Same arithmetic per sample, different schedule:
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_rege
 #ifndef RPT_NO_MEDIA_KERNELS
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_regen_body(sc, rp); }
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
-__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
+__global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_media_kernel)(const WithMedia<SceneSmallSdf>* __restrict__ sc, const RenderParams rp) { render_regen_body_tf(*sc, rp); }
 #endif
 
 #ifdef RPT_AB_KERNELS
@@ -882,7 +882,7 @@ RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& rp)
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
 #ifndef RPT_NO_MEDIA_KERNELS
-__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_media_kernel)(const WithMedia<SceneSmallSdf>* __restrict__ sc, const RenderParams rp) { render_sdf_march_body(*sc, rp); }
 #endif
 
 // SDF scenes, two rooms (dev_sdf_path.h, SdfDeferredQuery).  Per lane:
@@ -1033,7 +1033,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body(sc, rp); }
 #ifndef RPT_NO_MEDIA_KERNELS
-__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march2_body(sc, rp); }
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_media_kernel)(const WithMedia<SceneSmallSdf>* __restrict__ sc, const RenderParams rp) { render_sdf_march2_body(*sc, rp); }
 #endif
 
 #ifdef RPT_AB_KERNELS
@@ -1398,14 +1398,18 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #ifndef RPT_NO_MEDIA_KERNELS
         // scenes with participating media: the same forms, instantiated for WithMedia<Scene> (the A/B kernels have none)
         const WithMedia<SceneSmall> msc(sc);
-        const WithMedia<SceneSmallSdf> mscs(scs);
+        // The SDF kernels with media read the scene through a pointer: behind a by-value argument hipcc keeps a copy of the 2 KB
+        // struct in scratch for kernels this large (2.6 KB per lane; the blob full of fog ran at 0.77 instead of 1.84 Gsamples/s).
+        static_assert(sizeof(WithMedia<SceneSmallSdf>) == sizeof(SceneSmallSdf), "WithMedia adds no data");
+        const WithMedia<SceneSmallSdf>* const mscs_dev = reinterpret_cast<const WithMedia<SceneSmallSdf>*>(scs_dev);
+        if (has_sdf && !mscs_dev) return hipErrorInvalidValue;
         const WithMedia<SceneLarge> mscl(scl);
         if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_media_kernel), tiles, wg, 0, st, mscl, rp);
         else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_media_kernel), tiles, wg, 0, st, mscl, rp);
-        else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_media_kernel), tiles, wg, 0, st, mscs, rp);
-        else if (has_sdf && rp.sdf_resumable_march == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, mscs, rp);
-        else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_media_kernel), tiles, wg, 0, st, mscs, rp);
-        else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_media_kernel), tiles, wg, 0, st, mscs, rp);
+        else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_media_kernel), tiles, wg, 0, st, mscs_dev, rp);
+        else if (has_sdf && rp.sdf_resumable_march == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, mscs_dev, rp);
+        else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_media_kernel), tiles, wg, 0, st, mscs_dev, rp);
+        else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_media_kernel), tiles, wg, 0, st, mscs_dev, rp);
         else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_media_kernel), tiles, wg, 0, st, msc, rp);
         else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_media_kernel), tiles, wg, 0, st, msc, rp);
         else hipLaunchKernelGGL(RPT_K(render_small_regen_media_kernel), tiles, wg, 0, st, msc, rp);

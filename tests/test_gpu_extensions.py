@@ -100,7 +100,8 @@ def test_light_types_in_a_large_scene(rpt, oracle, torch_cuda):
 
 
 def test_context_scratch_is_ordered_across_streams(rpt, oracle):
-    """The wavefront form's path buffers and the denoiser's intermediate image belong to the CONTEXT, while rpt_render_device and
+    """The wavefront form's path buffers, the denoiser's intermediate image and the device copy of an SDF scene with media belong to
+    the CONTEXT, while rpt_render_device and
     rpt_denoise_device run on whatever stream the caller passes: two launches on two streams, nothing ordering them on the
     host side, must both come out right (the second waits on the device for the first one's event)."""
     import torch
@@ -128,4 +129,23 @@ def test_context_scratch_is_ordered_across_streams(rpt, oracle):
     torch.cuda.synchronize()
     for i, o in enumerate(outs):
         assert_bit_identical(o.pixels.cpu().numpy(), dn_want, "denoise %d on stream %d" % (i, i % 2))
+    t.close()
+    # SDF scenes with media read the scene (camera included: it depends on the frame size) from the context's device copy,
+    # rewritten by every launch: two frame sizes alternating on two streams
+    s = scenes.sdf_scene()
+    s.media = True
+    s.any_hit_uses_max_dist = True
+    s.materials[0] = rpt.Material(rgb=(1.0, 1.0, 1.0), roughness=0.05, spec_trans=1.0, ior=1.2,
+                                  medium=dict(type="scatter", density=0.8, color=(0.9, 0.9, 0.9), anisotropy=0.3))
+    t = rpt.Tracer(s, device=0, seed=3)
+    sizes = [(160, 90), (96, 128)]
+    wants = [oracle.render(s.describe(), ww, hh, 2, seed=3) for ww, hh in sizes]
+    bufs = [rpt.DeviceColorBuffer(*sizes[i % 2]) for i in range(6)]
+    torch.cuda.synchronize()
+    for i, b in enumerate(bufs):
+        with torch.cuda.stream(streams[i % 2 if i < 4 else (i + 1) % 2]):
+            t.render_n(b, 2)
+    torch.cuda.synchronize()
+    for i, b in enumerate(bufs):
+        assert_bit_identical(b.pixels.cpu().numpy(), wants[i % 2], "SDF + media launch %d" % i)
     t.close()
