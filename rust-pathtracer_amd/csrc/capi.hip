@@ -38,7 +38,7 @@ struct DevState {
     float* fb = nullptr;              // staging for the host-pointer API (this device's rows, or a whole image)
     size_t fb_bytes = 0;
     float* tile = nullptr;            // resident ColorBuffer rows of this rank: rows_padded x width RGBA f32
-    SceneSmallSdf* scene_small_dev = nullptr;   // the small scene in device memory, for the kernels that read it from there (SDF scenes with media; SDF compact)
+    SceneSmallSdf* scene_small_dev = nullptr;   // the small scene in device memory, for the one kernel that reads it from there (SDF compact, A/B)
     void* wf = nullptr;               // wavefront state of large scenes (dev_wavefront.h), grown on demand
     size_t wf_bytes = 0;
     float* dn = nullptr;              // the denoiser's intermediate buffer, grown on demand
@@ -490,7 +490,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     }
 
     const SceneSmallSdf* scs_dev = nullptr;
-    if (!ctx->large && scs.sdf.n_prims > 0 && ((rp.sdf_resumable_march == 3u && !nested) || ctx->media)) {
+    if (!ctx->large && scs.sdf.n_prims > 0 && rp.sdf_resumable_march == 3u && !nested) {
         // (a copy per launch: the camera in it depends on the frame size; pageable source, so the copy has left `scs` on return)
         if (!d.scene_small_dev) RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.scene_small_dev, sizeof(SceneSmallSdf)));
         // (the context's one copy: a launch on another stream may still be reading the previous frame size's camera)

@@ -51,6 +51,7 @@ VARIANTS = {
     "large_w7": ["-DRPT_LARGE_WAVES_PER_SIMD=7"],
     "large_w6": ["-DRPT_LARGE_WAVES_PER_SIMD=6"],
     "slp": ["-fslp-vectorize"],
+    "scene_plain": ["-DRPT_SCENE_ARGUMENT_PLAIN"],
     "no_max_ilp": ["-mllvm", "-amdgpu-sched-strategy=max-occupancy"],
     "large_w8": ["-DRPT_LARGE_WAVES_PER_SIMD=8"],
     "large_w5_sp": ["-DRPT_LARGE_WAVES_PER_SIMD=5", "-DRPT_SCALAR_DIVIDES_PLAIN"],
