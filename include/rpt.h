@@ -404,9 +404,8 @@ int rpt_resident_upload(rpt_ctx* ctx, const float* pixels, uint32_t width, uint3
  * pixels).  The RNG is keyed by the global pixel, so the image does not depend on
  * world.  world = 1, rank = 0 renders the whole image in place.
  * Calls on one context are ordered by the caller (one thread at a time).  The wavefront form of large scenes keeps its paths in
- * buffers of the context, and SDF scenes with media are read by their kernels from the context's device copy of the scene: a launch
- * on another stream than the previous one waits (on the device) for that one to finish with them; use one context per render that
- * is to run concurrently. */
+ * buffers of the context: a launch on another stream than the previous one waits (on the device) for that one to finish with
+ * them; use one context per render that is to run concurrently. */
 int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t height,
                       uint64_t frames_done, uint32_t spp, uint64_t seed, uint32_t flags,
                       uint32_t tile_rows, uint32_t rank, uint32_t world, void* stream);

@@ -100,8 +100,7 @@ def test_light_types_in_a_large_scene(rpt, oracle, torch_cuda):
 
 
 def test_context_scratch_is_ordered_across_streams(rpt, oracle):
-    """The wavefront form's path buffers, the denoiser's intermediate image and the device copy of an SDF scene with media belong to
-    the CONTEXT, while rpt_render_device and
+    """The wavefront form's path buffers and the denoiser's intermediate image belong to the CONTEXT, while rpt_render_device and
     rpt_denoise_device run on whatever stream the caller passes: two launches on two streams, nothing ordering them on the
     host side, must both come out right (the second waits on the device for the first one's event)."""
     import torch
@@ -130,8 +129,8 @@ def test_context_scratch_is_ordered_across_streams(rpt, oracle):
     for i, o in enumerate(outs):
         assert_bit_identical(o.pixels.cpu().numpy(), dn_want, "denoise %d on stream %d" % (i, i % 2))
     t.close()
-    # SDF scenes with media read the scene (camera included: it depends on the frame size) from the context's device copy,
-    # rewritten by every launch: two frame sizes alternating on two streams
+    # every launch carries its own scene (camera included: it depends on the frame size) in its kernel arguments: two frame sizes
+    # of an SDF scene with media alternating on two streams
     s = scenes.sdf_scene()
     s.media = True
     s.any_hit_uses_max_dist = True
