@@ -53,6 +53,8 @@ def _tuning_flags():
             _tuning_ok = r.returncode == 0
             if not _tuning_ok:
                 print("build.py: this hipcc rejects the -mllvm tuning options; building without them")
+    if os.environ.get("RPT_TUNING_FLAGS") is not None:               # experiments (tools/build_variants.py): replace the tuning options
+        return os.environ["RPT_TUNING_FLAGS"].split()
     return TUNING_FLAGS if _tuning_ok else []
 
 
