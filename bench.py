@@ -135,7 +135,7 @@ def other_configs(rpt, torch, device, small):
                 "note": "flops per sample exclude ray/sphere tests that missed (brute_force_flops_per_sample is the oracle's loop); "
                         "the grid walk's own arithmetic is not algorithmic work and is not counted"})
     t8 = run(big, w, h, 8, 2)
-    blk["progressive_8spp"] = {"kernel": "wf_walk_kernel + wf_shade_kernel" if w * h >= (3 << 19) else "render_large_regen_kernel",
+    blk["progressive_8spp"] = {"kernel": "render_large_regen_kernel",
                                "kernel_ms": round(t8 * 1e3, 3), "value": round(w * h * 8 / t8 / 1e6, 2),
                                "frac": round(ops["flops_per_sample"] * w * h * 8 / t8 / 1e12 / FP32_PEAK_TFLOPS, 5)}
     out["roofline_c5"] = blk

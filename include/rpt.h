@@ -294,10 +294,9 @@ enum {
      *   megakernel — the grid walks inside the path-regenerating kernel, like everything else;
      *   wavefront  — the grid walks in a kernel of their own over ray lists in HBM, the rest of a bounce in a shading
      *                kernel; needs 168 B of device memory per pixel of the tile while it runs (kept by the context) and
-     *                1 + 2 * (spp * max_depth + 1) launches, so it pays from about 1.5 M pixels per device up — and for
-     *                launches of a few samples per pixel: the megakernel regenerates over a launch's samples and is the
-     *                faster form from 16 (1-2 spp: wavefront +6 %, 8: +1 %, 16: -1 %, 32: -3 %).
-     * Default: wavefront for tiles of at least 1.5 M pixels and launches of at most 8 samples, megakernel otherwise.
+     *                1 + 2 * (spp * max_depth + 1) launches.
+     * Default: the megakernel (since round 3 it is the faster form at every tile size and sample count; the wavefront form runs its
+     * grid walks with three times the lane fill and remains for A/B measurement).
      * These two flags force one form (both set: RPT_ERR_INVALID_ARG); scenes without a grid ignore them. */
     RPT_RENDER_LARGE_WAVEFRONT = 1u << 6,
     RPT_RENDER_LARGE_MEGAKERNEL = 1u << 7,

@@ -203,19 +203,18 @@ static uint32_t sdf_pool_shade_lanes() { static const uint32_t v = env_lanes("RP
 static uint32_t sdf_pool_resolve_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_RESOLVE_LANES", 16); return v; }
 static uint32_t sdf_pool_min_batch() { static const uint32_t v = env_lanes("RPT_SDF_POOL_MIN_BATCH", 32); return v; }
 static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_POOL_PATIENCE") ? (uint32_t)atoi(getenv("RPT_SDF_POOL_PATIENCE")) : 8u; return v; }
-// Which form a large scene with a grid takes (include/rpt.h).  RPT_LARGE_FORM=wavefront|megakernel overrides flags and
-// default (A/B runs of unmodified callers).
-constexpr uint64_t kWavefrontMinPixels = 3ull << 19;                // 1.5 M
+// Which form a large scene with a grid takes (include/rpt.h): the megakernel unless the caller asks for the wavefront form.
+// (Rounds 2 and early 3 chose the wavefront form for launches of up to 8 samples on tiles from 1.5 M pixels; since the two tiers of
+// cell lists and the 5-wave megakernel the megakernel is ahead at every size and sample count: 2048^2 x 1 / 2 / 4 / 8 / 16 spp 2.51 /
+// 5.16 / 10.2 / 19.4 / 36.8 ms against 2.75 / 5.49 / 10.9 / 21.3 / 41.6, 4096^2 x 8: 71.9 against 78.7.)  RPT_LARGE_FORM=wavefront|megakernel
+// overrides flags and default (A/B runs of unmodified callers).
 constexpr uint64_t kWavefrontMaxBlindIterations = 256;              // iterations render_wavefront enqueues without looking at the device
-constexpr uint32_t kWavefrontMaxSpp = 8;                            // the megakernel regenerates over a launch's samples: from 16 per launch it is the faster form
-static bool wavefront_wanted(uint32_t flags, uint64_t tile_pixels, uint32_t spp)
+static bool wavefront_wanted(uint32_t flags)
 {
     static const char* form = getenv("RPT_LARGE_FORM");
     if (form && form[0] == 'w') return true;
     if (form && form[0] == 'm') return false;
-    if (flags & RPT_RENDER_LARGE_WAVEFRONT) return true;
-    if (flags & RPT_RENDER_LARGE_MEGAKERNEL) return false;
-    return tile_pixels >= kWavefrontMinPixels && spp <= kWavefrontMaxSpp;
+    return (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
 }
 // Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel).
 // (1 since round 3: 1080p, 1 spp 7.12 vs 6.83 Gsamples/s for the megakernel, 2 spp 7.01 vs 7.39: profiles/r3/spp_curve.txt)
@@ -461,7 +460,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         set_err(ctx, "render: RPT_RENDER_LARGE_WAVEFRONT and RPT_RENDER_LARGE_MEGAKERNEL exclude each other");
         return RPT_ERR_INVALID_ARG;
     }
-    bool wavefront = ctx->large && scl.use_accel && !nested && scl.max_depth != 0u && wavefront_wanted(flags, (uint64_t)rp.rows_local * width, spp);
+    bool wavefront = ctx->large && scl.use_accel && !nested && scl.max_depth != 0u && wavefront_wanted(flags);
     WfBuffers wb;
     if (wavefront) {
         const uint64_t n_slots = (uint64_t)rp.rows_local * width;

@@ -58,6 +58,10 @@ class Oracle:
         if pixels is None:
             pixels = np.zeros((height, width, 4), dtype=np.float32)
         r0, r1 = rows if rows is not None else (0, height)
+        if threads <= 0:
+            # OpenMP's team size is sticky (omp_set_num_threads) and defaults to every logical CPU in sight: a one-row call with 256
+            # spinning team members under a 16-CPU quota takes 10x as long.  One thread per row, at most 16.
+            threads = max(1, min(r1 - r0, 16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16))
         self.lib.oracle_render_flags.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64,
                                                  C.c_uint32, C.c_uint32, C.c_int, C.c_uint32]
         rc = self.lib.oracle_render_flags(C.byref(desc), pixels.ctypes.data, width, height, frames_done, spp, seed, r0, r1, threads, render_flags)

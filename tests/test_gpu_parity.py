@@ -790,9 +790,8 @@ def test_full_config5_all_512_spp_pixels_match_oracle(rpt, torch_cuda, oracle):
 
 
 def test_wavefront_long_launch_equals_megakernel(rpt, torch_cuda):
-    """A launch long enough for the wavefront form's host early-out (more than 512 iterations: 150 spp x depth 4) on a tile
-    above the default threshold, and the default choice on both sides of the 8-sample limit: whole frames bit-identical to the
-    megakernel's (which the oracle tests pin)."""
+    """A launch long enough for the wavefront form's host early-out (more than 512 iterations: 150 spp x depth 4) and a short one,
+    on a large tile, and the default form: whole frames bit-identical to the megakernel's (which the oracle tests pin)."""
     from rust_pathtracer_amd import scenes
     torch = torch_cuda
     A = rpt._abi
