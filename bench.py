@@ -116,6 +116,26 @@ def other_configs(rpt, torch, device, small):
         return sum(ms) / len(ms) / 1e3
 
     out = {}
+    # The headline workload once more with the device listed TWICE in its context (include/rpt.h, rpt_create_multi): two ranks on one
+    # GPU, each with its own stream and every other block of 16 rows, the frame resident in the context, steps issued back to back —
+    # one rank's launch fills the tail of the other's.  Not the headline `value`: a step is then two concurrent launches.
+    import time
+    from rust_pathtracer_amd import tiling
+    div0 = 8 if small else 1
+    w, h, spp, steps = C2[0] // div0, C2[1] // div0, max(1, C2[2] // (16 if small else 1)), 6
+    tracer = rpt.Tracer(rpt.AnalyticalScene(), devices=[device, device], seed=1)
+    frame = tiling.TiledRender(tracer, w, h, tile_rows=16)
+    frame.render_n(spp)
+    tracer.resident_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame.render_n(spp)
+    tracer.resident_sync()
+    dt = (time.perf_counter() - t0) / steps
+    tracer.close()
+    out["resident_two_streams"] = {"value": round(w * h * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+                                   "workload": "AnalyticalScene %dx%d x %d spp per step, frame resident in a context that lists the GPU twice "
+                                               "(two streams, cyclic 16-row blocks), host clock over %d steps" % (w, h, spp, steps)}
     div = 8 if small else 1
     sdf = scenes.sdf_scene()
     w, h, spp = 1920 // div, 1080 // div, 64 // (4 if small else 1)

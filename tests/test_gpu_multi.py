@@ -145,12 +145,19 @@ t.close()
     assert all(g > 0.0 for g in gaps), "devices ran one after the other: begin(rank k) - end(rank 0) = %r ms (rank 0 took %.3f ms)" % (gaps, own)
 
 
-def test_duplicate_devices_need_peer_gather(rpt, torch_cuda):
+def test_a_device_listed_twice_renders_on_two_streams(rpt, oracle, torch_cuda):
+    """rpt_create_multi with a repeated device id (no environment knob): two ranks on one GPU, each with its own stream and its
+    share of the rows, gathered with device copies instead of RCCL.  Progressive steps issued back to back without host
+    synchronisation (the point of it: one rank's launch fills the tail of the other's) give the oracle's frame bit for bit."""
     os.environ.pop("RPT_GATHER", None)
-    h = C.c_void_p()
-    ids = (C.c_int * 2)(0, 0)
-    assert rpt.lib().rpt_create_multi(C.byref(h), ids, 2) == rpt._abi.RPT_ERR_INVALID_ARG
-    assert b"distinct" in rpt.lib().rpt_last_error(None)
+    w, h = 200, 120
+    t = rpt.Tracer(rpt.AnalyticalScene(), devices=[0, 0], seed=4)
+    assert t.world() == (0, 2, 2)
+    for spp in (3, 1, 2):
+        t.render_resident(w, h, spp)
+    got = t.resident_to_host(w, h).image()
+    assert_bit_identical(got, oracle.render(oracle.scene_analytical(), w, h, 6, seed=4), "device listed twice")
+    t.close()
 
 
 def test_multi_context_large_scene_and_progressive_gathers(rpt, oracle, torch_cuda):
