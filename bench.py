@@ -132,7 +132,17 @@ def other_configs(rpt, torch, device, small):
         frame.render_n(spp)
     tracer.resident_sync()
     dt = (time.perf_counter() - t0) / steps
+    # ... and as the reference uses it: one render() per redraw (1 spp per step), 200 redraws back to back
+    frame.render_n(1)
+    tracer.resident_sync()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        frame.render_n(1)
+    tracer.resident_sync()
+    dt1 = (time.perf_counter() - t0) / 200
     tracer.close()
+    out["resident_two_streams_1spp"] = {"value": round(w * h / dt1 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt1 * 1e3, 4), "steps": 200,
+                                        "workload": "the same context, one sample per pixel per step (the reference's render() per redraw)"}
     out["resident_two_streams"] = {"value": round(w * h * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
                                    "workload": "AnalyticalScene %dx%d x %d spp per step, frame resident in a context that lists the GPU twice "
                                                "(two streams, cyclic 16-row blocks), host clock over %d steps" % (w, h, spp, steps)}
