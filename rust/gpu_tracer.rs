@@ -138,7 +138,8 @@ impl GpuTracer {
     pub fn new(scene: Box<dyn GpuScene>) -> Self { Self::with_devices(scene, &[0]) }
 
     /// The same over several GPUs of the node: `render` fans the image rows out over them inside the call,
-    /// exactly where the reference fans out over rayon's threads (tracer.rs:29-32).
+    /// exactly where the reference fans out over rayon's threads (tracer.rs:29-32).  A device may be listed twice
+    /// (`&[0, 0]`): two streams on that GPU, whose launches fill each other's tails in a redraw loop on the resident frame.
     pub fn with_devices(scene: Box<dyn GpuScene>, devices: &[i32]) -> Self {
         assert!(unsafe { rpt_abi_version() } == RPT_ABI_VERSION, "librpt_hip ABI version mismatch");
         assert!(unsafe { rpt_sizeof_scene_desc() } as usize == std::mem::size_of::<RptSceneDesc>(),
