@@ -141,6 +141,20 @@ def other_configs(rpt, torch, device, small):
     tracer.resident_sync()
     dt1 = (time.perf_counter() - t0) / 200
     tracer.close()
+    # ... and configs[3] (SDF scene) the same way
+    w4, h4, spp4 = 1920 // div0, 1080 // div0, max(1, 64 // (16 if small else 1))
+    tracer = rpt.Tracer(scenes.sdf_scene(), devices=[device, device], seed=1)
+    frame = tiling.TiledRender(tracer, w4, h4, tile_rows=16)
+    frame.render_n(spp4)
+    tracer.resident_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame.render_n(spp4)
+    tracer.resident_sync()
+    dt4 = (time.perf_counter() - t0) / steps
+    tracer.close()
+    out["resident_two_streams_c4"] = {"value": round(w4 * h4 * spp4 / dt4 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt4 * 1e3, 3), "steps": steps,
+                                      "workload": "SDF sphere-march scene %dx%d x %d spp per step, the GPU listed twice" % (w4, h4, spp4)}
     out["resident_two_streams_1spp"] = {"value": round(w * h / dt1 / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt1 * 1e3, 4), "steps": 200,
                                         "workload": "the same context, one sample per pixel per step (the reference's render() per redraw)"}
     out["resident_two_streams"] = {"value": round(w * h * spp / dt / 1e6, 2), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
