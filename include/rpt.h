@@ -362,6 +362,19 @@ int rpt_world(const rpt_ctx* ctx, int* rank, int* world, int* n_local);
 /* Rows per cyclic block for the NEXT resident buffer / rpt_render call (0 < tile_rows). */
 int rpt_set_tile_rows(rpt_ctx* ctx, uint32_t tile_rows);
 
+/* How the context's launches are dispatched.  None of this changes a pixel: it decides when and where a sample is computed.
+ * A workgroup of the render kernels computes a UNIT: one 16x16 tile x one chunk of the launch's samples.
+ *   cost_order     1 (default): within a chunk the tiles are dispatched most expensive first, as timed by the context's previous
+ *                  launch of the same shape, so that the cheap ones fill the launch's tail; 0: bottom rows first, always
+ *   unit_rounds    a launch whose tiles are fewer than this many rounds of workgroups on the device (default 12) is cut into
+ *                  chunks of samples until they are — a tile's chunks are handed from workgroup to workgroup through HBM, in
+ *                  order —; 0: one unit per tile (and launches of more samples than the kernel's sample tables hold, 512, are
+ *                  still one launch: chunks of 512)
+ *   unit_min_spp   ... but no chunk shorter than this many samples (default 64)
+ *   unit_slots     workgroups the device holds at once; 0 (default): 5 per compute unit
+ * Environment defaults: RPT_DISPATCH_ORDER, RPT_UNIT_ROUNDS, RPT_UNIT_MIN_SPP.                                               */
+int rpt_set_dispatch(rpt_ctx* ctx, uint32_t cost_order, uint32_t unit_rounds, uint32_t unit_min_spp, uint32_t unit_slots);
+
 /* Copy the scene into the context (Tracer owns its scene: tracer.rs:8). */
 int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* scene);
 
@@ -522,6 +535,12 @@ int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint6
  * of two different physical devices cannot be compared (RPT_ERR_UNSUPPORTED): the probe is for virtual ranks, i.e. repeated
  * device ids.  Waits for both events. */
 int rpt_debug_render_overlap_ms(rpt_ctx* ctx, int a, int b, float* ms);
+
+/* What the last launch on the context's first device left for the next one's dispatch (rpt_set_dispatch): per tile of that launch
+ * (16x16 pixels, row-major over the device's rows) out[tile * 4 + wave] = the time, in 10 ns, wave `wave` of the tile's last unit
+ * held its slot, then from out[4 * n] the dispatch order (position -> tile: a permutation of 0 .. n - 1) and 5 * n more words of
+ * development data (tools/dispatch_timeline.py).  `out` holds 10 * capacity_tiles dwords; *n_tiles = n.  Waits for the device. */
+int rpt_debug_sched_read(rpt_ctx* ctx, uint32_t* out, uint32_t capacity_tiles, uint32_t* n_tiles);
 
 #ifdef __cplusplus
 }

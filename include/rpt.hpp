@@ -160,6 +160,11 @@ public:
         sync_scene();
     }
     void set_tile_rows(uint32_t tile_rows) { check(rpt_set_tile_rows(ctx_, tile_rows), ctx_); }
+    // scheduling of the launches (rpt.h, rpt_set_dispatch): changes when a sample is computed, never its value
+    void set_dispatch(uint32_t cost_order = 1, uint32_t unit_rounds = 12, uint32_t unit_min_spp = 64, uint32_t unit_slots = 0)
+    {
+        check(rpt_set_dispatch(ctx_, cost_order, unit_rounds, unit_min_spp, unit_slots), ctx_);
+    }
     ~Tracer() { rpt_destroy(ctx_); }
     Tracer(const Tracer&) = delete;
     Tracer& operator=(const Tracer&) = delete;

@@ -145,6 +145,7 @@ SYMBOLS = {
     "rpt_create_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(rpt_unique_id)]),
     "rpt_world": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rpt_set_tile_rows": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rpt_set_dispatch": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rpt_resident_gather_device": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_resident_sync": (C.c_int, [C.c_void_p]),
     "rpt_resident_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
@@ -179,5 +180,6 @@ SYMBOLS = {
     "rpt_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_probe_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "rpt_debug_render_overlap_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "rpt_debug_sched_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),
     "rpt_probe_math": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 }

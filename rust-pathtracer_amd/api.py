@@ -358,6 +358,10 @@ class Tracer:
     def set_tile_rows(self, tile_rows):
         check(lib().rpt_set_tile_rows(self._h, int(tile_rows)), self._h)
 
+    def set_dispatch(self, cost_order=1, unit_rounds=12, unit_min_spp=64, unit_slots=0):
+        """Scheduling of the launches (include/rpt.h, rpt_set_dispatch): changes when a sample is computed, never its value."""
+        check(lib().rpt_set_dispatch(self._h, int(cost_order), int(unit_rounds), int(unit_min_spp), int(unit_slots)), self._h)
+
     def upload_scene(self):
         """Call after mutating the scene returned by scene()."""
         desc = self._scene.describe()

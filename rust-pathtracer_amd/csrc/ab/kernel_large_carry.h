@@ -96,7 +96,7 @@ RPT_DEV bool walk_cell2(const SceneLarge& sc, const RayD& ray, GridWalk& g, uint
 }
 
 template <class S>
-RPT_DEV void render_large_carry_body(const S& sc, const RenderParams& rp)
+RPT_DEV void render_large_carry_body(const S& sc, const RenderParams& launch)
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
@@ -108,7 +108,8 @@ RPT_DEV void render_large_carry_body(const S& sc, const RenderParams& rp)
     __shared__ float4 s_walk[256];                                  // a parked walk: cell (8 bits per axis), t at which the ray leaves it along x, y, z
     __shared__ float2 s_near[256];                                  // the path ray's nearest sphere so far: dist, best
     const uint32_t tid = threadIdx.x;
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+    RenderParams rp;                                                // this workgroup's unit of the launch
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
     const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
 
     uint32_t s = 0;
@@ -278,7 +279,7 @@ RPT_DEV void render_large_carry_body(const S& sc, const RenderParams& rp)
         }
     }
     RPT_PROF_FLUSH();
-    *pixel_address_again(rp) = s_acc[tid];
+    lane_finish(rp, s_acc[tid]);
 }
 
 __global__ __launch_bounds__(256, RPT_LARGE_CARRY_WAVES_PER_SIMD) void RPT_K(render_large_carry_kernel)(const SceneLarge sc, const RenderParams rp) { render_large_carry_body(sc, rp); }

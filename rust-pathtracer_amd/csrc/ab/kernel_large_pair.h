@@ -14,7 +14,7 @@
 #define RPT_LARGE_PAIR_WAVES_PER_SIMD 5
 #endif
 template <class S>
-RPT_DEV void render_large_pair_body(const S& sc, const RenderParams& rp)
+RPT_DEV void render_large_pair_body(const S& sc, const RenderParams& launch)
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
@@ -23,7 +23,8 @@ RPT_DEV void render_large_pair_body(const S& sc, const RenderParams& rp)
     __shared__ float4 s_pix[256];
     __shared__ float4 s_sho[256], s_shd[256], s_gain[256];          // the parked shadow ray (o.w: max_dist) and light sample of each lane
     const uint32_t tid = threadIdx.x;
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+    RenderParams rp;                                                // this workgroup's unit of the launch
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = ST_TRACE;
@@ -107,7 +108,7 @@ RPT_DEV void render_large_pair_body(const S& sc, const RenderParams& rp)
         }
     }
     RPT_PROF_FLUSH();
-    *pixel_address_again(rp) = s_acc[tid];
+    lane_finish(rp, s_acc[tid]);
 }
 
 __global__ __launch_bounds__(256, RPT_LARGE_PAIR_WAVES_PER_SIMD) void RPT_K(render_large_pair_kernel)(const SceneLarge sc, const RenderParams rp) { render_large_pair_body(sc, rp); }

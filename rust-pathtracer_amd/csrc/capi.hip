@@ -48,6 +48,15 @@ struct DevState {
     hipEvent_t wf_done = nullptr, dn_done = nullptr, sc_done = nullptr;
     hipStream_t wf_stream = nullptr, dn_stream = nullptr, sc_stream = nullptr;
     bool wf_used = false, dn_used = false, sc_used = false;
+    // dispatch (kernels.hip, "Dispatch: units, their order, their hand-off"), for launches of `sched_tiles` tiles: per tile 4 dwords of
+    // cost, 1 of order, 1 of sorting scratch, 4 of start stamps (development), then the hand-off words (SchedLayout)
+    uint32_t* sched = nullptr;
+    uint32_t sched_tiles = 0;
+    uint64_t sched_launches = 0;      // launches since the order was last started from scratch (the costs are re-sorted after the 1st, 2nd, 4th, ...)
+    hipEvent_t sched_done = nullptr;
+    hipStream_t sched_stream = nullptr;
+    bool sched_used = false;
+    bool sync_used = false;           // a chunked launch has run: the hand-off's timeout word is worth a look (check_handoffs)
     ncclComm_t comm = nullptr;
 };
 
@@ -57,6 +66,7 @@ struct rpt_ctx {
     bool use_comm = false;            // tiles are gathered through RCCL (false: world 1, or peer copies)
     bool peer_gather = false;         // single process, RPT_GATHER=p2p: hipMemcpyPeerAsync instead of RCCL
     uint32_t tile_rows = 2;
+    uint32_t dispatch[4] = {0xFFFFFFFFu, 0, 0, 0};   // rpt_set_dispatch: cost_order (0xFFFFFFFF: the environment's defaults), unit_rounds, unit_min_spp, unit_slots
     bool has_scene = false;
     bool large = false;               // scene exceeds the kernarg tables: SceneLarge + device tables
     bool media = false;               // RPT_SCENE_MEDIA and some material carries a medium: the media kernels (dev_media.h)
@@ -216,6 +226,58 @@ static bool wavefront_wanted(uint32_t flags)
     if (form && form[0] == 'm') return false;
     return (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
 }
+// Where things are in DevState::sched (dwords), for n tiles.
+struct SchedLayout {
+    size_t n;
+    size_t cost() const { return 0; }
+    size_t order() const { return 4 * n; }
+    size_t sorted() const { return 5 * n; }
+    size_t start() const { return 6 * n; }
+    size_t sync() const { return 10 * n; }                          // kSyncTimeout (kept), then from kSyncTicket on: zeroed before a chunked launch
+    size_t total() const { return 10 * n + 32 + n; }
+};
+constexpr size_t kSyncTimeoutWord = 0, kSyncZeroFrom = 16, kSyncDoneFrom = 32;     // = kernels.hip's kSyncTimeout / kSyncTicket / kSyncDone
+
+// Dispatch policy of a context (include/rpt.h, rpt_set_dispatch); the environment gives the defaults.
+struct DispatchPolicy {
+    uint32_t cost_order, unit_rounds, unit_min_spp, unit_slots;
+};
+static DispatchPolicy default_dispatch()
+{
+    // RPT_DISPATCH_ORDER: 0 bottom rows first, always; 1 most expensive tile first; 2 (development) the costs are recorded, the
+    // order stays bottom rows first (tools/dispatch_timeline.py)
+    static const DispatchPolicy p = {
+        getenv("RPT_DISPATCH_ORDER") ? (uint32_t)atoi(getenv("RPT_DISPATCH_ORDER")) : 1u,
+        getenv("RPT_UNIT_ROUNDS") ? (uint32_t)atoi(getenv("RPT_UNIT_ROUNDS")) : 12u,
+        getenv("RPT_UNIT_MIN_SPP") ? (uint32_t)atoi(getenv("RPT_UNIT_MIN_SPP")) : 64u,
+        0u};
+    return p;
+}
+
+static DispatchPolicy policy_of(const rpt_ctx* ctx)
+{
+    if (ctx->dispatch[0] == 0xFFFFFFFFu) return default_dispatch();
+    return DispatchPolicy{ctx->dispatch[0], ctx->dispatch[1], ctx->dispatch[2], ctx->dispatch[3]};
+}
+
+// How many chunks of samples a launch of `nblocks` tiles x `spp` samples is cut into (kernels.hip, units): enough for
+// `unit_rounds` rounds of workgroups on the device, no chunk shorter than `unit_min_spp` samples; 1 when the tiles alone are
+// that many rounds, or fit the device at once (then nothing waits for a slot and there is nothing to balance).  Measured
+// (tools/tile_rows_time.py, tools/launch_size_time.py): one rank's share of configs[2] (3.2 rounds, 1 024 spp) 1 / 2 / 4 / 8
+// chunks 11.05 / 10.92 / 11.22 / 11.24 Gsamples/s; 800x600 x 128 spp (1.5 rounds) 1 / 4 chunks 8.75 / 10.2; configs[1] (6.4
+// rounds) 1 / 2 / 4 chunks 11.75 / 11.73 / 11.47; configs[3] (64 spp) 1 / 2 chunks 3.05 / 2.97: a chunk's end drains every wave.
+static uint32_t unit_chunks(const DispatchPolicy& pol, uint64_t nblocks, uint32_t spp, uint32_t slots)
+{
+    if (pol.unit_rounds == 0u || pol.unit_min_spp == 0u || nblocks <= slots || spp < 2u * pol.unit_min_spp) return 1u;
+    const uint64_t want = ((uint64_t)pol.unit_rounds * slots + nblocks - 1u) / nblocks;
+    const uint64_t most = spp / pol.unit_min_spp;
+    const uint64_t n = want < most ? want : most;
+    return n < 1u ? 1u : (uint32_t)n;
+}
+
+// Launches of at least this many samples per pixel re-sort the order from their own costs every time (one small kernel behind
+// the launch); shorter ones only after the 1st, 2nd, 4th, 8th ... launch since the order was started.
+constexpr uint32_t kOrderAlwaysFromSpp = 16;
 // Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel).
 // (1 since round 3: 1080p, 1 spp 7.12 vs 6.83 Gsamples/s for the megakernel, 2 spp 7.01 vs 7.39: profiles/r3/spp_curve.txt)
 static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 1u; return v; }
@@ -266,6 +328,8 @@ static void free_dev(DevState& d)
     if (d.wf) (void)hipFree(d.wf);
     if (d.dn) (void)hipFree(d.dn);
     if (d.scene_small_dev) (void)hipFree(d.scene_small_dev);
+    if (d.sched) (void)hipFree(d.sched);
+    if (d.sched_done) (void)hipEventDestroy(d.sched_done);
     if (d.ev_begin) (void)hipEventDestroy(d.ev_begin);
     if (d.ev_end) (void)hipEventDestroy(d.ev_end);
     if (d.ev_ready) (void)hipEventDestroy(d.ev_ready);
@@ -300,7 +364,8 @@ static int open_dev(DevState& d, int device_id, int rank, const char* who)
         hipEventCreateWithFlags(&d.ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.wf_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.sc_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d.dn_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&d.dn_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d.sched_done, hipEventDisableTiming) != hipSuccess) {
         set_err(nullptr, "%s: cannot create a stream on device %d", who, device_id);
         free_dev(d);
         return RPT_ERR_HIP;
@@ -500,13 +565,61 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
 
     if (wavefront && d.wf_used && d.wf_stream != stream) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, d.wf_done, 0));   // the path buffers are the context's
 
-    // The LDS tables of the regenerating kernel hold a bounded number of samples: larger batches are
-    // split into consecutive launches (the running mean carries over in the framebuffer).
+    // Dispatch (kernels.hip): this device's launches of `nblocks` tiles run most expensive tile first, as measured by the previous
+    // one, and in units of one tile x one chunk of the samples.
+    // Kernels without units: nested loops, the compacting kernel of small scenes, the A/B compacting SDF kernel.
+    const bool unit_kernel = !wavefront && !nested && !(rp.compact && !ctx->large && scs.sdf.n_prims == 0) && !scs_dev;
+    const SchedLayout lay{(size_t)nblocks};
+    bool reorder = false;
+    const DispatchPolicy pol = policy_of(ctx);
+    if (!wavefront && !nested && (pol.cost_order != 0u || unit_kernel)) {
+        if (d.sched_tiles != (uint32_t)nblocks) {
+            if (d.sched) { RPT_HIP_CHECK(ctx, hipFree(d.sched)); d.sched = nullptr; d.sched_tiles = 0; }   // (hipFree waits for the device)
+            RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.sched, lay.total() * sizeof(uint32_t)));
+            d.sched_tiles = (uint32_t)nblocks;
+            d.sched_launches = 0;
+            d.sched_used = false;
+            RPT_HIP_CHECK(ctx, hipMemsetAsync(d.sched + lay.sync(), 0, (32 + lay.n) * sizeof(uint32_t), stream));
+            RPT_HIP_CHECK(ctx, rptlaunch::sched_init(d.sched + lay.cost(), d.sched + lay.order(), d.sched_tiles, stream));
+        }
+        if (d.sched_used && d.sched_stream != stream) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, d.sched_done, 0));
+        if (pol.cost_order != 0u) {
+            d.sched_launches += 1;
+            reorder = spp >= kOrderAlwaysFromSpp || (d.sched_launches & (d.sched_launches - 1u)) == 0u;
+            rp.tile_order = d.sched + lay.order();
+            rp.tile_cost = reorder ? d.sched + lay.cost() : nullptr;
+            rp.tile_start = (reorder && getenv("RPT_DISPATCH_TIMELINE")) ? d.sched + lay.start() : nullptr;
+        }
+        rp.sched_sync = d.sched + lay.sync();
+    }
+
     const uint32_t max_chunk = rptlaunch::max_spp_per_launch();
+    if (unit_kernel) {
+        // ONE launch whatever spp is: the LDS tables of the state-machine kernels hold a chunk's samples, and a launch is as many
+        // chunks as it takes.  Workgroup slots of the device: 5 workgroups per CU (__launch_bounds__(256, 5)).
+        static const int n_cu = []() { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+        uint32_t n_chunks = unit_chunks(pol, nblocks, spp, pol.unit_slots ? pol.unit_slots : (uint32_t)n_cu * 5u);
+        uint32_t chunk_spp = (spp + n_chunks - 1u) / n_chunks;
+        if (chunk_spp > max_chunk) chunk_spp = max_chunk;
+        n_chunks = (spp + chunk_spp - 1u) / chunk_spp;
+        if (nblocks * n_chunks > 0x7FFFFFFFull) { set_err(ctx, "render: grid too large (%llu tiles x %u chunks of samples)", (unsigned long long)nblocks, n_chunks); return RPT_ERR_INVALID_ARG; }
+        rp.n_chunks = n_chunks;
+        rp.chunk_spp = chunk_spp;
+        rp.spp = spp;
+        rp.frames_done = frames_done;
+        if (n_chunks > 1u) RPT_HIP_CHECK(ctx, hipMemsetAsync(d.sched + lay.sync() + kSyncZeroFrom, 0, (32 - kSyncZeroFrom + lay.n) * sizeof(uint32_t), stream));
+        const uint32_t grid = (uint32_t)(nblocks * n_chunks);
+        if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, grid, stream, scs_dev));
+        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, grid, stream, scs_dev, ctx->media));
+        d.sync_used = d.sync_used || n_chunks > 1u;
+    } else
+    // Kernels without units: batches beyond what one launch holds are split into consecutive launches (the running mean carries
+    // over in the framebuffer).
     for (uint32_t done = 0; done < spp;) {
         const uint32_t chunk = (spp - done > max_chunk) ? max_chunk : (spp - done);
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
+        rp.n_chunks = 0u;
         if (wavefront && (flags & RPT_RENDER_FAST_MATH)) RPT_HIP_CHECK(ctx, rptlaunch_fast::render_wavefront(scl, rp, wb, stream));
         else if (wavefront) RPT_HIP_CHECK(ctx, rptlaunch::render_wavefront(scl, rp, wb, stream, ctx->media));
         else if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
@@ -518,10 +631,33 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         d.wf_stream = stream;
         d.wf_used = true;
     }
+    if (rp.tile_order || rp.sched_sync) {
+        if (reorder && pol.cost_order != 2u)
+            RPT_HIP_CHECK(ctx, rptlaunch::sched_order(d.sched + lay.cost(), d.sched + lay.order(), d.sched_tiles, stream));
+        RPT_HIP_CHECK(ctx, hipEventRecord(d.sched_done, stream));
+        d.sched_stream = stream;
+        d.sched_used = true;
+    }
     if (scs_dev) {
         RPT_HIP_CHECK(ctx, hipEventRecord(d.sc_done, stream));
         d.sc_stream = stream;
         d.sc_used = true;
+    }
+    return RPT_OK;
+}
+
+// Behind a wait for the device: did a unit of a chunked launch give up waiting for its tile's previous chunk (kernels.hip,
+// unit_begin)?  It cannot happen by construction (the predecessor holds an earlier ticket); if it ever does the image is wrong
+// and the caller must know.
+static int check_handoffs(rpt_ctx* ctx, DevState& d)
+{
+    if (!d.sync_used || !d.sched) return RPT_OK;
+    uint32_t timed_out = 0;
+    RPT_HIP_CHECK(ctx, hipMemcpy(&timed_out, d.sched + SchedLayout{(size_t)d.sched_tiles}.sync() + kSyncTimeoutWord, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    d.sync_used = false;
+    if (timed_out) {
+        set_err(ctx, "render: a workgroup timed out waiting for its tile's previous chunk of samples on device %d; the image is incomplete", d.device);
+        return RPT_ERR_HIP;
     }
     return RPT_OK;
 }
@@ -728,6 +864,13 @@ int rpt_set_tile_rows(rpt_ctx* ctx, uint32_t tile_rows)
     return RPT_OK;
 }
 
+int rpt_set_dispatch(rpt_ctx* ctx, uint32_t cost_order, uint32_t unit_rounds, uint32_t unit_min_spp, uint32_t unit_slots)
+{
+    if (!ctx || cost_order > 2u) { set_err(ctx, "rpt_set_dispatch: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    ctx->dispatch[0] = cost_order; ctx->dispatch[1] = unit_rounds; ctx->dispatch[2] = unit_min_spp; ctx->dispatch[3] = unit_slots;
+    return RPT_OK;
+}
+
 void rpt_destroy(rpt_ctx* ctx)
 {
     if (!ctx) return;
@@ -860,6 +1003,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         ctx->large = true;
         ctx->media = media;
         ctx->has_scene = true;
+        for (DevState& dv : ctx->devs) dv.sched_launches = 0;           // a new scene: the dispatch order is learned again
         return RPT_OK;
     }
 
@@ -897,6 +1041,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
     ctx->large = false;
     ctx->media = media;
     ctx->has_scene = true;
+    for (DevState& dv : ctx->devs) dv.sched_launches = 0;
     return RPT_OK;
 }
 
@@ -1012,7 +1157,26 @@ int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height, uin
             rc_sync = RPT_ERR_HIP;
         }
     }
+    if (rc == RPT_OK && rc_sync == RPT_OK)
+        for (DevState& d : ctx->devs) {
+            if (guard.to(d.device) != hipSuccess) return RPT_ERR_HIP;
+            const int rc_h = check_handoffs(ctx, d);
+            if (rc_h != RPT_OK) return rc_h;
+        }
     return rc != RPT_OK ? rc : rc_sync;
+}
+
+// Test / development probe (include/rpt.h): device 0's tile costs (4 per tile), dispatch order, development data.
+int rpt_debug_sched_read(rpt_ctx* ctx, uint32_t* out, uint32_t capacity_tiles, uint32_t* n_tiles)
+{
+    if (!ctx || !out || !n_tiles) return RPT_ERR_INVALID_ARG;
+    DevState& d = ctx->devs[0];
+    *n_tiles = d.sched_tiles;
+    if (!d.sched || d.sched_tiles > capacity_tiles) { set_err(ctx, "rpt_debug_sched_read: no launch yet, or %u tiles do not fit", d.sched_tiles); return RPT_ERR_INVALID_ARG; }
+    RPT_ON_DEVICE(ctx);
+    RPT_HIP_CHECK(ctx, hipDeviceSynchronize());
+    RPT_HIP_CHECK(ctx, hipMemcpy(out, d.sched, (size_t)d.sched_tiles * 10u * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RPT_OK;
 }
 
 // Test probe (include/rpt.h): how long before device `a`'s last render ENDED device `b`'s began.
@@ -1196,6 +1360,8 @@ int rpt_resident_sync(rpt_ctx* ctx)
     for (DevState& d : ctx->devs) {
         RPT_HIP_CHECK(ctx, guard.to(d.device));
         RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
+        const int rc = check_handoffs(ctx, d);
+        if (rc != RPT_OK) return rc;
     }
     return RPT_OK;
 }
@@ -1335,7 +1501,7 @@ int rpt_synchronize(rpt_ctx* ctx, void* stream)
     if (!ctx) { set_err(nullptr, "rpt_synchronize: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
-    return RPT_OK;
+    return check_handoffs(ctx, ctx->devs[0]);
 }
 
 int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint64_t n, uint32_t use_grid, void* stream)

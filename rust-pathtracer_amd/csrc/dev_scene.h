@@ -146,6 +146,14 @@ struct RenderParams {
     uint32_t carry_wait_at;        // ... it leaves the walk loop for the block when this many lanes are through their walks ...
     uint32_t carry_walk_min;       // ... or when fewer than this many still walk (and somebody waits)
     uint32_t compact;              // small scenes: the kernel that re-deals its workgroup's paths before every stage (few samples per launch)
+    // Dispatch (kernels.hip, "Dispatch: units, their order, their hand-off").  A launch of the state-machine kernels is
+    // n_chunks * (tiles) workgroups; each renders chunk_spp samples (the last chunk: the rest of spp) of one tile.  n_chunks == 0:
+    // a kernel without units (nested loops, the compacting kernel): workgroup b renders tile tile_order[b], all samples.
+    uint32_t n_chunks, chunk_spp;
+    uint32_t* sched_sync;          // ticket counter + per-tile progress (zeroed before every launch with n_chunks > 1)
+    const uint32_t* tile_order;    // position -> tile, most expensive first (NULL: bottom rows first)
+    uint32_t* tile_cost;           // [tile * 4 + wave] the time the wave held its slot, for the next launch's order (NULL: not recorded)
+    uint32_t* tile_start;          // development (tools/dispatch_timeline.py): each wave's start stamp, like tile_cost; NULL: not recorded
 };
 
 }  // namespace rptdev

@@ -55,13 +55,104 @@ RPT_DEV void pixel_coords(const RenderParams& rp, uint32_t col, uint32_t lrow, f
     pixel_index = grow * rp.width + col;
 }
 
+// Dispatch: units, their order, their hand-off.
+//
+// The hardware hands out workgroups in the order of blockIdx.x, and what a workgroup of the state-machine kernels renders is
+// a UNIT: one 16x16 tile x one chunk of the launch's samples.  Two things decide how full the chip is at the end of a launch
+// (tools/dispatch_timeline.py: bottom rows first and one unit per tile, the last 9 % of a 6-round launch and the last 20 % of a
+// 3-round one ran at a fraction of the resident waves):
+//  * the ORDER within a chunk: most expensive tile first (longest-processing-time order), the cost of a tile being the longest
+//    time one of its waves held its slot in the context's previous launch of the same shape (rp.tile_cost -> sched_order_kernel
+//    -> rp.tile_order; before anything is known: bottom rows first).  +2.4 % on configs[1], +12 % on configs[3] and [4].
+//  * the LENGTH of a unit: a pixel's running mean is sequential, so a tile's chunks must run one after the other — but not in
+//    the same workgroup.  Units are drawn from a ticket counter (chunk-major: every tile's chunk c before any tile's chunk
+//    c + 1); the unit (c, T) waits until the four waves of (c - 1, T) have published their pixels (agent-scope release ->
+//    counter; poll -> agent-scope acquire: the L2s of the XCDs are not coherent with each other).  Its predecessor holds an
+//    EARLIER ticket, i.e. it has started and waits for nothing that comes later: every wait ends.  A launch of few rounds of
+//    workgroups is cut into enough chunks for ~12 rounds of units (capi.hip, unit_chunks).
+// The order and the chunking decide WHEN and WHERE a sample is computed, never its value.
+__shared__ uint32_t g_unit[2];        // this workgroup's unit: tile, chunk
+__shared__ uint32_t g_unit_t0[4];     // each wave's clock at its start
+
+// the tile this workgroup renders (wave-uniform)
+RPT_DEV uint32_t block_tile(const RenderParams& rp)
+{
+    if (rp.n_chunks != 0u) return (uint32_t)__builtin_amdgcn_readfirstlane((int)g_unit[0]);        // lane_setup put it there
+    const RPT_CONST_AS uint32_t* order = (const RPT_CONST_AS uint32_t*)rp.tile_order;               // kernels without units
+    return order ? order[blockIdx.x] : gridDim.x - 1u - blockIdx.x;
+}
+
+RPT_DEV uint32_t cost_clock() { return (uint32_t)wall_clock64(); }      // s_memrealtime: 100 MHz, one counter for the whole chip (s_memtime is per XCD)
+
+constexpr uint32_t kSyncTimeout = 0u, kSyncTicket = 16u, kSyncDone = 32u;   // dwords of rp.sched_sync: "a wait timed out" (sticky), ticket counter, done[tile] from dword 32 (capi.hip, SchedLayout)
+
+// Takes this workgroup's unit and, for a chunk other than the first, waits for the tile's previous chunk.  Returns the
+// unit's share of the launch in `rp` (frames_done, spp).  Contains a barrier; the caller's next barrier (lane_setup's, behind
+// the table fill) is the one that holds every wave until thread 0's acquire has completed.
+RPT_DEV void unit_begin(const RenderParams& launch, RenderParams& rp)
+{
+    const uint32_t tid = threadIdx.x;
+    if ((tid & 63u) == 0u) g_unit_t0[tid >> 6] = cost_clock();
+    if (tid == 0u) {
+        uint32_t unit = blockIdx.x;
+        if (launch.n_chunks > 1u) unit = __hip_atomic_fetch_add(launch.sched_sync + kSyncTicket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t n_tiles = gridDim.x / launch.n_chunks;
+        const uint32_t chunk = unit / n_tiles, pos = unit - chunk * n_tiles;
+        g_unit[0] = launch.tile_order ? launch.tile_order[pos] : n_tiles - 1u - pos;
+        g_unit[1] = chunk;
+    }
+    __syncthreads();
+    const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_unit[1]);
+    rp = launch;
+    rp.frames_done = launch.frames_done + (uint64_t)chunk * launch.chunk_spp;
+    const uint32_t left = launch.spp - chunk * launch.chunk_spp;
+    rp.spp = left < launch.chunk_spp ? left : launch.chunk_spp;
+    if (chunk != 0u && tid == 0u) {
+        uint32_t* done = launch.sched_sync + kSyncDone + g_unit[0];
+        const uint32_t want = 4u * chunk;                               // every wave of every earlier chunk has counted (unit_end)
+        uint32_t spins = 0u;
+        while (__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(32);
+            if (++spins == (1u << 27)) {                                // (minutes: a lost hand-off must end as an error, not as a hang)
+                __hip_atomic_store(launch.sched_sync + kSyncTimeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
+// A wave's part of the end of a unit: its pixels are published for the tile's next chunk, its time is recorded.  Every wave
+// of the workgroup counts exactly once, also one that has no pixel at all (lane_setup).  `stored`: the wave has written pixels.
+RPT_DEV void unit_end(const RenderParams& rp, bool stored)
+{
+    const uint64_t act = __ballot(1);
+    const bool first = __lane_id() == (uint32_t)__ffsll((unsigned long long)act) - 1u;
+    const uint32_t chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_unit[1]);
+    if (rp.n_chunks > 1u && chunk + 1u < rp.n_chunks) {
+        if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's stores have left it
+        if (first) {
+            if (stored) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (always: the compiler may drop the fence's own wait)
+            }
+            __hip_atomic_fetch_add(rp.sched_sync + kSyncDone + block_tile(rp), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (rp.tile_cost && first && stored) {
+        const uint32_t wave = threadIdx.x >> 6;
+        const uint32_t slot = block_tile(rp) * 4u + wave;
+        rp.tile_cost[slot] = cost_clock() - g_unit_t0[wave];
+        if (rp.tile_start) rp.tile_start[slot] = g_unit_t0[wave];
+    }
+}
+
 RPT_DEV PixelSetup pixel_setup(const RenderParams& rp, uint32_t tid)
 {
     // A wave covers an 8x8 pixel block (coherent paths), a 256-thread workgroup 16x16.
     PixelSetup ps;
-    // Bottom rows are dispatched first: in the usual outdoor framing they are the expensive
-    // ones (floor / objects), so the cheap sky tiles fill the tail of the launch (+3 %).
-    const uint32_t tile = gridDim.x - 1u - blockIdx.x;
+    const uint32_t tile = block_tile(rp);
     const uint32_t tx = tile % rp.tiles_x;
     const uint32_t ty = tile / rp.tiles_x;
     const uint32_t wave = tid >> 6;
@@ -101,8 +192,10 @@ RPT_DEV void blend(float4& acc, v3 rad, float v)
 // launch of S samples is bit-identical to S reference render() calls; the framebuffer
 // is read and written once per launch as float4 (16 B per lane, 128 B per 8-pixel row).
 template <class S>
-RPT_DEV void render_nested_body(const S& sc, const RenderParams& rp)
+RPT_DEV void render_nested_body(const S& sc, const RenderParams& launch)
 {
+    RenderParams rp = launch;
+    rp.n_chunks = 0u;                                               // (no units: one workgroup per tile, all samples)
     const PixelSetup ps = pixel_setup(rp);
     if (!ps.valid) return;
     float4* pix = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
@@ -157,7 +250,10 @@ __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_media_kernel)(con
 //    `shade_threshold` lanes are parked (wave ballot + popcount), or nobody is left to trace.  The
 //    expensive block therefore executes with most lanes active, while the cheap one absorbs the
 //    divergence.
-constexpr uint32_t kMaxSppPerLaunch = 512;
+#ifndef RPT_MAX_SPP_PER_LAUNCH
+#define RPT_MAX_SPP_PER_LAUNCH 512
+#endif
+constexpr uint32_t kMaxSppPerLaunch = RPT_MAX_SPP_PER_LAUNCH;
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd argument of
 // __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
@@ -180,10 +276,12 @@ struct LaneTables {
     float4* pix;               // [256] {coord.x, coord.y, bits(a), bits(b)}: a = pcg_hash(pixel_index), b = pcg_hash(a) (Rng::init)
 };
 
-// Fills the tables and this lane's slots.  False: the lane has no pixel, or the scene has max_depth == 0 (no bounce
-// loop at all: every sample's radiance is zero and the lane's pixel is finished here) — the caller returns.
-RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderParams& rp)
+// Takes the workgroup's unit (unit_begin), fills the tables and this lane's slots.  `rp`: the unit's share of the launch.
+// False: the lane has no pixel, or the scene has max_depth == 0 (no bounce loop at all: every sample's radiance is zero and
+// the lane's pixel is finished here) — the caller returns.
+RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderParams& launch, RenderParams& rp)
 {
+    unit_begin(launch, rp);
     for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
         const uint64_t frames = rp.frames_done + i;
         lt.fkey[i] = frame_key_hd(rp.seed, frames);
@@ -192,21 +290,31 @@ RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderPa
     __syncthreads();
     if (max_depth == 0) {                                           // (its own address computation: sharing the one below keeps the
         const PixelSetup ps0 = pixel_setup(rp);                     //  64-bit address live, and spilled, across the whole kernel)
+        const bool any0 = __ballot(ps0.valid) != 0ull;
         if (ps0.valid) {
             float4* pixel0 = reinterpret_cast<float4*>(rp.pixels) + ps0.pix_offset;
             float4 acc = *pixel0;
             for (uint32_t s = 0; s < rp.spp; ++s) blend(acc, mk3(0.0f, 0.0f, 0.0f), lt.weight[s]);
             *pixel0 = acc;
         }
+        unit_end(rp, any0);
         return false;
     }
     const PixelSetup ps = pixel_setup(rp);
+    if (__ballot(ps.valid) == 0ull) unit_end(rp, false);            // a wave without a pixel still counts for the tile's next chunk
     if (!ps.valid) return false;
     float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
     lt.acc[threadIdx.x] = *pixel;
     const uint32_t pix_a = pcg_hash(ps.pixel_index);
     lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(pix_a), rpt_u2f(pcg_hash(pix_a)));
     return true;
+}
+
+// The end of a state-machine kernel: the lane's running mean goes back to its pixel, the wave ends its unit.
+RPT_DEV void lane_finish(const RenderParams& rp, float4 acc)
+{
+    *pixel_address_again(rp) = acc;
+    unit_end(rp, true);
 }
 
 enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u, ST_MISS = 4u };
@@ -219,7 +327,7 @@ enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u, ST
 // with 34 % of the lanes, and the background inside TRACE with 46 % (profiles/r2/block_profile_c2.txt); replayed over the oracle's
 // path events (tools/sched_sim2.py, sim_finish_room) thresholds 56 / 24 cost 5 % less than that.
 template <class S>
-RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
+RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch)
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
@@ -227,7 +335,8 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
     const uint32_t tid = threadIdx.x;
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+    RenderParams rp;                                                // this workgroup's unit of the launch
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = ST_TRACE;
@@ -275,7 +384,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
         }
     }
     RPT_PROF_FLUSH();
-    *pixel_address_again(rp) = s_acc[tid];
+    lane_finish(rp, s_acc[tid]);
 }
 
 // The same kernel with FINISH un-voted at the top of every pass and the background inside TRACE (round 2's schedule): what large
@@ -283,7 +392,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& rp)
 // is a lane that does not walk, and the three-room loop above measured 2-4 % SLOWER (10 k spheres, 2048^2 x 32 spp: 1 675 vs
 // 1 611-1 648 Msamples/s at finishing thresholds 1-64; profiles/r3/experiments/).
 template <class S>
-RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& rp)
+RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& launch)
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
@@ -291,7 +400,8 @@ RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& rp)
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
     const uint32_t tid = threadIdx.x;
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+    RenderParams rp;                                                // this workgroup's unit of the launch
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = ST_TRACE;
@@ -336,7 +446,7 @@ RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& rp)
         }
     }
     RPT_PROF_FLUSH();
-    *pixel_address_again(rp) = s_acc[tid];
+    lane_finish(rp, s_acc[tid]);
 }
 
 #ifndef RPT_SMALL_WAVES_PER_SIMD
@@ -693,9 +803,11 @@ RPT_DEV bool compact_finish(const S& sc, const RenderParams& rp, uint32_t i, Pat
 // entries of S from thread 0 up and, at the same time, FINISH (background for a miss, blend, the pixel's next camera path)
 // for the entries of F from thread 255 down — |S| + |F| <= 256, so at most one wave has both kinds.
 template <class S>
-RPT_DEV void render_compact_body(const S& sc, const RenderParams& rp)
+RPT_DEV void render_compact_body(const S& sc, const RenderParams& launch)
 {
     constexpr bool M = S::kMedia;
+    RenderParams rp = launch;
+    rp.n_chunks = 0u;                                               // (no units: one workgroup per tile, all samples)
     __shared__ WfRecords rec;                                       // u[4] = sample index << 1 | "the ray left the scene"
     __shared__ uint8_t l_trace[2][256], l_shade[256], l_fin[256];   // path = pixel of the tile = thread that started it
     __shared__ uint32_t n_trace[2], n_shade[2], n_fin[2];
@@ -800,7 +912,7 @@ __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_
 enum : uint32_t { SM_MARCH_P = 0u, SM_MARCH_S = 1u, SM_RESOLVE = 2u, SM_SHADE = 3u, SM_DONE = 4u, SM_FINISH = 5u };
 
 template <class S>
-RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& rp)
+RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& launch)
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
@@ -809,7 +921,8 @@ RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& rp)
     __shared__ float4 s_pix[256];
     __shared__ float4 s_hit[256];                                   // parked hit point (the shadow march borrows p.ray.o)
     const uint32_t tid = threadIdx.x;
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+    RenderParams rp;                                                // this workgroup's unit of the launch
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = SM_MARCH_P;
@@ -896,7 +1009,7 @@ RPT_DEV void render_sdf_march_body(const S& sc, const RenderParams& rp)
         }
     }
     RPT_PROF_FLUSH();
-    *pixel_address_again(rp) = s_acc[tid];
+    lane_finish(rp, s_acc[tid]);
 }
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march_body(kernarg_scene(sc), rp); }
@@ -913,7 +1026,7 @@ __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_
 enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u };
 
 template <class S>
-RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
+RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch)
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
@@ -926,7 +1039,8 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
     float4* const s_shd = g_sdf_shd;                                // gain.w: t_useful of the path ray's march while the shadow ray is marched first
     float4* const s_gain = g_sdf_gain;
     const uint32_t tid = threadIdx.x;
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+    RenderParams rp;                                                // this workgroup's unit of the launch
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = S2_MARCH_P;
@@ -1047,7 +1161,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& rp)
         }
     }
     RPT_PROF_FLUSH();
-    *pixel_address_again(rp) = s_acc[tid];
+    lane_finish(rp, s_acc[tid]);
 }
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) 
@@ -1061,7 +1175,7 @@ __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_
 // lane in MARCH_P / MARCH_S has SUBMITTED its march and only polls for the answer; the marching itself is done by
 // whichever lanes of the workgroup are serving the queue.  Per pass a wave either runs one of its own blocks — when
 // `pool_block_lanes` lanes wait at it, or when there is no march work left to do meanwhile — or serves the queue.
-RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& rp)
+RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& launch)
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
@@ -1071,7 +1185,8 @@ RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& r
     __shared__ MarchPool pool;
     pool_init(pool);                                                // (lane_setup has the barrier)
     const uint32_t tid = threadIdx.x;
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, rp)) return;
+    RenderParams rp;                                                // this workgroup's unit of the launch
+    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
 
     uint32_t s = 0;
     uint32_t state = SM_MARCH_P;
@@ -1190,7 +1305,7 @@ RPT_DEV void render_sdf_pool_body(const SceneSmallSdf& sc, const RenderParams& r
         }
     }
     RPT_PROF_FLUSH();
-    *pixel_address_again(rp) = s_acc[tid];
+    lane_finish(rp, s_acc[tid]);
 }
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_pool_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_pool_body(kernarg_scene(sc), rp); }
@@ -1212,6 +1327,74 @@ __global__ __launch_bounds__(256) void RPT_K(untile_kernel)(const float4* __rest
     const uint32_t rank = gb % world;
     const uint32_t lrow = (gb / world) * tile_rows + (grow % tile_rows);
     image[idx] = gathered[((uint64_t)rank * rows_padded + lrow) * width + col];
+}
+
+// The dispatch order of a context's next launch from the costs its last one left (block_tile above): a counting sort of the
+// tiles by cost, descending, in one workgroup.  cost[t * 4 + w]: cycles / 64 for which wave w of tile t held its slot (0: the
+// wave had no pixel); a tile's cost is the sum over its waves — the slot time it takes.  Ties keep no particular order.
+constexpr uint32_t kOrderBuckets = 1024;
+// A tile's cost: the LONGEST time one of its waves held its slot.  (The sum over the waves — the slot time the tile takes — is the
+// wrong key: a tile on a silhouette, one expensive wave and three of sky, ends as late as a tile of four expensive waves.
+// configs[1]: by the sum 11.1, bottom rows first 11.4, by the maximum 11.7 Gsamples/s.)
+RPT_DEV uint32_t tile_key(uint4 c)
+{
+    const uint32_t a = c.x > c.y ? c.x : c.y, b = c.z > c.w ? c.z : c.w;
+    return a > b ? a : b;
+}
+__global__ __launch_bounds__(1024) void RPT_K(sched_order_kernel)(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n_tiles)
+{
+    __shared__ uint32_t s_bucket[kOrderBuckets];
+    __shared__ uint32_t s_scan[kOrderBuckets];
+    __shared__ uint32_t s_max;
+    const uint32_t tid = threadIdx.x;
+    s_bucket[tid] = 0u;
+    if (tid == 0u) s_max = 0u;
+    __syncthreads();
+    const uint4* cost4 = reinterpret_cast<const uint4*>(cost);
+    uint32_t m = 0u;
+    for (uint32_t t = tid; t < n_tiles; t += 1024u) {
+        const uint4 c = cost4[t];
+        const uint32_t sum = tile_key(c);
+        m = sum > m ? sum : m;
+    }
+    atomicMax(&s_max, m);
+    __syncthreads();
+    const uint32_t mx = s_max;
+    if (mx == 0u) return;                                           // nothing was recorded: the order stays what it is
+    const float scale = (float)(kOrderBuckets - 1u) / (float)mx;
+    const auto bucket_of = [&](uint32_t t) {
+        const uint4 c = cost4[t];
+        const uint32_t sum = tile_key(c);
+        uint32_t b = (uint32_t)((float)sum * scale);
+        b = b > kOrderBuckets - 1u ? kOrderBuckets - 1u : b;
+        return kOrderBuckets - 1u - b;                              // most expensive first
+    };
+    for (uint32_t t = tid; t < n_tiles; t += 1024u) atomicAdd(&s_bucket[bucket_of(t)], 1u);
+    __syncthreads();
+    // exclusive prefix sum over the buckets (Hillis-Steele on 1 024 entries, one per thread)
+    uint32_t v = s_bucket[tid];
+    const uint32_t own = v;
+    s_scan[tid] = v;
+    __syncthreads();
+    for (uint32_t off = 1u; off < kOrderBuckets; off <<= 1) {
+        const uint32_t add = tid >= off ? s_scan[tid - off] : 0u;
+        __syncthreads();
+        v += add;
+        s_scan[tid] = v;
+        __syncthreads();
+    }
+    s_bucket[tid] = v - own;                                        // where this bucket's tiles start
+    __syncthreads();
+    for (uint32_t t = tid; t < n_tiles; t += 1024u) order[atomicAdd(&s_bucket[bucket_of(t)], 1u)] = t;
+}
+
+// the order before anything is known: bottom rows first; and no costs yet
+__global__ __launch_bounds__(256) void RPT_K(sched_init_kernel)(uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n_tiles)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_tiles) return;
+    order[i] = n_tiles - 1u - i;
+    reinterpret_cast<uint4*>(cost)[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // Rust `as u8`: saturating, NaN -> 0, truncation toward zero.
@@ -1503,6 +1686,20 @@ hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const 
 }
 
 #ifndef RPT_RENDER_KERNELS_ONLY
+hipError_t sched_init(uint32_t* cost, uint32_t* order, uint32_t n_tiles, hipStream_t st)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(RPT_K(sched_init_kernel), dim3((n_tiles + 255u) / 256u), dim3(256), 0, st, cost, order, n_tiles);
+    return hipGetLastError();
+}
+
+hipError_t sched_order(const uint32_t* cost, uint32_t* order, uint32_t n_tiles, hipStream_t st)
+{
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(RPT_K(sched_order_kernel), dim3(1), dim3(1024), 0, st, cost, order, n_tiles);
+    return hipGetLastError();
+}
+
 hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
                   uint32_t rows_padded, hipStream_t st)
 {

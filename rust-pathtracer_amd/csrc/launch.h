@@ -49,6 +49,10 @@ hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneL
 // "anything left?" flag (it waits for the stream there: a bound of up to 256 iterations is enqueued blind).
 hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st,
                             bool media = false);
+// Cost-ordered dispatch (kernels.hip, block_tile): `cost` holds 4 dwords per tile, `order` one; init = bottom rows first and no
+// costs; order = the tiles sorted by the costs the last launch left, most expensive first.
+hipError_t sched_init(uint32_t* cost, uint32_t* order, uint32_t n_tiles, hipStream_t st);
+hipError_t sched_order(const uint32_t* cost, uint32_t* order, uint32_t n_tiles, hipStream_t st);
 hipError_t untile(const float* gathered, float* image, uint32_t width, uint32_t height, uint32_t tile_rows, uint32_t world,
                   uint32_t rows_padded, hipStream_t st);
 hipError_t convert_to_u8(const float* pixels, uint8_t* out, uint64_t n_pixels, hipStream_t st);

@@ -1,0 +1,157 @@
+"""Dispatch of the render launches (include/rpt.h, rpt_set_dispatch; kernels.hip, "Dispatch: units, their order, their hand-off"):
+the order of the tiles and the cutting of a launch's samples into chunks that are handed from workgroup to workgroup decide when
+and where a sample is computed — never its value.  Every case is compared bit for bit with the oracle or with the undivided
+launch.  Needs an MI355X."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import assert_bit_identical
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+# (cost_order, unit_rounds, unit_min_spp, unit_slots): pretending the device holds 8 workgroups makes small frames many rounds
+PLAIN = (0, 0, 64, 0)                 # bottom rows first, one unit per tile
+MANY_CHUNKS = (1, 100000, 1, 8)       # cost order, every sample its own chunk
+SOME_CHUNKS = (1, 40, 3, 8)
+
+
+def _render(rpt, torch, scene, w, h, spp, dispatch, steps=1, seed=1, flags=0):
+    t = rpt.Tracer(scene, device=0, seed=seed)
+    t.flags = flags
+    t.set_dispatch(*dispatch)
+    buf = rpt.DeviceColorBuffer(w, h)
+    for _ in range(steps):
+        t.render_n(buf, spp)
+    torch.cuda.synchronize()
+    img = buf.pixels.cpu().numpy()
+    t.close()
+    return img
+
+
+@pytest.mark.parametrize("dispatch", [PLAIN, MANY_CHUNKS, SOME_CHUNKS], ids=["plain", "one-sample-chunks", "chunks-of-3"])
+@pytest.mark.parametrize("size", [(160, 96), (333, 77), (64, 200)], ids=["160x96", "333x77-ragged", "64x200"])
+def test_chunked_launches_match_the_oracle(rpt, oracle, torch_cuda, dispatch, size):
+    """Ragged frames have tiles with waves that own no pixel at all: they must still count for the hand-off."""
+    w, h = size
+    spp = 10
+    s = rpt.AnalyticalScene()
+    want = oracle.render(s.describe(), w, h, spp, seed=1)
+    got = _render(rpt, torch_cuda, s, w, h, spp, dispatch)
+    assert_bit_identical(got, want, "%dx%d, dispatch %r" % (w, h, dispatch))
+
+
+def test_progressive_steps_learn_an_order_and_stay_exact(rpt, oracle, torch_cuda):
+    """Step k is dispatched in the order of step k - 1's costs; three steps of 7 samples are 21 render() calls."""
+    w, h = 208, 144
+    s = rpt.AnalyticalScene()
+    want = oracle.render(s.describe(), w, h, 21, seed=1)
+    for dispatch in (PLAIN, MANY_CHUNKS, SOME_CHUNKS):
+        got = _render(rpt, torch_cuda, s, w, h, 7, dispatch, steps=3)
+        assert_bit_identical(got, want, "3 x 7 spp, dispatch %r" % (dispatch,))
+
+
+def test_more_samples_than_the_kernel_tables_hold_is_one_launch(rpt, oracle, torch_cuda):
+    """The state-machine kernels keep a chunk's samples in LDS tables of 512 entries; 1 100 samples are chunks of one launch."""
+    w, h, spp = 48, 32, 1100
+    s = rpt.AnalyticalScene()
+    want = oracle.render(s.describe(), w, h, spp, seed=1)
+    for dispatch in (PLAIN, (1, 12, 64, 0), (1, 100, 100, 2)):
+        got = _render(rpt, torch_cuda, s, w, h, spp, dispatch)
+        assert_bit_identical(got, want, "1 100 spp, dispatch %r" % (dispatch,))
+
+
+def test_every_kernel_family_takes_chunks(rpt, oracle, torch_cuda):
+    from rust_pathtracer_amd import scenes
+    A = rpt._abi
+    cases = [("sdf two rooms", scenes.sdf_scene(), 0), ("sdf three rooms", scenes.sdf_scene(), A.RPT_RENDER_SDF_THREE_ROOM_MARCH),
+             ("sdf inline march", scenes.sdf_scene(), A.RPT_RENDER_SDF_INLINE_MARCH),
+             ("300 spheres", scenes.random_spheres_scene(300, 5), A.RPT_RENDER_LARGE_MEGAKERNEL),
+             ("media", scenes.media_scene(), 0), ("roulette", rpt.AnalyticalScene(), A.RPT_RENDER_RUSSIAN_ROULETTE)]
+    w, h, spp = 112, 80, 6
+    for name, scene, flags in cases:
+        oflags = flags & A.RPT_RENDER_RUSSIAN_ROULETTE
+        want = oracle.render(scene.describe(), w, h, spp, seed=1, render_flags=oflags)
+        for dispatch in (PLAIN, MANY_CHUNKS):
+            got = _render(rpt, torch_cuda, scene, w, h, spp, dispatch, flags=flags)
+            assert_bit_identical(got, want, "%s, dispatch %r" % (name, dispatch))
+
+
+def test_a_scene_without_bounces_with_chunks(rpt, oracle, torch_cuda):
+    s = rpt.AnalyticalScene()
+    s.max_depth = 0
+    w, h, spp = 100, 52, 9
+    want = oracle.render(s.describe(), w, h, spp, seed=1)
+    got = _render(rpt, torch_cuda, s, w, h, spp, MANY_CHUNKS)
+    assert_bit_identical(got, want, "max_depth 0, chunked")
+
+
+def test_rank_tiles_with_chunks(rpt, oracle, torch_cuda):
+    """One rank's rows of a row-tiled image (cyclic 2-row blocks), chunked: the rows of the full oracle frame it owns."""
+    from rust_pathtracer_amd import tiling
+    torch = torch_cuda
+    w, h, spp, world, tile_rows = 200, 120, 8, 3, 2
+    s = rpt.AnalyticalScene()
+    want = oracle.render(s.describe(), w, h, spp, seed=1)
+    t = rpt.Tracer(s, device=0, seed=1)
+    t.set_dispatch(*MANY_CHUNKS)
+    for rank in range(world):
+        rows = tiling.tile_global_rows(h, tile_rows, rank, world)
+        tile = torch.zeros(len(rows), w, 4, dtype=torch.float32, device="cuda")
+        t.render_tile(tile, w, h, 0, spp, tile_rows, rank, world)
+        torch.cuda.synchronize()
+        assert_bit_identical(tile.cpu().numpy(), want[rows], "rank %d of %d" % (rank, world))
+    t.close()
+
+
+def test_full_size_frame_in_32_chunks_equals_the_undivided_launch(rpt, torch_cuda):
+    """The hand-off under load: 8 160 tiles x 32 chunks of one sample on the real device geometry (every chunk's workgroups
+    wait for, acquire and re-read what another compute unit — usually another XCD — has just written), three steps so that the
+    order is the learned one; the whole frame must hash like the plain launches'."""
+    w, h, spp = 1920, 1080, 32
+    s = rpt.AnalyticalScene()
+    ref = _render(rpt, torch_cuda, s, w, h, spp, PLAIN, steps=3)
+    got = _render(rpt, torch_cuda, s, w, h, spp, (1, 1000, 1, 0), steps=3)
+    assert hashlib.sha1(got.tobytes()).hexdigest() == hashlib.sha1(ref.tobytes()).hexdigest()
+    got = _render(rpt, torch_cuda, s, w, h, spp, (1, 12, 8, 0), steps=3)
+    assert hashlib.sha1(got.tobytes()).hexdigest() == hashlib.sha1(ref.tobytes()).hexdigest()
+
+
+def test_the_dispatch_order_is_a_permutation_that_puts_expensive_tiles_first(rpt, torch_cuda):
+    torch = torch_cuda
+    w, h, spp = 640, 368, 32
+    t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
+    buf = rpt.DeviceColorBuffer(w, h)
+    n = (w // 16) * (h // 16)
+    raw = np.zeros(10 * n, dtype=np.uint32)
+    nt = C.c_uint32(0)
+    for step in range(3):
+        t.render_n(buf, spp)
+        rpt._lib.check(rpt.lib().rpt_debug_sched_read(t._h, raw.ctypes.data_as(C.POINTER(C.c_uint32)), n, C.byref(nt)), t._h)
+        assert nt.value == n
+        order = raw[4 * n:5 * n]
+        assert sorted(order.tolist()) == list(range(n)), "step %d: the dispatch order is not a permutation" % step
+        cost = raw[:4 * n].reshape(n, 4).max(axis=1).astype(np.float64)
+        assert (cost > 0).all(), "every tile of this frame has pixels in every wave"
+        along = cost[order]                                           # costs in dispatch order: non-increasing up to the bucket width
+        assert along[: n // 8].mean() > 3.0 * along[-n // 8:].mean(), "floor and spheres before sky"
+        assert (np.diff(along) <= cost.max() / 1024.0 * 2.0 + 1.0).all(), "step %d: not sorted by cost" % step
+    t.close()
+
+
+def test_set_dispatch_validates(rpt, torch_cuda):
+    A = rpt._abi
+    t = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
+    assert rpt.lib().rpt_set_dispatch(t._h, 7, 0, 0, 0) == A.RPT_ERR_INVALID_ARG
+    assert rpt.lib().rpt_set_dispatch(None, 1, 12, 64, 0) == A.RPT_ERR_INVALID_ARG
+    t.close()
