@@ -402,6 +402,12 @@ int rpt_resident_kernel_ms(rpt_ctx* ctx, float* ms);
 int rpt_resident_download(rpt_ctx* ctx, float* pixels);                 /* width*height*4 f32 */
 int rpt_resident_download_u8(rpt_ctx* ctx, uint8_t* frame);             /* convert_to_u8 on the device, width*height*4 bytes */
 int rpt_resident_reset(rpt_ctx* ctx);
+/* Page-lock a host buffer the caller will hand to rpt_resident_download[_u8] / rpt_render again and again (the redraw loop's
+ * frame, renderer/src/main.rs:122): copies to and from page-locked memory are one DMA at the link's rate (8.3 MB of a 1080p u8
+ * frame: ~0.2 ms), copies to pageable memory are staged by the runtime at ~7 GB/s (1.2 ms).  The buffer must stay allocated
+ * until rpt_host_unpin; a buffer the caller has registered with HIP itself is as good.  Not needed for correctness. */
+int rpt_host_pin(void* buffer, size_t bytes);
+int rpt_host_unpin(void* buffer);
 /* The resident image assembled ON THE ROOT DEVICE (no PCIe): RCCL gather of the tiles + scatter kernel, enqueued
  * behind the renders on the context's streams.  image_dev: width*height*4 f32 on rank 0's device (ignored on other
  * ranks; NULL = into the context's own staging image).  Returns without waiting; rpt_resident_sync waits.

@@ -165,6 +165,8 @@ SYMBOLS = {
     "rpt_resident_download": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_resident_download_u8": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rpt_resident_reset": (C.c_int, [C.c_void_p]),
+    "rpt_host_pin": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rpt_host_unpin": (C.c_int, [C.c_void_p]),
     "rpt_render_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64,
                                     C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     "rpt_tile_row_count": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -334,6 +334,7 @@ class Tracer:
         self._scene = scene
         self.seed = int(seed)
         self.flags = 0                 # RPT_RENDER_* bits (0 = the strict, bit-exact regenerating kernel)
+        self._frame = None             # resident_to_u8's page-locked frame
         self._h = C.c_void_p()
         if devices is not None:
             ids = (C.c_int * len(devices))(*devices)
@@ -406,10 +407,24 @@ class Tracer:
         b.frames = self.resident_frames()
         return b
 
-    def resident_to_u8(self, width, height):
-        out = np.zeros(width * height * 4, dtype=np.uint8)
-        check(lib().rpt_resident_download_u8(self._h, out.ctypes.data), self._h)
-        return out
+    def resident_to_u8(self, width, height, frame=None):
+        """buffer.convert_to_u8(frame) on the device + the 4 B per pixel over PCIe.  `frame`: the caller's uint8 array
+        (renderer/src/main.rs:122 passes the window's); None: the tracer's own page-locked frame, REUSED by the next call."""
+        if frame is None:
+            n = width * height * 4
+            if self._frame is None or self._frame.size != n:
+                self._drop_frame()
+                self._frame = np.zeros(n, dtype=np.uint8)
+                check(lib().rpt_host_pin(self._frame.ctypes.data, n))
+            frame = self._frame
+        assert frame.dtype == np.uint8 and frame.size == width * height * 4
+        check(lib().rpt_resident_download_u8(self._h, frame.ctypes.data), self._h)
+        return frame
+
+    def _drop_frame(self):
+        if getattr(self, "_frame", None) is not None:
+            lib().rpt_host_unpin(self._frame.ctypes.data)
+            self._frame = None
 
     def resident_reset(self):
         check(lib().rpt_resident_reset(self._h), self._h)
@@ -441,6 +456,7 @@ class Tracer:
                                       tile_rows, rank, world, C.c_void_p(stream)), self._h)
 
     def close(self):
+        self._drop_frame()
         if self._h:
             lib().rpt_destroy(self._h)
             self._h = C.c_void_p()

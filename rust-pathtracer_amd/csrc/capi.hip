@@ -80,6 +80,8 @@ struct rpt_ctx {
     float* gathered = nullptr;
     float* image = nullptr;
     uint8_t* frame_u8 = nullptr;
+    void* stage = nullptr;            // page-locked host staging for downloads into pageable buffers (download_to_host)
+    size_t stage_bytes = 0;
     hipEvent_t gather_consumed = nullptr;   // peer gather: recorded behind the scatter kernel that reads `gathered`
     bool timed = false;               // ev_begin / ev_end bracket a render
     std::string err;
@@ -383,18 +385,14 @@ static void free_resident(rpt_ctx* ctx)
     if (ctx->gathered) { (void)hipFree(ctx->gathered); ctx->gathered = nullptr; }
     if (ctx->image) { (void)hipFree(ctx->image); ctx->image = nullptr; }
     if (ctx->frame_u8) { (void)hipFree(ctx->frame_u8); ctx->frame_u8 = nullptr; }
+    if (ctx->stage) { (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
     if (ctx->gather_consumed) { (void)hipEventDestroy(ctx->gather_consumed); ctx->gather_consumed = nullptr; }
     ctx->has_res = false;
     ctx->res_w = ctx->res_h = ctx->res_tile_rows = ctx->res_rows_padded = 0;
     ctx->res_frames = 0;
 }
 
-static uint32_t rows_padded_for(uint32_t height, uint32_t tile_rows, uint32_t world)
-{
-    uint32_t m = 0;
-    for (uint32_t r = 0; r < world; ++r) { const uint32_t n = tile_row_count(height, tile_rows, r, world); m = n > m ? n : m; }
-    return m;
-}
+static uint32_t rows_padded_for(uint32_t height, uint32_t tile_rows, uint32_t world) { return tile_rows_padded(height, tile_rows, world); }
 
 // Copy the rows rank `rank` owns between a host top-down image and its compact tile (either direction), following
 // rpt_tile_copy_plan: one strided copy for the full blocks plus one plain copy when the rank owns the image's short last block.
@@ -1064,27 +1062,7 @@ uint32_t rpt_tile_rows_padded(uint32_t height, uint32_t tile_rows, uint32_t worl
 
 int rpt_tile_copy_plan(uint32_t height, uint32_t tile_rows, uint32_t rank, uint32_t world, rpt_tile_plan* out)
 {
-    if (!out || tile_rows == 0 || world == 0 || rank >= world || height == 0) return RPT_ERR_INVALID_ARG;
-    memset(out, 0, sizeof(*out));
-    if (world == 1) {                                                // everything is one block
-        out->full_blocks = 1; out->block_rows = height; out->host_row0 = 0; out->host_row_stride = height;
-        return RPT_OK;
-    }
-    const uint32_t nblocks = (height + tile_rows - 1u) / tile_rows;
-    if (rank >= nblocks) return RPT_OK;                              // this rank owns no row
-    const uint32_t nb = (nblocks - rank + world - 1u) / world;       // blocks of this rank: rank, rank + world, ...
-    const uint32_t last_b = rank + (nb - 1u) * world;
-    const bool ragged = (last_b == nblocks - 1u) && (height % tile_rows != 0u);
-    out->full_blocks = ragged ? nb - 1u : nb;
-    out->block_rows = tile_rows;
-    out->host_row0 = rank * tile_rows;
-    out->host_row_stride = world * tile_rows;
-    if (ragged) {
-        out->ragged_rows = height - last_b * tile_rows;
-        out->ragged_host_row0 = last_b * tile_rows;
-        out->ragged_tile_row0 = (nb - 1u) * tile_rows;
-    }
-    return RPT_OK;
+    return tile_copy_plan(height, tile_rows, rank, world, out);
 }
 
 int rpt_render_device(rpt_ctx* ctx, float* pixels_dev, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp,
@@ -1366,6 +1344,53 @@ int rpt_resident_sync(rpt_ctx* ctx)
     return RPT_OK;
 }
 
+int rpt_host_pin(void* buffer, size_t bytes)
+{
+    if (!buffer || bytes == 0) { set_err(nullptr, "rpt_host_pin: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    const hipError_t e = hipHostRegister(buffer, bytes, hipHostRegisterPortable);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return RPT_OK; }
+    if (e != hipSuccess) { (void)hipGetLastError(); set_err(nullptr, "rpt_host_pin: hipHostRegister failed: %s", hipGetErrorString(e)); return RPT_ERR_HIP; }
+    return RPT_OK;
+}
+
+int rpt_host_unpin(void* buffer)
+{
+    if (!buffer) { set_err(nullptr, "rpt_host_unpin: invalid argument"); return RPT_ERR_INVALID_ARG; }
+    const hipError_t e = hipHostUnregister(buffer);
+    if (e != hipSuccess) { (void)hipGetLastError(); set_err(nullptr, "rpt_host_unpin: hipHostUnregister failed: %s", hipGetErrorString(e)); return RPT_ERR_HIP; }
+    return RPT_OK;
+}
+
+// Is `p` page-locked host memory (hipHostMalloc / hipHostRegister)?  Then a copy to it is one DMA.
+static bool host_is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Device -> the caller's host buffer on the root's stream, then wait.  Page-locked destinations take the copy directly; a
+// pageable one goes through the context's page-locked staging buffer (one DMA + one memcpy: the runtime's own staging of
+// pageable copies runs at ~7 GB/s on this host, a third of that).
+static int download_to_host(rpt_ctx* ctx, void* dst, const void* src_dev, size_t bytes)
+{
+    DevState& root = ctx->devs[0];
+    if (host_is_pinned(dst)) {
+        RPT_HIP_CHECK(ctx, hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, root.stream));
+        return rpt_resident_sync(ctx);
+    }
+    if (bytes > ctx->stage_bytes) {
+        if (ctx->stage) { RPT_HIP_CHECK(ctx, hipHostFree(ctx->stage)); ctx->stage = nullptr; ctx->stage_bytes = 0; }
+        RPT_HIP_CHECK(ctx, hipHostMalloc(&ctx->stage, bytes, hipHostMallocDefault));
+        ctx->stage_bytes = bytes;
+    }
+    RPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->stage, src_dev, bytes, hipMemcpyDeviceToHost, root.stream));
+    const int rc = rpt_resident_sync(ctx);
+    if (rc != RPT_OK) return rc;
+    memcpy(dst, ctx->stage, bytes);
+    return RPT_OK;
+}
+
 int rpt_resident_download(rpt_ctx* ctx, float* pixels)
 {
     if (!ctx) { set_err(nullptr, "rpt_resident_download: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
@@ -1375,7 +1400,7 @@ int rpt_resident_download(rpt_ctx* ctx, float* pixels)
     if (rc != RPT_OK) return rc;
     DevState& root = ctx->devs[0];
     DeviceGuard guard(root.device);
-    if (ctx->is_root()) RPT_HIP_CHECK(ctx, hipMemcpyAsync(pixels, img, (size_t)ctx->res_w * ctx->res_h * 16u, hipMemcpyDeviceToHost, root.stream));
+    if (ctx->is_root()) return download_to_host(ctx, pixels, img, (size_t)ctx->res_w * ctx->res_h * 16u);
     return rpt_resident_sync(ctx);
 }
 
@@ -1392,7 +1417,7 @@ int rpt_resident_download_u8(rpt_ctx* ctx, uint8_t* frame)
         const size_t n = (size_t)ctx->res_w * ctx->res_h;
         if (!ctx->frame_u8) RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->frame_u8, n * 4u));
         RPT_HIP_CHECK(ctx, rptlaunch::convert_to_u8(img, ctx->frame_u8, n, root.stream));
-        RPT_HIP_CHECK(ctx, hipMemcpyAsync(frame, ctx->frame_u8, n * 4u, hipMemcpyDeviceToHost, root.stream));
+        return download_to_host(ctx, frame, ctx->frame_u8, n * 4u);
     }
     return rpt_resident_sync(ctx);
 }

@@ -823,6 +823,7 @@ RPT_DEV void render_compact_body(const S& sc, const RenderParams& launch)
         return;
     }
     if (tid < 2u) { n_trace[tid] = 0u; n_shade[tid] = 0u; n_fin[tid] = 0u; }
+    const uint32_t t0 = cost_clock();
     __syncthreads();
     if (ps.valid) {
         PathRegs p;
@@ -884,6 +885,8 @@ RPT_DEV void render_compact_body(const S& sc, const RenderParams& launch)
         }
         __syncthreads();
     }
+    // the workgroup's time, for the dispatch order of the next launch (its waves end together: one figure for all four)
+    if (rp.tile_cost && (tid & 63u) == 0u) rp.tile_cost[block_tile(rp) * 4u + (tid >> 6)] = cost_clock() - t0;
 }
 
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
@@ -1590,6 +1593,8 @@ namespace RPT_LAUNCH_NS {
 
 uint32_t max_spp_per_launch() { return kMaxSppPerLaunch; }
 
+static uint32_t compact_dense_max() { static const uint32_t v = getenv("RPT_COMPACT_DENSE_MAX") ? (uint32_t)atoi(getenv("RPT_COMPACT_DENSE_MAX")) : 3072u; return v; }
+
 hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, bool nested, const RenderParams& rp, uint32_t nblocks, hipStream_t st,
                   const SceneSmallSdf* scs_dev, bool media)
 {
@@ -1636,7 +1641,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), tiles, wg, 0, st, scs, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), tiles, wg, 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
-    else if (rp.compact && nblocks <= 3072u) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
+    else if (rp.compact && nblocks <= compact_dense_max()) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
     else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_kernel), tiles, wg, 0, st, sc, rp);
     else {
         // RPT_DEBUG_EXTRA_LDS (bytes, experiments only): pads the workgroup's LDS so that fewer waves fit a CU — how the

@@ -8,29 +8,7 @@
 #include "dev_scene_large.h"
 #include "dev_wavefront.h"
 
-namespace rptdev {
-
-// cyclic row-block tiling (multi-GPU): block b of `tile_rows` rows -> rank b % world
-__host__ __device__ inline uint32_t tile_global_row(uint32_t local_row, uint32_t tile_rows, uint32_t rank, uint32_t world)
-{
-    uint32_t lb = local_row / tile_rows;
-    return (lb * world + rank) * tile_rows + (local_row % tile_rows);
-}
-
-inline uint32_t tile_row_count(uint32_t height, uint32_t tile_rows, uint32_t rank, uint32_t world)
-{
-    if (tile_rows == 0 || world == 0 || rank >= world) return 0;
-    uint32_t nblocks = (height + tile_rows - 1) / tile_rows;        // last block may be short
-    uint32_t rows = 0;
-    for (uint32_t b = rank; b < nblocks; b += world) {
-        uint32_t start = b * tile_rows;
-        uint32_t n = (start + tile_rows <= height) ? tile_rows : (height - start);
-        rows += n;
-    }
-    return rows;
-}
-
-}  // namespace rptdev
+#include "tile_plan.h"
 
 namespace rptlaunch {
 
