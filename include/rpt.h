@@ -328,6 +328,12 @@ uint32_t rpt_abi_version(void);
 /* sizeof(rpt_scene_desc) as this library was built: a binding in another language asserts it against its own
  * mirror of the struct before the first rpt_upload_scene (rust/gpu_tracer.rs does). */
 uint32_t rpt_sizeof_scene_desc(void);
+/* 1 when the library was built with -DRPT_AB_KERNELS (python rust-pathtracer_amd/build.py --ab): it then holds every kernel form that was
+ * ever measured — the wavefront form of large scenes, the three-room and inline-march SDF kernels, the nested-loop kernels of every
+ * scene class, the forms under csrc/ab/ — for A/B timing and for the parity tests that run each form against the oracle.  The shipped
+ * library (0) holds the default form of every scene class, the compacting kernel of one-sample launches and one nested-loop baseline
+ * (small scenes without media); it answers the other forms' flags with RPT_ERR_UNSUPPORTED. */
+uint32_t rpt_build_has_ab_kernels(void);
 
 /* ---- the GPUs of one node (what replaces rayon's fan-out, tracer.rs:29-32) -----------------------------
  * The reference's only parallel construct is INSIDE render(): one rayon task per scanline.  Here the image is

@@ -140,6 +140,7 @@ class rpt_unique_id(C.Structure):
 # every symbol include/rpt.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rpt_sizeof_scene_desc": (C.c_uint32, []),
+    "rpt_build_has_ab_kernels": (C.c_uint32, []),
     "rpt_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
     "rpt_comm_unique_id": (C.c_int, [C.POINTER(rpt_unique_id)]),
     "rpt_create_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(rpt_unique_id)]),

@@ -1,7 +1,7 @@
 """Build the HIP extension (librpt_hip.so) for gfx950, in-tree.
 
     python rust-pathtracer_amd/build.py            # the shipped library
-    python rust-pathtracer_amd/build.py --ab       # + the measured-slower A/B kernel forms (csrc/ab/, -DRPT_AB_KERNELS)
+    python rust-pathtracer_amd/build.py --ab       # librpt_hip_ab.so: + every kernel form kept for A/B runs (-DRPT_AB_KERNELS); RPT_LIB selects it
 """
 import glob
 import os
@@ -99,5 +99,10 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="buil
     return lib
 
 
+AB_LIB = os.path.join(HERE, "librpt_hip_ab.so")           # every kernel form ever measured (-DRPT_AB_KERNELS), next to the shipped library
+
 if __name__ == "__main__":
-    print(build(force=True, verbose=True, ab="--ab" in sys.argv[1:]))
+    if "--ab" in sys.argv[1:]:                            # RPT_LIB=rust-pathtracer_amd/librpt_hip_ab.so python -m pytest tests -m gpu
+        print(build(force=True, verbose=True, ab=True, lib=AB_LIB, objdir_name="build_ab"))
+    else:
+        print(build(force=True, verbose=True))

@@ -504,6 +504,19 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     if (nblocks > 0x7FFFFFFFull) { set_err(ctx, "render: grid too large"); return RPT_ERR_INVALID_ARG; }
     if (flags & RPT_RENDER_GRID_RESUMABLE_WALK) { set_err(ctx, "render: RPT_RENDER_GRID_RESUMABLE_WALK was removed (measured slower, DESIGN.md 4b)"); return RPT_ERR_UNSUPPORTED; }
 #ifndef RPT_AB_KERNELS
+    // Forms that only A/B builds hold (kernels.hip, rptlaunch::render): refused loudly, never replaced by another form in silence.
+    {
+        const bool has_sdf = !ctx->large && scs.sdf.n_prims > 0;
+        const char* what = nullptr;
+        if ((flags & RPT_RENDER_NESTED_LOOPS) && (ctx->large || has_sdf || ctx->media)) what = "RPT_RENDER_NESTED_LOOPS for a large scene, an SDF object or media";
+        else if (has_sdf && (flags & RPT_RENDER_SDF_INLINE_MARCH)) what = "RPT_RENDER_SDF_INLINE_MARCH";
+        else if (has_sdf && (flags & RPT_RENDER_SDF_THREE_ROOM_MARCH)) what = "RPT_RENDER_SDF_THREE_ROOM_MARCH";
+        else if (ctx->large && scl.use_accel && scl.max_depth != 0u && wavefront_wanted(flags)) what = "RPT_RENDER_LARGE_WAVEFRONT";
+        if (what) {
+            set_err(ctx, "render: the A/B kernel form %s is not in this build (-DRPT_AB_KERNELS: python rust-pathtracer_amd/build.py --ab)", what);
+            return RPT_ERR_UNSUPPORTED;
+        }
+    }
     if (flags & RPT_RENDER_SDF_COMPACT) {
         set_err(ctx, "render: the A/B kernel RPT_RENDER_SDF_COMPACT is not in this build (-DRPT_AB_KERNELS)");
         return RPT_ERR_UNSUPPORTED;
@@ -569,7 +582,13 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     const bool unit_kernel = !wavefront && !nested && !(rp.compact && !ctx->large && scs.sdf.n_prims == 0) && !scs_dev;
     const SchedLayout lay{(size_t)nblocks};
     bool reorder = false;
-    const DispatchPolicy pol = policy_of(ctx);
+    DispatchPolicy pol = policy_of(ctx);
+    // workgroup slots of the device: 5 workgroups per CU (__launch_bounds__(256, 5))
+    static const int n_cu = []() { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+    const uint32_t slots = pol.unit_slots ? pol.unit_slots : (uint32_t)n_cu * 5u;
+    // The compacting kernel of one-sample launches below three rounds of workgroups stays bottom rows first: most expensive first
+    // costs 8 % at the reference's 800x600 window (1.5 rounds; 0.081 -> 0.088 ms) and gains 2 % at 1920x1080 (6.4 rounds).
+    if (!unit_kernel && nblocks < 3ull * slots) pol.cost_order = 0u;
     if (!wavefront && !nested && (pol.cost_order != 0u || unit_kernel)) {
         if (d.sched_tiles != (uint32_t)nblocks) {
             if (d.sched) { RPT_HIP_CHECK(ctx, hipFree(d.sched)); d.sched = nullptr; d.sched_tiles = 0; }   // (hipFree waits for the device)
@@ -594,9 +613,8 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     const uint32_t max_chunk = rptlaunch::max_spp_per_launch();
     if (unit_kernel) {
         // ONE launch whatever spp is: the LDS tables of the state-machine kernels hold a chunk's samples, and a launch is as many
-        // chunks as it takes.  Workgroup slots of the device: 5 workgroups per CU (__launch_bounds__(256, 5)).
-        static const int n_cu = []() { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-        uint32_t n_chunks = unit_chunks(pol, nblocks, spp, pol.unit_slots ? pol.unit_slots : (uint32_t)n_cu * 5u);
+        // chunks as it takes.
+        uint32_t n_chunks = unit_chunks(pol, nblocks, spp, slots);
         uint32_t chunk_spp = (spp + n_chunks - 1u) / n_chunks;
         if (chunk_spp > max_chunk) chunk_spp = max_chunk;
         n_chunks = (spp + chunk_spp - 1u) / chunk_spp;
@@ -688,6 +706,14 @@ extern "C" {
 
 uint32_t rpt_abi_version(void) { return RPT_ABI_VERSION; }
 uint32_t rpt_sizeof_scene_desc(void) { return (uint32_t)sizeof(rpt_scene_desc); }
+uint32_t rpt_build_has_ab_kernels(void)
+{
+#ifdef RPT_AB_KERNELS
+    return 1u;
+#else
+    return 0u;
+#endif
+}
 
 const char* rpt_last_error(const rpt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 

@@ -229,10 +229,14 @@ template <class S>
 RPT_DEV const S& kernarg_scene(const S& by_value) { return by_value; }
 #endif
 
+// The shipped library holds ONE nested-loop kernel, the baseline of the reference's own scene class; the other scene classes' only
+// in A/B builds (-DRPT_AB_KERNELS, build.py --ab), where the parity tests run every form against the oracle.
 __global__ __launch_bounds__(256) void RPT_K(render_small_nested_kernel)(const SceneSmall sc, const RenderParams rp) { render_nested_body(kernarg_scene(sc), rp); }
+#ifdef RPT_AB_KERNELS
 __global__ __launch_bounds__(256) void RPT_K(render_large_nested_kernel)(const SceneLarge sc, const RenderParams rp) { render_nested_body(kernarg_scene(sc), rp); }
 __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(kernarg_scene(sc), rp); }
-#ifndef RPT_NO_MEDIA_KERNELS
+#endif
+#if defined(RPT_AB_KERNELS) && !defined(RPT_NO_MEDIA_KERNELS)
 // The same kernels for scenes with participating media (dev_scene.h WithMedia, dev_media.h): every form below has one.
 __global__ __launch_bounds__(256) void RPT_K(render_small_nested_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_nested_body(kernarg_scene(sc), rp); }
 __global__ __launch_bounds__(256) void RPT_K(render_large_nested_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_nested_body(kernarg_scene(sc), rp); }
@@ -475,12 +479,16 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 #define RPT_LARGE_WAVES_PER_SIMD 5
 #endif
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
-// Small scenes with the procedural SDF object (sphere marching inside closest_hit / any_hit).
+#ifdef RPT_AB_KERNELS
+// Small scenes with the procedural SDF object, the sphere march inside closest_hit / any_hit (RPT_RENDER_SDF_INLINE_MARCH): A/B builds.
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body_tf(kernarg_scene(sc), rp); }
+#endif
 #ifndef RPT_NO_MEDIA_KERNELS
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_regen_body(kernarg_scene(sc), rp); }
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
+#ifdef RPT_AB_KERNELS
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_regen_body_tf(kernarg_scene(sc), rp); }
+#endif
 #endif
 
 #ifdef RPT_AB_KERNELS
@@ -488,6 +496,7 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_rege
 #include "ab/kernel_large_carry.h"
 #endif
 
+#ifdef RPT_AB_KERNELS    // the wavefront form of large scenes (RPT_RENDER_LARGE_WAVEFRONT): A/B builds only since round 4 (the megakernel is ahead at every size)
 // Large scenes as a wavefront (dev_wavefront.h): WALK(k) walks the rays SHADE(k-1) listed, SHADE(k) does the rest of the bounce
 // for every slot that still has work and lists the next rays.
 #ifndef RPT_WF_WALK_WAVES_PER_SIMD
@@ -510,6 +519,8 @@ __global__ __launch_bounds__(256, RPT_WF_WALK_WAVES_PER_SIMD) void RPT_K(wf_walk
     wf_walk_body(sc, wb, refill_at);
     RPT_PROF_FLUSH();
 }
+
+#endif
 
 // One workgroup per 256 slots (= pixels of the tile), in four stages with the workgroup's slots RE-DEALT to its threads in
 // between, so that each expensive block runs on full waves whatever the mix of outcomes:
@@ -573,6 +584,7 @@ RPT_DEV void wf_list_add(T* list, uint32_t* count, bool want, uint32_t value)
     if (want) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (T)value;
 }
 
+#ifdef RPT_AB_KERNELS
 template <class S>
 RPT_DEV void wf_shade_body(const S& sc, const RenderParams& rp, const WfBuffers& wb, uint32_t parity, uint32_t first)
 {
@@ -769,6 +781,7 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
     wf_shade_body(kernarg_scene(sc), rp, wb, parity, first);
 }
 #endif
+#endif  // RPT_AB_KERNELS (wavefront form)
 
 // Small scenes, FEW samples per launch (the reference's own usage: one render() per redraw).  With nothing to regenerate a
 // wave of the megakernel drains: its lanes end one by one and the wave runs on for its longest path.  Here the workgroup's 256
@@ -891,8 +904,9 @@ RPT_DEV void render_compact_body(const S& sc, const RenderParams& launch)
 
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
 // Frames of a few thousand workgroups (the reference's 800x600 window: 1 875) are a question of how many ROUNDS of workgroups the
-// chip needs: six resident per CU (80 VGPRs, 112 B of scratch) make that 1.2 instead of 1.5 rounds, 0.096 instead of 0.101 ms;
-// from 1080p up the five-per-CU build is 1 % faster.
+// chip needs: six resident per CU make that 1.2 instead of 1.5 rounds.  The price is 80 VGPRs, 35 of the kernel's ~100 live values
+// in scratch (116 B per lane, L1/L2-resident at this launch size) — and it is worth it: 800x600 x 1 spp 0.0809 ms against 0.0914
+// with five per CU and no spill to speak of (round 4, tools/compact_time.py); from 1080p up the five-per-CU build is 1 % faster.
 __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
 #ifndef RPT_NO_MEDIA_KERNELS
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
@@ -902,6 +916,7 @@ __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_
 #include "ab/kernel_sdf_compact.h"
 #endif
 
+#ifdef RPT_AB_KERNELS    // round 2's three-room march kernel (RPT_RENDER_SDF_THREE_ROOM_MARCH): A/B builds only since round 4
 // SDF scenes, resumable march (dev_sdf_path.h).  Per lane:
 //   MARCH_P --(march over)--> RESOLVE --(miss / emitter)--> next sample: MARCH_P
 //                                     --(surface)--> MARCH_S --(march over)--> SHADE --> MARCH_P
@@ -1019,6 +1034,7 @@ __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_
 #ifndef RPT_NO_MEDIA_KERNELS
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march_body(kernarg_scene(sc), rp); }
 #endif
+#endif  // RPT_AB_KERNELS (three-room march)
 
 // SDF scenes, two rooms (dev_sdf_path.h, SdfDeferredQuery).  Per lane:
 //   [MARCH_S: the parked shadow ray of the bounce just shaded] -> MARCH_P: the path ray -> WAIT -> one block: add the parked light
@@ -1593,8 +1609,9 @@ namespace RPT_LAUNCH_NS {
 
 uint32_t max_spp_per_launch() { return kMaxSppPerLaunch; }
 
-static uint32_t compact_dense_max() { static const uint32_t v = getenv("RPT_COMPACT_DENSE_MAX") ? (uint32_t)atoi(getenv("RPT_COMPACT_DENSE_MAX")) : 3072u; return v; }
-
+// Which forms a build holds: the shipped library the default form of every scene class, the compacting kernel of one-sample
+// launches and ONE nested-loop baseline (small scenes without media); builds with -DRPT_AB_KERNELS every form ever measured.
+// A form that is not there is hipErrorNotSupported here and RPT_ERR_UNSUPPORTED at the C ABI (capi.hip checks the flags first).
 hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, bool nested, const RenderParams& rp, uint32_t nblocks, hipStream_t st,
                   const SceneSmallSdf* scs_dev, bool media)
 {
@@ -1602,19 +1619,25 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     const SceneSmall sc = scs;                                       // the plain part (slicing is intended)
     const dim3 tiles(nblocks), wg(256);
     (void)hipGetLastError();                                         // the thread's sticky error may be somebody else's (a host process's own HIP calls)
+    (void)scs_dev;
     if (media) {
 #ifndef RPT_NO_MEDIA_KERNELS
-        // scenes with participating media: the same forms, instantiated for WithMedia<Scene> (the A/B kernels have none)
+        // scenes with participating media: the same forms, instantiated for WithMedia<Scene> (csrc/ab/ has none)
         const WithMedia<SceneSmall> msc(sc);
         const WithMedia<SceneSmallSdf> mscs(scs);
         const WithMedia<SceneLarge> mscl(scl);
-        if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_media_kernel), tiles, wg, 0, st, mscl, rp);
-        else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_media_kernel), tiles, wg, 0, st, mscl, rp);
+        if (false) {}
+#ifdef RPT_AB_KERNELS
+        else if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_media_kernel), tiles, wg, 0, st, mscl, rp);
         else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_media_kernel), tiles, wg, 0, st, mscs, rp);
-        else if (has_sdf && rp.sdf_resumable_march == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, mscs, rp);
-        else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_media_kernel), tiles, wg, 0, st, mscs, rp);
-        else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_media_kernel), tiles, wg, 0, st, mscs, rp);
         else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_media_kernel), tiles, wg, 0, st, msc, rp);
+        else if (has_sdf && rp.sdf_resumable_march == 1u) hipLaunchKernelGGL(RPT_K(render_sdf_march_media_kernel), tiles, wg, 0, st, mscs, rp);
+        else if (has_sdf && rp.sdf_resumable_march == 0u) hipLaunchKernelGGL(RPT_K(render_sdf_regen_media_kernel), tiles, wg, 0, st, mscs, rp);
+#else
+        else if (nested || (has_sdf && rp.sdf_resumable_march != 4u)) return hipErrorNotSupported;
+#endif
+        else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_media_kernel), tiles, wg, 0, st, mscl, rp);
+        else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, mscs, rp);
         else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_media_kernel), tiles, wg, 0, st, msc, rp);
         else hipLaunchKernelGGL(RPT_K(render_small_regen_media_kernel), tiles, wg, 0, st, msc, rp);
         return hipGetLastError();
@@ -1622,26 +1645,23 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
         return hipErrorNotSupported;
 #endif
     }
-    if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), tiles, wg, 0, st, scl, rp);
+    if (false) {}
 #ifdef RPT_AB_KERNELS
+    else if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), tiles, wg, 0, st, scl, rp);
     else if (large && rp.large_pair_walk && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_pair_kernel), tiles, wg, 0, st, scl, rp);
-#endif
-#ifdef RPT_AB_KERNELS
     else if (large && rp.large_carry_walk && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_carry_kernel), tiles, wg, 0, st, scl, rp);
+    else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), tiles, wg, 0, st, scs, rp);
+    else if (has_sdf && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), tiles, wg, 0, st, scs, rp);
+    else if (has_sdf && rp.sdf_resumable_march == 3u && scs_dev) hipLaunchKernelGGL(RPT_K(render_sdf_compact_kernel), tiles, wg, 0, st, scs_dev, rp);
+    else if (has_sdf && rp.sdf_resumable_march == 1u) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), tiles, wg, 0, st, scs, rp);
+    else if (has_sdf && rp.sdf_resumable_march == 0u) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), tiles, wg, 0, st, scs, rp);
+#else
+    else if ((nested && (large || has_sdf)) || (has_sdf && rp.sdf_resumable_march != 4u)) return hipErrorNotSupported;
 #endif
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), tiles, wg, 0, st, scl, rp);
-    else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), tiles, wg, 0, st, scs, rp);
-#ifdef RPT_AB_KERNELS
-    else if (has_sdf && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), tiles, wg, 0, st, scs, rp);
-#endif
-#ifdef RPT_AB_KERNELS
-    else if (has_sdf && rp.sdf_resumable_march == 3u && scs_dev) hipLaunchKernelGGL(RPT_K(render_sdf_compact_kernel), tiles, wg, 0, st, scs_dev, rp);
-#endif
-    else if (has_sdf && rp.sdf_resumable_march == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_kernel), tiles, wg, 0, st, scs, rp);
-    else if (has_sdf && rp.sdf_resumable_march) hipLaunchKernelGGL(RPT_K(render_sdf_march_kernel), tiles, wg, 0, st, scs, rp);
-    else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_regen_kernel), tiles, wg, 0, st, scs, rp);
+    else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_march2_kernel), tiles, wg, 0, st, scs, rp);
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
-    else if (rp.compact && nblocks <= compact_dense_max()) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
+    else if (rp.compact && nblocks <= 3072u) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
     else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_kernel), tiles, wg, 0, st, sc, rp);
     else {
         // RPT_DEBUG_EXTRA_LDS (bytes, experiments only): pads the workgroup's LDS so that fewer waves fit a CU — how the
@@ -1652,6 +1672,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     return hipGetLastError();
 }
 
+#ifdef RPT_AB_KERNELS
 hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const WfBuffers& wb, hipStream_t st, bool media)
 {
     static const uint32_t refill_at = getenv("RPT_WF_REFILL_AT") ? ((uint32_t)atoi(getenv("RPT_WF_REFILL_AT")) & 63u) : 40u;
@@ -1689,6 +1710,9 @@ hipError_t render_wavefront(const SceneLarge& sc, const RenderParams& rp, const 
     }
     return hipGetLastError();
 }
+#else
+hipError_t render_wavefront(const SceneLarge&, const RenderParams&, const WfBuffers&, hipStream_t, bool) { return hipErrorNotSupported; }
+#endif
 
 #ifndef RPT_RENDER_KERNELS_ONLY
 hipError_t sched_init(uint32_t* cost, uint32_t* order, uint32_t n_tiles, hipStream_t st)

@@ -65,6 +65,26 @@ def rpt():
     return load_package()
 
 
+def ab_built():
+    """Does the library under test hold the kernel forms kept for A/B runs (include/rpt.h, rpt_build_has_ab_kernels)?  The shipped
+    library does not; `python rust-pathtracer_amd/build.py --ab` + RPT_LIB=rust-pathtracer_amd/librpt_hip_ab.so runs the tests on one that does."""
+    return bool(load_package().lib().rpt_build_has_ab_kernels())
+
+
+def only_in_ab_builds(*items):
+    """`items` when the library holds the A/B kernel forms, nothing otherwise: for loops over kernel forms."""
+    return tuple(items) if ab_built() else ()
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    """A test that asks the shipped library for an A/B-only kernel form is skipped from there on (what it checked before stands)."""
+    outcome = yield
+    exc = outcome.excinfo
+    if exc and exc[0].__name__ == "RptError" and "-DRPT_AB_KERNELS" in str(exc[1]):
+        outcome.force_exception(pytest.skip.Exception("needs a library with the A/B kernel forms (build.py --ab): %s" % exc[1]))
+
+
 def has_gpu():
     try:
         import torch

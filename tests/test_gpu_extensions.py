@@ -4,6 +4,8 @@ light types (RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES).  Bit-identical to the oracle lik
 import numpy as np
 import pytest
 
+import conftest
+
 from test_gpu_parity import assert_bit_identical
 
 pytestmark = pytest.mark.gpu
@@ -109,17 +111,21 @@ def test_context_scratch_is_ordered_across_streams(rpt, oracle):
     s = scenes.random_spheres_scene(n_spheres=400, n_lights=4)
     w, h, spp = 96, 64, 3
     t = rpt.Tracer(s, device=0, seed=5)
-    t.flags = rpt._abi.RPT_RENDER_LARGE_WAVEFRONT
     want = oracle.render(s.describe(), w, h, spp, seed=5)
-    bufs = [rpt.DeviceColorBuffer(w, h) for _ in range(4)]
     streams = [torch.cuda.Stream() for _ in range(2)]
-    torch.cuda.synchronize()
-    for i, b in enumerate(bufs):
-        with torch.cuda.stream(streams[i % 2]):
-            t.render_n(b, spp)
-    torch.cuda.synchronize()
-    for i, b in enumerate(bufs):
-        assert_bit_identical(b.pixels.cpu().numpy(), want, "wavefront launch %d on stream %d" % (i, i % 2))
+    # the megakernel's dispatch tables (tile costs, order, hand-off words: rpt_set_dispatch) and, in A/B builds, the wavefront form's
+    # path buffers
+    for form, flags in (("megakernel in one-sample chunks", 0),) + conftest.only_in_ab_builds(("wavefront", rpt._abi.RPT_RENDER_LARGE_WAVEFRONT)):
+        t.flags = flags
+        t.set_dispatch(1, 1000, 1, 4)
+        bufs = [rpt.DeviceColorBuffer(w, h) for _ in range(4)]
+        torch.cuda.synchronize()
+        for i, b in enumerate(bufs):
+            with torch.cuda.stream(streams[i % 2]):
+                t.render_n(b, spp)
+        torch.cuda.synchronize()
+        for i, b in enumerate(bufs):
+            assert_bit_identical(b.pixels.cpu().numpy(), want, "%s, launch %d on stream %d" % (form, i, i % 2))
     dn_want = oracle.denoise(want, w, h, 4, 2.0)
     outs = []
     for i in range(4):

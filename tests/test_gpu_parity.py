@@ -10,6 +10,8 @@ import ctypes as C
 import numpy as np
 import pytest
 
+import conftest
+
 pytestmark = pytest.mark.gpu
 
 
@@ -335,7 +337,7 @@ def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
     t = rpt.Tracer(s, device=0, seed=5)
     # the default form (at this size: the grid walk inside the megakernel, from 64 spheres up); nested loops; then both forms
     # forced: the wavefront (walks in their own kernel) and the megakernel (scenes without a grid ignore the two flags)
-    for flags in (0, rpt._abi.RPT_RENDER_NESTED_LOOPS, rpt._abi.RPT_RENDER_LARGE_WAVEFRONT, rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL):
+    for flags in (0, rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL) + conftest.only_in_ab_builds(rpt._abi.RPT_RENDER_NESTED_LOOPS, rpt._abi.RPT_RENDER_LARGE_WAVEFRONT):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -359,7 +361,7 @@ def test_large_scene_both_tiers_of_cell_lists(rpt, oracle, cam, look, reach, mon
     w, h, spp = 112, 63, 3
     t = rpt.Tracer(s, device=0, seed=7)
     want = oracle.render(s.describe(), w, h, spp, seed=7)
-    for flags in (rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL, rpt._abi.RPT_RENDER_LARGE_WAVEFRONT):
+    for flags in (rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL,) + conftest.only_in_ab_builds(rpt._abi.RPT_RENDER_LARGE_WAVEFRONT):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -412,7 +414,7 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
         s.any_hit_uses_max_dist = use_max
         t = rpt.Tracer(s, device=0, seed=9)
         want = oracle.render(s.describe(), w, h, spp, seed=9)
-        for flags in (0, rpt._abi.RPT_RENDER_SDF_THREE_ROOM_MARCH, rpt._abi.RPT_RENDER_SDF_INLINE_MARCH, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+        for flags in (0,) + conftest.only_in_ab_builds(rpt._abi.RPT_RENDER_SDF_THREE_ROOM_MARCH, rpt._abi.RPT_RENDER_SDF_INLINE_MARCH, rpt._abi.RPT_RENDER_NESTED_LOOPS):
             t.flags = flags
             buf = rpt.ColorBuffer(w, h)
             t.render_n(buf, spp)
@@ -670,7 +672,7 @@ def test_random_large_scenes_match_oracle_in_both_forms(rpt, oracle, seed):
     rflags = A.RPT_RENDER_RUSSIAN_ROULETTE if seed % 3 == 0 else 0
     want = oracle.render(s.describe(), w, h, spp, seed=seed, render_flags=rflags)
     t = rpt.Tracer(s, device=0, seed=seed)
-    for form in (A.RPT_RENDER_LARGE_WAVEFRONT, A.RPT_RENDER_LARGE_MEGAKERNEL):
+    for form in (A.RPT_RENDER_LARGE_MEGAKERNEL,) + conftest.only_in_ab_builds(A.RPT_RENDER_LARGE_WAVEFRONT):
         t.flags = form | rflags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -704,7 +706,7 @@ def test_random_sdf_scenes_match_oracle(rpt, oracle, seed):
     w, h, spp = int(rng.integers(8, 90)), int(rng.integers(8, 60)), int(rng.integers(1, 4))
     want = oracle.render(s.describe(), w, h, spp, seed=seed)
     t = rpt.Tracer(s, device=0, seed=seed)
-    for flags in (0, A.RPT_RENDER_SDF_THREE_ROOM_MARCH, A.RPT_RENDER_SDF_INLINE_MARCH, A.RPT_RENDER_NESTED_LOOPS):
+    for flags in (0,) + conftest.only_in_ab_builds(A.RPT_RENDER_SDF_THREE_ROOM_MARCH, A.RPT_RENDER_SDF_INLINE_MARCH, A.RPT_RENDER_NESTED_LOOPS):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -924,7 +926,8 @@ def test_fast_math_mode_in_the_other_kernels(rpt, torch_cuda):
     from rust_pathtracer_amd import scenes
     A = rpt._abi
     cases = [("compact", rpt.AnalyticalScene(), A.RPT_RENDER_SMALL_COMPACT, 256, 144, 32),
-             ("wavefront", scenes.random_spheres_scene(n_spheres=400, n_lights=6), A.RPT_RENDER_LARGE_WAVEFRONT, 192, 108, 24)]
+             ("large scene", scenes.random_spheres_scene(n_spheres=400, n_lights=6), A.RPT_RENDER_LARGE_MEGAKERNEL, 192, 108, 24)]
+    cases += conftest.only_in_ab_builds(("wavefront", scenes.random_spheres_scene(n_spheres=400, n_lights=6), A.RPT_RENDER_LARGE_WAVEFRONT, 192, 108, 24))
     for name, scene, form, w, h, spp in cases:
         t = rpt.Tracer(scene, device=0, seed=2)
         t.flags = form
