@@ -219,11 +219,33 @@ RPT_DEV float grid_cell_exit(const GridWalk& g)
     return m < g.tmz ? m : g.tmz;
 }
 
-RPT_DEV void grid_step(const SceneLarge& sc, GridWalk& g)
+RPT_DEV void grid_step(const SceneLarge& sc, GridWalk& g)                   // (the wavefront walk and csrc/ab/: a step with its in-range test)
 {
     if (g.tmx <= g.tmy && g.tmx <= g.tmz) { g.ix += g.sx; g.tmx += g.tdx; g.alive = (g.ix >= 0) && (g.ix < (int)sc.gn[0]); }
     else if (g.tmy <= g.tmz) { g.iy += g.sy; g.tmy += g.tdy; g.alive = (g.iy >= 0) && (g.iy < (int)sc.gn[1]); }
     else { g.iz += g.sz; g.tmz += g.tdz; g.alive = (g.iz >= 0) && (g.iz < (int)sc.gn[2]); }
+}
+
+// The megakernel's step (round 4).  Selects, not a three-way branch: every lane of a wave takes its own way, so all three arms ran
+// anyway, each behind its own exec-mask bookkeeping on the scalar unit.  And no in-range test of the new cell: the walks below end
+// when the ray leaves the grid BOX (t_exit > t_end, which they test anyway) and clamp the cell index instead.  Should rounding
+// let the indices leave the grid a step before the exit time says so, the walk tests the spheres of a cell it need not have
+// visited, which cannot change its answer: the answer is the nearest (any) hit among ALL spheres — the reference's loop tests
+// every one — and a walk is right as long as the cells it MUST visit are among those it visits.
+RPT_DEV void grid_advance(GridWalk& g)
+{
+    const bool ax = g.tmx <= g.tmy && g.tmx <= g.tmz;
+    const bool ay = !ax && g.tmy <= g.tmz;
+    const bool az = !ax && !ay;
+    g.ix += ax ? g.sx : 0; g.iy += ay ? g.sy : 0; g.iz += az ? g.sz : 0;
+    g.tmx = ax ? g.tmx + g.tdx : g.tmx; g.tmy = ay ? g.tmy + g.tdy : g.tmy; g.tmz = az ? g.tmz + g.tdz : g.tmz;
+}
+
+RPT_DEV uint32_t grid_cell_index_clamped(const SceneLarge& sc, const GridWalk& g)
+{
+    const uint32_t last = sc.gn[0] * sc.gn[1] * sc.gn[2] - 1u;     // (scalar)
+    const uint32_t c = ((uint32_t)g.iz * sc.gn[1] + (uint32_t)g.iy) * sc.gn[0] + (uint32_t)g.ix;     // an index outside the grid wraps or aliases: any cell will do
+    return (c < last ? c : last) + g.coff;
 }
 
 // nearest sphere along the ray (dist/best in-out), equivalent to the ordered loop over all spheres
@@ -263,16 +285,23 @@ RPT_DEV bool brute_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_ma
 RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& dist, uint32_t& best, bool& hit)
 {
     if (!grid_usable(sc, ray)) { brute_closest_sphere(sc, ray, dist, best, hit); return; }
+    // `hit` and "a candidate is parked" as WORDS in vector registers: as bools the compiler keeps them as lane masks in SGPRs and
+    // merges them with scalar instructions at every join of the walk's nested branches — and the scalar unit, one per CU for its
+    // four SIMDs, issues one instruction for every two vector ones in this kernel (profiles/r3/c5_megakernel: 2.3e10 SALU + 5.5e9
+    // branches against 4.6e10 VALU).  10 k spheres, 2048^2 x 32 spp: 2 138 -> 2 212 Msamples/s (+3.5 %), round 4.
+    uint32_t hit_w = hit ? 1u : 0u;
+#define RPT_HIT_SET() (hit_w = 1u)
+#define RPT_HIT() (hit_w != 0u)
     {   // sphere 0: accepted whenever it is hit (analytical.rs:43)
         const float4 s = sphere_uniform(sc, 0);
         float t;
-        if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; hit = true; }
+        if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; RPT_HIT_SET(); }
     }
     for (uint32_t j = 0; j < sc.n_oversize; ++j) {                  // the spheres that are not in the grid (wave-uniform loop)
         const uint32_t i = ((cuint_p)sc.oversize)[j];
         const float4 s = sphere_uniform(sc, i);
         float t;
-        if (i != 0u && hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (t < dist || (t == dist && i < best))) { dist = t; best = i; hit = true; }
+        if (i != 0u && hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (t < dist || (t == dist && i < best))) { dist = t; best = i; RPT_HIT_SET(); }
     }
     GridWalk g;
     { RPT_PROF(PB_GRID_BEGIN); g = grid_begin(sc, ray); }
@@ -281,12 +310,14 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
     // A DDA crosses at most nx+ny+nz cells; the guard guarantees every wave leaves the loop.
     uint32_t k0 = 0, k1 = 0;
     if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
-    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
+    if (g.alive)
+    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; guard != 0u; --guard) {
         RPT_PROF(PB_GRID_CELL);
         const float t_exit = grid_cell_exit(g);                     // of the cell whose list is [k0, k1)
-        grid_step(sc, g);                                           // g is the NEXT cell from here on
-        uint32_t n0 = 0, n1 = 0;
-        if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), n0, n1);
+        const bool last = t_exit > g.t_end;                         // the ray leaves the grid box in this cell
+        grid_advance(g);                                            // g is the NEXT cell from here on
+        uint32_t n0, n1;
+        cell_bounds(sc, grid_cell_index_clamped(sc, g), n0, n1);    // (also when this is the last cell: the index is always a cell's, and an unconditional load needs no exec mask)
         // The cell's list, RPT_GRID_BATCH entries per trip: the loads go out together, hit_sphere's discriminant is computed
         // branch-free for all of them and only candidates (the line meets the sphere: few) take its square-root half.  The
         // acceptance rule is order-independent, so neither batching nor parking changes the winner.  (Against the plain loop
@@ -295,27 +326,25 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
         // The first candidate of a cell parks hit_sphere's tca and radius2 - d2 and its square-root half runs once, behind the
         // list, with the other lanes' (+1.4 %); further candidates of the same cell are resolved at once.
         float c_tca = 0.0f, c_rd = 0.0f;
-        uint32_t c_k = 0u;
-        bool parked = false;
+        uint32_t c_k = 0xFFFFFFFFu;                                 // 0xFFFFFFFF: nothing parked
+#define RPT_PARKED() (c_k != 0xFFFFFFFFu)
+        // hit_sphere's second half (analytical.rs:176-189) for a candidate, in selects.  Its swap of the roots is not here: thc is a
+        // square root, so t0 = tca - thc <= tca + thc = t1 unless both are NaN, and then nothing below accepts them either.  The
+        // sphere's index is loaded only for a root that can still win (t <= dist).
         auto resolve = [&](float tca, float rd, uint32_t kk) {
             const float thc = fsqrt(rd);
-            float t0 = tca - thc;
-            float t1 = tca + thc;
-            if (t0 > t1) { const float tmp = t0; t0 = t1; t1 = tmp; }
-            bool ok = true;
-            if (t0 < 0.0f) { t0 = t1; if (t0 < 0.0f) ok = false; }
-            if (ok) {
+            const float t0 = tca - thc;
+            const float t1 = tca + thc;
+            const float t = t0 < 0.0f ? t1 : t0;
+            if (!(t < 0.0f) && t <= dist) {
                 const uint32_t i = sc.cell_items[kk];
-                if (i != 0u && (t0 < dist || (t0 == dist && i < best))) { dist = t0; best = i; hit = true; }
+                if (i != 0u && (t < dist || i < best)) { dist = t; best = i; RPT_HIT_SET(); }
             }
         };
         for (uint32_t k = k0; k < k1; k += RPT_GRID_BATCH) {
             float4 sp[RPT_GRID_BATCH];
 #pragma unroll
-            for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) {
-                sp[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (k + j < k1) sp[j] = sc.cell_spheres[k + j];
-            }
+            for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) sp[j] = sc.cell_spheres[k + j];     // (the array ends in RPT_GRID_BATCH - 1 spare entries: host_grid.h)
 #pragma unroll
             for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) {
                 const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
@@ -323,16 +352,20 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
                 const float d2 = dot3(l, l) - tca * tca;
                 const float radius2 = sp[j].w * sp[j].w;
                 if ((k + j < k1) && !(d2 > radius2)) {
-                    if (!parked) { c_tca = tca; c_rd = radius2 - d2; c_k = k + j; parked = true; }
+                    if (!RPT_PARKED()) { c_tca = tca; c_rd = radius2 - d2; c_k = k + j; }
                     else resolve(tca, radius2 - d2, k + j);
                 }
             }
         }
-        if (parked) resolve(c_tca, c_rd, c_k);
-        if (hit && dist <= t_exit) break;                           // nothing beyond this cell can be nearer
-        if (t_exit > g.t_end) break;
+        if (RPT_PARKED()) resolve(c_tca, c_rd, c_k);
+        if (RPT_HIT() && dist <= t_exit) break;                     // nothing beyond this cell can be nearer
+        if (last) break;
         k0 = n0; k1 = n1;
     }
+    hit = hit_w != 0u;
+#undef RPT_HIT_SET
+#undef RPT_HIT
+#undef RPT_PARKED
 }
 
 RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max, float max_dist)
@@ -346,47 +379,55 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
     GridWalk g;
     { RPT_PROF(PB_GRID_BEGIN); g = grid_begin(sc, ray); }
     uint32_t k0 = 0, k1 = 0;
+    uint32_t occluded = 0u;                                         // (a word, not a bool: see grid_closest_sphere)
     if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
-    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; g.alive && guard != 0u; --guard) {
+    if (g.alive)
+    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; guard != 0u; --guard) {
         RPT_PROF(PB_GRID_CELL);
         const float t_exit = grid_cell_exit(g);
-        grid_step(sc, g);                                           // as in grid_closest_sphere
-        uint32_t n0 = 0, n1 = 0;
-        if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), n0, n1);
+        const bool last = t_exit > g.t_end;
+        grid_advance(g);                                            // as in grid_closest_sphere
+        uint32_t n0, n1;
+        cell_bounds(sc, grid_cell_index_clamped(sc, g), n0, n1);
         // (as in grid_closest_sphere; parking the candidate as well, or 3 per trip, is slower here: -2 %, -4 %)
-        for (uint32_t k = k0; k < k1; k += RPT_GRID_BATCH_ANY) {
+        for (uint32_t k = k0; k < k1 && occluded == 0u; k += RPT_GRID_BATCH_ANY) {
             float4 sp[RPT_GRID_BATCH_ANY];
+            float c_tca[RPT_GRID_BATCH_ANY], c_rd[RPT_GRID_BATCH_ANY];
             bool cand[RPT_GRID_BATCH_ANY];
             bool any_cand = false;
 #pragma unroll
-            for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) {
-                sp[j] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (k + j < k1) sp[j] = sc.cell_spheres[k + j];
-            }
+            for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) sp[j] = sc.cell_spheres[k + j];
 #pragma unroll
             for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) {
                 const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
                 const float tca = dot3(l, ray.d);
                 const float d2 = dot3(l, l) - tca * tca;
-                cand[j] = (k + j < k1) && !(d2 > sp[j].w * sp[j].w);
+                const float radius2 = sp[j].w * sp[j].w;
+                cand[j] = (k + j < k1) && !(d2 > radius2);
                 any_cand = any_cand || cand[j];
+                c_tca[j] = tca;
+                c_rd[j] = radius2 - d2;
             }
             if (any_cand) {
 #pragma unroll
                 for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) {
-                    float t;
-                    if (cand[j] && hit_sphere(ray, mk3(sp[j].x, sp[j].y, sp[j].z), sp[j].w, t) && (!use_max || t < max_dist)) return true;
+                    if (cand[j]) {                                  // hit_sphere's second half, as in grid_closest_sphere's resolve
+                        const float thc = fsqrt(c_rd[j]);
+                        const float t0 = c_tca[j] - thc, t1 = c_tca[j] + thc;
+                        const float t = t0 < 0.0f ? t1 : t0;
+                        if (!(t < 0.0f) && (!use_max || t < max_dist)) occluded = 1u;
+                    }
                 }
             }
         }
-        if (t_exit > g.t_end) break;
+        if (occluded != 0u || last) break;
         if (use_max && t_exit > max_dist) {
             // a sphere entirely beyond max_dist cannot occlude; one straddling this cell was tested
             break;
         }
         k0 = n0; k1 = n1;
     }
-    return false;
+    return occluded != 0u;
 }
 
 // GeomHit.code of a large scene: the nearest sphere's index in the low 28 bits (kNoSphere: none), the mask of

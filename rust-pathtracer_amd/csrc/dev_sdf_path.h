@@ -45,6 +45,17 @@ RPT_DEV bool march_step(const DevSdf& sd, v3 origin, MarchRegs& m)
     return (m.t > sd.max_t) || (m.t > m.t_useful);
 }
 
+// march_step with the primitive records in LDS (sdf_eval_lds)
+RPT_DEV bool march_step_lds(const DevSdf& sd, const float4* prims, v3 origin, MarchRegs& m)
+{
+    if (m.steps >= sd.max_steps) return true;
+    float dist = sdf_eval_lds(sd, prims, origin + m.t * m.d);
+    if (dist < sd.hit_eps * m.t) { m.hit = true; return true; }
+    m.t = m.t + dist;
+    m.steps += 1;
+    return (m.t > sd.max_t) || (m.t > m.t_useful);
+}
+
 // Scene queries answered from a finished march.
 struct SdfInjectedQuery {
     SdfMarchResult r;

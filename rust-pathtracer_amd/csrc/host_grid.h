@@ -178,6 +178,8 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
 
 // The acceleration structure of a large scene, serialised: built once on the host, copied into the device table allocation
 // after the plain tables (host_scene.h binds the pointers into each device's SceneLarge).
+constexpr size_t kSpareListEntries = 8;
+
 struct HostAccelData {
     HostGrid grid;
     std::vector<float> cell_spheres;          // {cx, cy, cz, r} of items[k] at k: a cell's spheres are one load away from its bounds
@@ -199,7 +201,9 @@ inline bool build_accel(const rpt_sphere* sph, uint32_t count, HostAccelData& a,
 {
     const char* e = getenv("RPT_GRID_SPHERES_PER_CELL");
     if (!build_grid(sph, count, e ? atof(e) : 1.0, a.grid, why)) return false;
-    a.cell_spheres.resize(a.grid.items.size() * 4);
+    // (kSpare more entries than the lists hold: the walks read a list RPT_GRID_BATCH entries per trip without asking whether the
+    // last trip's entries are all there — the answer is in the candidate test anyway — so the array must be readable a little past its end)
+    a.cell_spheres.assign((a.grid.items.size() + kSpareListEntries) * 4, 0.0f);
     for (size_t k = 0; k < a.grid.items.size(); ++k) {
         const rpt_sphere& s = sph[a.grid.items[k]];
         a.cell_spheres[4 * k + 0] = s.center[0]; a.cell_spheres[4 * k + 1] = s.center[1];

@@ -37,7 +37,8 @@ static void check_accel(const std::vector<rpt_sphere>& sph, const rpthost::HostA
     const size_t ncell = (size_t)g.n[0] * g.n[1] * g.n[2];
     const int tiers = g.near_r2 >= 0.0f ? 2 : 1;
     CHECK(g.cell_start.size() == (ncell + 1) * (size_t)tiers, "%s: cell_start has %zu entries for %zu cells x %d tiers", what, g.cell_start.size(), ncell, tiers);
-    CHECK(a.cell_spheres.size() == g.items.size() * 4, "%s: cell_spheres / items size", what);
+    CHECK(a.cell_spheres.size() == (g.items.size() + rpthost::kSpareListEntries) * 4, "%s: cell_spheres / items size", what);
+    CHECK(a.sz_cell_sph == a.cell_spheres.size() * sizeof(float), "%s: the spare list entries are part of the device table", what);
     std::vector<char> oversize(sph.size(), 0);
     for (uint32_t i : g.oversize) { CHECK(i < sph.size(), "%s: oversize index", what); oversize[i] = 1; }
     for (int t = 0; t < tiers; ++t) {

@@ -59,6 +59,8 @@ VARIANTS = {
     "sdf_w6": ["-DRPT_SDF_WAVES_PER_SIMD=6"],
     "pair_w4": ["-DRPT_LARGE_PAIR_WAVES_PER_SIMD=4"],
     "pair_w6": ["-DRPT_LARGE_PAIR_WAVES_PER_SIMD=6"],
+    # round 4
+    "sdf_prims_lds": ["-DRPT_SDF_PRIMS_IN_LDS"],               # the SDF primitive records staged in LDS instead of read through the scalar cache
 }
 
 if __name__ == "__main__":
