@@ -988,7 +988,21 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
             std::string why;
             if (!build_accel(s->spheres, s->n_spheres, accel, why)) { set_err(ctx, "rpt_upload_scene: %s", why.c_str()); return RPT_ERR_UNSUPPORTED; }
         }
-        const size_t sz_tables = sz_sph + sz_smat + sz_lights + sz_mats;
+        // The spherical lights once more as {centre, radius} records with their indices, padded to whole groups of four: what
+        // Scene::sample_lights' loop streams (dev_scene_large.h, closest_geom_finish).  Only when every light that DOES something
+        // in sample_lights is spherical: always, unless the scene samples the other light types and has a rectangular one.
+        bool lights_fast = true;
+        std::vector<float> lsph;
+        std::vector<uint32_t> lids;
+        for (uint32_t i = 0; i < s->n_lights; ++i) {
+            const rpt_light& l = s->lights[i];
+            if (l.type == RPT_LIGHT_SPHERICAL) { lsph.insert(lsph.end(), {l.position[0], l.position[1], l.position[2], l.radius}); lids.push_back(i); }
+            else if (l.type == RPT_LIGHT_RECTANGULAR && (s->flags & RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES)) lights_fast = false;
+        }
+        const uint32_t n_light_spheres = (uint32_t)lids.size();
+        while (lids.size() % 4u) { lsph.insert(lsph.end(), {0.0f, 0.0f, 0.0f, 0.0f}); lids.push_back(0u); }
+        const size_t sz_lsph = sizeof(float) * lsph.size(), sz_lids = (sizeof(uint32_t) * lids.size() + 15) & ~(size_t)15;
+        const size_t sz_tables = sz_sph + sz_smat + sz_lights + sz_mats + sz_lsph + sz_lids;
         const size_t sz_accel = accel.bytes();
         std::vector<unsigned char> host(sz_tables + sz_accel, 0);
         float4* h_sph = reinterpret_cast<float4*>(host.data());
@@ -1001,6 +1015,9 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         }
         for (uint32_t i = 0; i < s->n_lights; ++i) h_lights[i] = dev_light(s->lights[i]);
         for (uint32_t i = 0; i < s->n_materials; ++i) h_mats[i] = dev_material(s->materials[i]);
+        const size_t off_lsph = sz_sph + sz_smat + sz_lights + sz_mats;
+        if (!lsph.empty()) memcpy(host.data() + off_lsph, lsph.data(), sz_lsph);
+        if (!lids.empty()) memcpy(host.data() + off_lsph + sz_lsph, lids.data(), sizeof(uint32_t) * lids.size());
         if (use_accel) accel.write(host.data() + sz_tables);
         for (DevState& d : ctx->devs) {
             DeviceGuard guard(d.device);
@@ -1019,6 +1036,9 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
             L.sphere_material = reinterpret_cast<const uint32_t*>(base + sz_sph);
             L.lights = reinterpret_cast<const DevLight*>(base + sz_sph + sz_smat);
             L.materials = reinterpret_cast<const DevMaterial*>(base + sz_sph + sz_smat + sz_lights);
+            L.light_spheres = reinterpret_cast<const float4*>(base + off_lsph);
+            L.light_sphere_ids = reinterpret_cast<const uint32_t*>(base + off_lsph + sz_lsph);
+            L.n_light_spheres = lights_fast ? n_light_spheres : 0xFFFFFFFFu;
             for (uint32_t i = 0; i < s->n_planes; ++i) L.planes[i] = dev_plane(s->planes[i]);
             L.use_accel = use_accel ? 1u : 0u;
             if (use_accel) accel.bind(L, base + sz_tables);

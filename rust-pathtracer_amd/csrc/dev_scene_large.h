@@ -50,6 +50,12 @@ struct SceneLarge {
     const float4* cell_spheres;       // spheres[cell_items[k]] stored at k: a cell's spheres are one dependent load away, not two
     uint32_t n_oversize;              // spheres kept out of the grid (far larger than the rest: host_scene.h), tested by every walk
     const uint32_t* oversize;
+    // Scene::sample_lights' loop (closest_geom_finish): the spherical lights as {centre, radius} in index order, in whole groups of
+    // four, with their indices into `lights`; n_light_spheres == 0xFFFFFFFF: the scene has a light of another kind that acts (a
+    // rectangular one under RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES): the loop over `lights` itself runs
+    const float4* light_spheres;
+    const uint32_t* light_sphere_ids;
+    uint32_t n_light_spheres;
 };
 
 // Wave-uniform table reads: plain dwords through the constant address space, which the
@@ -455,11 +461,59 @@ RPT_DEV bool closest_geom_finish(const SceneLarge& sc, const RayD& ray, PathStat
 
     // Scene::sample_lights, scene.rs:65-85
     float ldist = ps.hit_dist;
-    for (uint32_t i = 0; i < sc.n_lights; ++i) {
-        const DevLight L = light_uniform(sc, i);
-        hit = light_intersect(L, sc.flags, ray, ps, e, ldist) || hit;
+    if (sc.n_light_spheres == 0xFFFFFFFFu) {
+        for (uint32_t i = 0; i < sc.n_lights; ++i) {
+            const DevLight L = light_uniform(sc, i);
+            hit = light_intersect(L, sc.flags, ray, ps, e, ldist) || hit;
+        }
+        return hit;
     }
-    return hit;
+    // The same loop for spherical lights (the other kinds do nothing in it), four lights per trip: one scalar load brings four
+    // {centre, radius} records, the first half of the sphere test (scene.rs:39-50) runs for all four without a branch, and only a
+    // light the ray's line actually meets — rare — takes the second half and, if it is the nearest so far, fetches the light
+    // itself.  Per light the operations and their order are light_intersect's.  (Until round 4 every closest_hit loaded 16 light
+    // records of 15 dwords one after the other and waited for each: a fifth of the 10 k-sphere frame's time.)
+    uint32_t hit_w = hit ? 1u : 0u;
+    for (uint32_t i = 0; i < sc.n_light_spheres; i += 4u) {
+        cfloat_p rec = (cfloat_p)sc.light_spheres + 4u * i;
+        float c_tca[4], c_rd[4];
+        bool cand[4];
+        bool any_cand = false;
+#pragma unroll
+        for (uint32_t j = 0; j < 4u; ++j) {
+            const v3 l = mk3(rec[4u * j], rec[4u * j + 1u], rec[4u * j + 2u]) - ray.o;
+            const float tca = dot3(l, ray.d);
+            const float d2 = dot3(l, l) - tca * tca;
+            const float radius2 = rec[4u * j + 3u] * rec[4u * j + 3u];
+            cand[j] = (i + j < sc.n_light_spheres) && !(d2 > radius2);
+            any_cand = any_cand || cand[j];
+            c_tca[j] = tca;
+            c_rd[j] = radius2 - d2;
+        }
+        if (any_cand) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; ++j) {
+                if (cand[j]) {
+                    const float thc = fsqrt(c_rd[j]);
+                    const float t0 = c_tca[j] - thc, t1 = c_tca[j] + thc;       // (t0 <= t1: thc is a square root)
+                    const float t = t0 < 0.0f ? t1 : t0;
+                    if (!(t < 0.0f) && t < ldist) {                 // light_intersect from here on
+                        const DevLight L = light_uniform(sc, ((cuint_p)sc.light_sphere_ids)[i + j]);
+                        const v3 pos = mk3(L.px, L.py, L.pz);
+                        ldist = t;
+                        const v3 hit_point = ray.o + t * ray.d;
+                        const float cos_theta = dot3(-ray.d, norm3(hit_point - pos));
+                        e.light_pdf = fdiv(ldist * ldist, L.area * cos_theta * 0.5f);
+                        e.light_emission = mk3(L.ex, L.ey, L.ez);
+                        e.is_emitter = true;
+                        ps.hit_dist = t;
+                        hit_w = 1u;
+                    }
+                }
+            }
+        }
+    }
+    return hit_w != 0u;
 }
 
 RPT_DEV bool closest_geom(const SceneLarge& sc, const RayD& ray, PathState& ps, GeomHit& g, EmitterHit& e)
