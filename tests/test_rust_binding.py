@@ -13,7 +13,7 @@ HEADER = os.path.join(ROOT, "include", "rpt.h")
 
 RENAMES = {("RptLight", "light_type"): "type"}             # `type` is a Rust keyword
 PRIMS = {"u8": (1, 1), "u32": (4, 4), "i32": (4, 4), "c_int": (4, 4), "u64": (8, 8), "f32": (4, 4), "c_char": (1, 1)}
-C_PRIMS = {"uint8_t": "u8", "uint32_t": "u32", "int": "c_int", "uint64_t": "u64", "float": "f32", "char": "c_char", "void": "c_void"}
+C_PRIMS = {"uint8_t": "u8", "uint32_t": "u32", "int": "c_int", "uint64_t": "u64", "float": "f32", "char": "c_char", "void": "c_void", "size_t": "usize"}
 
 
 def camel(c_name):
@@ -213,9 +213,11 @@ def check_binding(rust_src, tmp_path):
             if ra != ca:
                 problems.append("%s: argument %d is %s != rpt.h %s" % (fname, i, ra, ca))
     for must in ("rpt_create", "rpt_create_multi", "rpt_destroy", "rpt_upload_scene", "rpt_render", "rpt_last_error", "rpt_sizeof_scene_desc",
-                 "rpt_resident_render", "rpt_resident_download_u8"):
+                 "rpt_resident_render", "rpt_resident_download_u8", "rpt_convert_to_u8", "rpt_denoise", "rpt_set_dispatch", "rpt_host_pin"):
         if must not in r_fns:
             problems.append("%s: not bound" % must)
+    if not re.search(r"unsafe\s+impl\s+Send\s+for\s+GpuTracer", strip_comments(rust_src, rust=True)):
+        problems.append("GpuTracer is not Send (the reference's Tracer is: scene.rs:5)")
     # every struct reachable from the scene descriptor must be mirrored
     for cname in ("rpt_scene_desc", "rpt_material", "rpt_sphere", "rpt_plane", "rpt_light", "rpt_camera", "rpt_background", "rpt_sdf", "rpt_sdf_prim"):
         if camel(cname) not in r_structs:
