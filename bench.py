@@ -34,7 +34,14 @@ FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 GPU_CLOCK_HZ = 2.4e9           # the same table's engine clock (the PMC passes measured 2.37e9 under this kernel)
 C2 = (1920, 1080, 256)         # BASELINE.json configs[1]
 C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
-TRAFFIC_JSON = os.path.join("profiles", "r3", "c2_bench_final", "traffic.json")
+PROFILES = os.path.join("profiles", "r4")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
+TRAFFIC_JSON = os.path.join(PROFILES, "c2_bench", "traffic.json")
+# What a correctly rounded f32 divide / square root costs the VALU in this library (csrc/dev_math.h): a quotient is v_rcp + 2 fma
+# shared by the numerators of one denominator, then mul + 2 fma + v_div_fixup each, plus the range guard's v_frexp_exp / min /
+# max / compare — 7.7 instructions per quotient in normalize's three-quotient form, 13 for a lone one: 9 is used; a root is
+# v_sqrt + v_rsq + mul + 2 fma + 3 of guard.  (Rounds 1-3 priced them at hipcc's expansions, 12 and 15, which the library no
+# longer executes.)
+DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS = 9, 8
 
 
 def weak_frame(n_gpus):
@@ -80,9 +87,9 @@ def roofline_block(ops, launch_samples, kernel_s, kernel, launches, pixels):
     """FP32-VALU roofline of one config (no dense contraction, HBM is not the limiter): algorithmic flops per
     step = flops per sample (oracle op counts) x samples per step, over the measured duration of the step's launches."""
     tfl = ops["flops_per_sample"] * launch_samples / kernel_s / 1e12
-    # the same work with every correctly rounded divide / sqrt counted at the 12 / 15 VALU instructions
-    # (~2 flops each where they are fmas) gfx950 needs for it: what the VALU actually has to issue
-    expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (2 * 12 - 1) + ops["sqrts_per_sample"] * (2 * 15 - 1)
+    # the same work with every correctly rounded divide / sqrt counted at the VALU instructions this library issues for it
+    # (one operation per instruction, an fma as one): what the VALU actually has to issue for the algorithmic flops
+    expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (DIV_INSTRUCTIONS - 1) + ops["sqrts_per_sample"] * (SQRT_INSTRUCTIONS - 1)
     hbm = 32.0 * pixels / kernel_s / 1e9
     return {"bound": "fp32_valu", "achieved": round(tfl, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tfl / FP32_PEAK_TFLOPS, 5), "traffic": None,
@@ -90,7 +97,17 @@ def roofline_block(ops, launch_samples, kernel_s, kernel, launches, pixels):
             "algorithmic_flops_per_step": ops["flops_per_sample"] * launch_samples, **ops,
             "ieee_expanded_flops_per_sample": round(expanded, 1),
             "ieee_expanded_frac": round(expanded * launch_samples / kernel_s / 1e12 / FP32_PEAK_TFLOPS, 5),
+            "ieee_expanded_note": "flops with a divide counted as %d and a square root as %d operations: the instructions of csrc/dev_math.h's correctly rounded sequences" % (DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS),
             "hbm_algorithmic_GBs": round(hbm, 3), "hbm_frac": round(hbm / HBM_PEAK_GBS, 6)}
+
+
+def committed_traffic(name):
+    """HBM bytes per launch from the committed PMC passes of a profile directory (profiles/r4/<name>/traffic.json), or None."""
+    path = os.path.join(ROOT, PROFILES, name, "traffic.json")
+    if not os.path.exists(path):
+        return None, None
+    t = json.load(open(path))
+    return t["hbm_bytes_per_launch"], "%s: rocprofv3 PMC passes, committed (%s)" % (os.path.join(PROFILES, name, "traffic.json"), t["correction"])
 
 
 def other_configs(rpt, torch, device, small):
@@ -167,6 +184,8 @@ def other_configs(rpt, torch, device, small):
     blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march2_kernel", 1, w * h)
     blk.update({"workload": "SDF sphere-march scene %dx%d x %d spp per step (BASELINE.json configs[3])" % (w, h, spp),
                 "value": round(w * h * spp / t / 1e6, 2), "value_unit": "Msamples/s"})
+    if not small:
+        blk["traffic"], blk["traffic_source"] = committed_traffic("c4")
     out["roofline_c4"] = blk
     big = scenes.random_spheres_scene(10000, 16)
     ops = op_counts(big.describe(), (128, 128, 1), skip_missed_sphere_tests=True)
@@ -182,6 +201,9 @@ def other_configs(rpt, torch, device, small):
     blk["progressive_8spp"] = {"kernel": "render_large_regen_kernel",
                                "kernel_ms": round(t8 * 1e3, 3), "value": round(w * h * 8 / t8 / 1e6, 2),
                                "frac": round(ops["flops_per_sample"] * w * h * 8 / t8 / 1e12 / FP32_PEAK_TFLOPS, 5)}
+    if not small:
+        # (the committed counters are of the same kernel on the 2048 x 2048 x 32-spp frame: 2 x 16 B per pixel + the spills)
+        blk["progressive_8spp"]["traffic_2048x2048x32"], blk["traffic_source"] = committed_traffic("c5")
     out["roofline_c5"] = blk
     # the denoiser (include/rpt.h, project-defined): an HBM pass, 32 B per pixel per iteration
     for name, (dw, dh) in (("roofline_denoise_1080p", (1920 // div, 1080 // div)), ("roofline_denoise_4k", (3840 // div, 2160 // div))):
@@ -201,8 +223,10 @@ def other_configs(rpt, torch, device, small):
         del res
         t = min(ms) / 1e3
         gbs = iters * 32.0 * dw * dh / t / 1e9
+        tr, tr_src = committed_traffic("denoise_1080p" if name.endswith("1080p") else "denoise_4k") if not small else (None, None)
         out[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                     "traffic": None, "kernel": "denoise_tile_kernel<1>, <2>, <4>", "kernel_ms": round(t * 1e3, 4),
+                     "traffic": tr, **({"traffic_source": tr_src} if tr_src else {}),
+                     "kernel": "denoise_tile_kernel<1>, <2>, <4>", "kernel_ms": round(t * 1e3, 4),
                      "algorithmic_bytes_per_step": iters * 32.0 * dw * dh,
                      "workload": "a-trous denoiser, %d iterations on a %dx%d RGBA f32 buffer (16 B read + 16 B written per pixel per iteration)" % (iters, dw, dh)}
         del buf
@@ -467,6 +491,38 @@ def main():
             extra["strong_scaling"] = {"t1_ms": round(ts * 1e3, 3), "tN_ms": round(elapsed / args.steps * 1e3, 3),
                                        "speedup": round(ts / (elapsed / args.steps), 3), "n_gpus": world,
                                        "note": "same configs[2] frame rendered by rank 0 alone after the timed region (1 step)"}
+        # secondary: BASELINE.json configs[4] as written — 10 k spheres + 16 lights, 4096 x 4096 x 512 spp, row-tiled over the N GPUs
+        # (cyclic 2-row blocks), gathered to rank 0: one step, host clock, max over ranks.  The same contexts and communicator: the
+        # scene is swapped (Tracer.scene() + upload_scene()).
+        if not isinstance(job, TorchGatherRender):
+            from rust_pathtracer_amd import scenes
+            big = scenes.random_spheres_scene(10000, 16)
+            if tracer:
+                tracer._scene = big
+                tracer.upload_scene()
+            bw, bh, bspp = shrink((4096, 4096, 512))
+            bjob = job_of(bw, bh)
+            if bjob:
+                bjob.render_n(max(1, bspp // 32))      # warm: device tables, the dispatch order, the communicator's buffers for this size
+                bjob.gather()
+            host_fence()
+            tb = time.perf_counter()
+            if bjob:
+                bjob.render_n(bspp)
+                bjob.gather_begin()
+                bjob.gather_end()
+            host_fence()
+            tb = time.perf_counter() - tb
+            t = torch.tensor([tb], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            extra["configs4"] = {"workload": "10k spheres + 16 lights %dx%d x %d spp in one step, cyclic 2-row tiles over %d GPUs, gather to rank 0 inside the "
+                                             "timed region (BASELINE.json configs[4])" % (bw, bh, bspp, world),
+                                 "steps": 1, "ms_per_step": round(float(t.item()) * 1e3, 3),
+                                 "value": round(bw * bh * bspp / float(t.item()) / 1e6, 2), "unit": "Msamples/s",
+                                 "note": "render_large_regen_kernel; the one-GPU figure of the same frame is roofline_c5.value of the N = 1 line"}
+            if tracer:
+                tracer._scene = scene
+                tracer.upload_scene()
         dist.barrier()
 
     if rank == 0:
@@ -478,11 +534,11 @@ def main():
         launch_samples = local_pixels * spp
         algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
         hbm = algo_bytes / avg_kernel_s / 1e9
-        launches = -(-spp // 512)                 # the kernel's LDS tables hold 512 samples: longer batches are split
+        launches = 1                              # one launch whatever spp is (kernels.hip: a launch is tiles x chunks of samples)
         kernel = "render_small_regen_kernel" if spp > 1 else "render_small_compact_kernel"     # (capi.hip: RPT_COMPACT_MAX_SPP)
         roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels)
         roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
-                            "rounded f32 divide or sqrt costs 12-15 VALU instructions on gfx950; kernel_ms = HIP events on the launch stream")
+                            "rounded f32 divide or sqrt costs 8-13 VALU instructions in this library (ieee_expanded_*); kernel_ms = HIP events on the launch stream")
         tj = os.path.join(ROOT, TRAFFIC_JSON)
         if world == 1 and not args.small and os.path.exists(tj):
             t = json.load(open(tj))

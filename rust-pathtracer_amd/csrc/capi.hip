@@ -38,6 +38,12 @@ struct DevState {
     float* fb = nullptr;              // staging for the host-pointer API (this device's rows, or a whole image)
     size_t fb_bytes = 0;
     float* tile = nullptr;            // resident ColorBuffer rows of this rank: rows_padded x width RGBA f32
+    // The gather runs beside the next render (gather_to_root): it sends a SNAPSHOT of the tile on a stream of its own.
+    float* snap = nullptr;            // the tile as it was when the gather was asked for
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t snap_ready = nullptr;  // on `stream`: the snapshot is taken
+    hipEvent_t snap_free = nullptr;   // on `comm_stream`: the snapshot has been sent (the next one may overwrite it)
+    bool snap_used = false;
     SceneSmallSdf* scene_small_dev = nullptr;   // the small scene in device memory, for the one kernel that reads it from there (SDF compact, A/B)
     void* wf = nullptr;               // wavefront state of large scenes (dev_wavefront.h), grown on demand
     size_t wf_bytes = 0;
@@ -82,7 +88,8 @@ struct rpt_ctx {
     uint8_t* frame_u8 = nullptr;
     void* stage = nullptr;            // page-locked host staging for downloads into pageable buffers (download_to_host)
     size_t stage_bytes = 0;
-    hipEvent_t gather_consumed = nullptr;   // peer gather: recorded behind the scatter kernel that reads `gathered`
+    hipEvent_t gather_done = nullptr;       // on the root's comm_stream: the assembled image of the last gather is complete
+    bool gather_issued = false;
     bool timed = false;               // ev_begin / ev_end bracket a render
     std::string err;
 
@@ -335,6 +342,10 @@ static void free_dev(DevState& d)
     if (d.ev_begin) (void)hipEventDestroy(d.ev_begin);
     if (d.ev_end) (void)hipEventDestroy(d.ev_end);
     if (d.ev_ready) (void)hipEventDestroy(d.ev_ready);
+    if (d.snap) (void)hipFree(d.snap);
+    if (d.snap_ready) (void)hipEventDestroy(d.snap_ready);
+    if (d.snap_free) (void)hipEventDestroy(d.snap_free);
+    if (d.comm_stream) (void)hipStreamDestroy(d.comm_stream);
     if (d.wf_done) (void)hipEventDestroy(d.wf_done);
     if (d.sc_done) (void)hipEventDestroy(d.sc_done);
     if (d.dn_done) (void)hipEventDestroy(d.dn_done);
@@ -364,6 +375,9 @@ static int open_dev(DevState& d, int device_id, int rank, const char* who)
     if (guard.status != hipSuccess || hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&d.ev_begin) != hipSuccess || hipEventCreate(&d.ev_end) != hipSuccess ||
         hipEventCreateWithFlags(&d.ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&d.snap_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&d.snap_free, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.wf_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.sc_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.dn_done, hipEventDisableTiming) != hipSuccess ||
@@ -380,13 +394,16 @@ static void free_resident(rpt_ctx* ctx)
     for (DevState& d : ctx->devs) {
         DeviceGuard guard(d.device);
         if (d.tile) { (void)hipFree(d.tile); d.tile = nullptr; }
+        if (d.snap) { (void)hipFree(d.snap); d.snap = nullptr; }
+        d.snap_used = false;
     }
     DeviceGuard guard(ctx->devs[0].device);
     if (ctx->gathered) { (void)hipFree(ctx->gathered); ctx->gathered = nullptr; }
     if (ctx->image) { (void)hipFree(ctx->image); ctx->image = nullptr; }
     if (ctx->frame_u8) { (void)hipFree(ctx->frame_u8); ctx->frame_u8 = nullptr; }
     if (ctx->stage) { (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_bytes = 0; }
-    if (ctx->gather_consumed) { (void)hipEventDestroy(ctx->gather_consumed); ctx->gather_consumed = nullptr; }
+    if (ctx->gather_done) { (void)hipEventDestroy(ctx->gather_done); ctx->gather_done = nullptr; }
+    ctx->gather_issued = false;
     ctx->has_res = false;
     ctx->res_w = ctx->res_h = ctx->res_tile_rows = ctx->res_rows_padded = 0;
     ctx->res_frames = 0;
@@ -898,7 +915,7 @@ int rpt_set_dispatch(rpt_ctx* ctx, uint32_t cost_order, uint32_t unit_rounds, ui
 void rpt_destroy(rpt_ctx* ctx)
 {
     if (!ctx) return;
-    for (DevState& d : ctx->devs) { DeviceGuard guard(d.device); (void)hipStreamSynchronize(d.stream); }
+    for (DevState& d : ctx->devs) { DeviceGuard guard(d.device); (void)hipStreamSynchronize(d.stream); (void)hipStreamSynchronize(d.comm_stream); }
     free_resident(ctx);
     RcclApi* api = ctx->use_comm ? rccl_api() : nullptr;
     for (DevState& d : ctx->devs) {
@@ -1226,7 +1243,12 @@ int rpt_debug_render_overlap_ms(rpt_ctx* ctx, int a, int b, float* ms)
 int rpt_resident_reset(rpt_ctx* ctx)
 {
     if (!ctx) { set_err(nullptr, "rpt_resident_reset: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
-    for (DevState& d : ctx->devs) { DeviceGuard guard(d.device); RPT_HIP_CHECK(ctx, guard.status); RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream)); }
+    for (DevState& d : ctx->devs) {
+        DeviceGuard guard(d.device);
+        RPT_HIP_CHECK(ctx, guard.status);
+        RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
+        RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.comm_stream));
+    }
     free_resident(ctx);
     return RPT_OK;
 }
@@ -1314,7 +1336,12 @@ int rpt_resident_upload(rpt_ctx* ctx, const float* pixels, uint32_t width, uint3
     return RPT_OK;
 }
 
-// Tiles -> rank-major `gathered` on the root -> top-down image on the root, all enqueued (no host wait).
+// Tiles -> rank-major `gathered` on the root -> top-down image on the root, all enqueued (no host wait), and BESIDE the renders
+// that follow: every rank copies its tile into a snapshot on its render stream (a device copy: 16.6 MB for configs[2]'s share,
+// ~10 us) and everything else — the RCCL send / receive or the peer copy, the scatter kernel on the root — runs on the rank's
+// second stream, `comm_stream`, behind an event.  The next render waits for nothing but that copy; gather k overlaps render k + 1
+// and ranks no longer meet at every step (round 4).  The image is complete when the root's comm_stream has drained:
+// rpt_resident_sync waits for both streams, the download paths wait for `gather_done` on the device.
 // Returns the device pointer of the assembled image in *image_out (root only).
 static int gather_to_root(rpt_ctx* ctx, float* image_dst, float** image_out)
 {
@@ -1331,39 +1358,55 @@ static int gather_to_root(rpt_ctx* ctx, float* image_dst, float** image_out)
     if (ctx->is_root()) {
         if (!ctx->gathered) RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->gathered, count * 4u * world));
         if (!image_dst && !ctx->image) RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->image, (size_t)w * h * 16u));
+        if (!ctx->gather_done) RPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->gather_done, hipEventDisableTiming));
     }
+    // 1. snapshots, on the render streams
+    for (DevState& d : ctx->devs) {
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        if (!d.snap) RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.snap, count * 4u));
+        if (d.snap_used) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(d.stream, d.snap_free, 0));     // the previous gather still sends from it
+        RPT_HIP_CHECK(ctx, hipMemcpyAsync(d.snap, d.tile, count * 4u, hipMemcpyDeviceToDevice, d.stream));
+        RPT_HIP_CHECK(ctx, hipEventRecord(d.snap_ready, d.stream));
+        RPT_HIP_CHECK(ctx, hipStreamWaitEvent(d.comm_stream, d.snap_ready, 0));
+        d.snap_used = true;
+    }
+    // 2. the exchange, on the comm streams
     if (ctx->peer_gather) {
-        // single process: peer copies over xGMI into the root's buffer, each on its source device's stream
+        // single process: peer copies over xGMI into the root's buffer, each on its source device's comm stream (which is ordered
+        // behind the root's previous scatter by `gather_done`: that kernel still reads `gathered`)
         for (DevState& d : ctx->devs) {
             RPT_HIP_CHECK(ctx, guard.to(d.device));
-            if (ctx->gather_consumed) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(d.stream, ctx->gather_consumed, 0));   // the previous scatter still reads `gathered`
-            RPT_HIP_CHECK(ctx, hipMemcpyPeerAsync(ctx->gathered + (size_t)d.rank * count, root.device, d.tile, d.device, count * 4u, d.stream));
-            RPT_HIP_CHECK(ctx, hipEventRecord(d.ev_ready, d.stream));
+            if (ctx->gather_issued) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(d.comm_stream, ctx->gather_done, 0));
+            RPT_HIP_CHECK(ctx, hipMemcpyPeerAsync(ctx->gathered + (size_t)d.rank * count, root.device, d.snap, d.device, count * 4u, d.comm_stream));
+            RPT_HIP_CHECK(ctx, hipEventRecord(d.snap_free, d.comm_stream));
         }
         RPT_HIP_CHECK(ctx, guard.to(root.device));
-        for (DevState& d : ctx->devs) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(root.stream, d.ev_ready, 0));
+        for (DevState& d : ctx->devs) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(root.comm_stream, d.snap_free, 0));
     } else {
-        // RCCL gather over xGMI: every rank sends its tile to rank 0, which posts one receive per rank; one group, so the
-        // 7 incoming transfers use 7 links at once.  Each operation is ordered behind the render on its device's stream.
+        // RCCL over xGMI: every rank sends its snapshot to rank 0, which posts one receive per rank; one group, so the 7 incoming
+        // transfers use 7 links at once.
         RcclApi* api = rccl_api();
         if (!api) { set_err(ctx, "gather: cannot load RCCL: %s", rccl_why()); return RPT_ERR_RCCL; }
         RPT_RCCL_CHECK(ctx, api, api->GroupStart());
         for (DevState& d : ctx->devs) {
             if (d.rank == 0)
                 for (uint32_t r = 0; r < world; ++r)
-                    RPT_RCCL_CHECK(ctx, api, api->Recv(ctx->gathered + (size_t)r * count, count, ncclFloat, (int)r, d.comm, d.stream));
-            RPT_RCCL_CHECK(ctx, api, api->Send(d.tile, count, ncclFloat, 0, d.comm, d.stream));
+                    RPT_RCCL_CHECK(ctx, api, api->Recv(ctx->gathered + (size_t)r * count, count, ncclFloat, (int)r, d.comm, d.comm_stream));
+            RPT_RCCL_CHECK(ctx, api, api->Send(d.snap, count, ncclFloat, 0, d.comm, d.comm_stream));
         }
         RPT_RCCL_CHECK(ctx, api, api->GroupEnd());
+        for (DevState& d : ctx->devs) {
+            RPT_HIP_CHECK(ctx, guard.to(d.device));
+            RPT_HIP_CHECK(ctx, hipEventRecord(d.snap_free, d.comm_stream));
+        }
     }
+    // 3. the scatter into the top-down image, on the root's comm stream
     if (ctx->is_root()) {
         RPT_HIP_CHECK(ctx, guard.to(root.device));
         float* img = image_dst ? image_dst : ctx->image;
-        RPT_HIP_CHECK(ctx, rptlaunch::untile(ctx->gathered, img, w, h, ctx->res_tile_rows, world, ctx->res_rows_padded, root.stream));
-        if (ctx->peer_gather) {
-            if (!ctx->gather_consumed) RPT_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->gather_consumed, hipEventDisableTiming));
-            RPT_HIP_CHECK(ctx, hipEventRecord(ctx->gather_consumed, root.stream));
-        }
+        RPT_HIP_CHECK(ctx, rptlaunch::untile(ctx->gathered, img, w, h, ctx->res_tile_rows, world, ctx->res_rows_padded, root.comm_stream));
+        RPT_HIP_CHECK(ctx, hipEventRecord(ctx->gather_done, root.comm_stream));
+        ctx->gather_issued = true;
         if (image_out) *image_out = img;
     } else if (image_out) *image_out = nullptr;
     return RPT_OK;
@@ -1384,6 +1427,7 @@ int rpt_resident_sync(rpt_ctx* ctx)
     for (DevState& d : ctx->devs) {
         RPT_HIP_CHECK(ctx, guard.to(d.device));
         RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
+        RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.comm_stream));    // (a gather in flight: gather_to_root)
         const int rc = check_handoffs(ctx, d);
         if (rc != RPT_OK) return rc;
     }
@@ -1446,6 +1490,7 @@ int rpt_resident_download(rpt_ctx* ctx, float* pixels)
     if (rc != RPT_OK) return rc;
     DevState& root = ctx->devs[0];
     DeviceGuard guard(root.device);
+    if (ctx->is_root() && !ctx->plain()) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(root.stream, ctx->gather_done, 0));   // the image is assembled on the comm stream
     if (ctx->is_root()) return download_to_host(ctx, pixels, img, (size_t)ctx->res_w * ctx->res_h * 16u);
     return rpt_resident_sync(ctx);
 }
@@ -1461,6 +1506,7 @@ int rpt_resident_download_u8(rpt_ctx* ctx, uint8_t* frame)
     DeviceGuard guard(root.device);
     if (ctx->is_root()) {
         const size_t n = (size_t)ctx->res_w * ctx->res_h;
+        if (!ctx->plain()) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(root.stream, ctx->gather_done, 0));
         if (!ctx->frame_u8) RPT_HIP_CHECK(ctx, hipMalloc((void**)&ctx->frame_u8, n * 4u));
         RPT_HIP_CHECK(ctx, rptlaunch::convert_to_u8(img, ctx->frame_u8, n, root.stream));
         return download_to_host(ctx, frame, ctx->frame_u8, n * 4u);

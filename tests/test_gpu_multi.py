@@ -211,3 +211,52 @@ def test_bench_fallback_gather_gives_the_same_image(rpt, oracle, torch_cuda):
         t.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_a_gather_in_flight_shows_the_frame_it_was_asked_for(rpt, oracle, torch_cuda):
+    """The gather runs beside the renders that follow it (a snapshot of every tile, sent on a second stream): asked for after
+    step 1 and waited for after step 2 has been enqueued, it must deliver step 1's frame; the next one step 2's."""
+    torch = torch_cuda
+    from rust_pathtracer_amd import tiling
+    s = rpt.AnalyticalScene()
+    w, h = 160, 96
+    os.environ["RPT_GATHER"] = "p2p"
+    try:
+        t = rpt.Tracer(s, devices=[0, 0, 0], seed=2)
+    finally:
+        os.environ.pop("RPT_GATHER", None)
+    job = tiling.TiledRender(t, w, h, tile_rows=2)
+    images = []
+    for step in range(3):
+        job.render_n(2)
+        job.gather_begin()
+        job.render_n(1)                                             # enqueued behind the snapshot, beside the exchange
+        images.append(job.gather_end().cpu().numpy().copy())
+    desc = s.describe()
+    for step, img in enumerate(images):
+        assert_bit_identical(img, oracle.render(desc, w, h, 3 * step + 2, seed=2), "gather %d" % step)
+    assert_bit_identical(t.resident_to_host(w, h).image(), oracle.render(desc, w, h, 9, seed=2), "download after the last step")
+    t.close()
+
+
+def test_bench_runs_the_multi_gpu_control_flow_on_one_gpu(rpt, torch_cuda):
+    """bench.py --gpus 2 as the driver launches it, with both ranks on this box's one GPU (--smoke-shared-gpu: virtual ranks, peer
+    copies) and small frames: the JSON line must carry configs[2]'s strong-scaling step, the fixed-work-per-GPU leg, the one-GPU
+    time of the same frame and the configs[4] leg."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--small",
+                        "--smoke-shared-gpu"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["width"] == 3840 // 8 and d["roofline"]["launches_per_step"] == 1
+    for key in ("weak_scaling", "strong_scaling", "configs4"):
+        assert key in d and (d[key].get("value", 1) > 0), key
+    assert "10k spheres" in d["configs4"]["workload"]
