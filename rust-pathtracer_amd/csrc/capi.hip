@@ -1096,7 +1096,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
     d.sdf.inv_smooth_k = s->sdf.n_prims ? 1.0f / s->sdf.smooth_k : 0.0f;
     for (uint32_t i = 0; i < s->sdf.n_prims; ++i) {
         const rpt_sdf_prim& a = s->sdf.prims[i];
-        d.sdf.prims[i] = DevSdfPrim{a.kind, a.center[0], a.center[1], a.center[2], a.params[0], a.params[1]};
+        d.sdf.prims[i] = DevSdfPrim{a.center[0], a.center[1], a.center[2], a.params[0], a.params[1], a.kind, {0u, 0u}};
     }
     ctx->camera = s->camera;
     ctx->large = false;

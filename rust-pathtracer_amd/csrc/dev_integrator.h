@@ -25,6 +25,11 @@ RPT_DEV uint32_t uniform_here(uint32_t x)
 }
 RPT_DEV float uniform_here(float x) { return rpt_u2f(uniform_here(rpt_f2u(x))); }
 
+// (Round 4 tried fetching a whole table record — sphere, plane, light, material patch — in as few wide scalar loads as it has
+// power-of-two pieces, all requested up front, instead of the field-by-field loads the compiler emits, each behind its own wait:
+// geometry and light records +0.3 % / -0.5 % on configs[1] / [3], material patches -2.2 % / -1.4 % (a patch of 29 dwords of which
+// the mask selects three or four; four more spilled SGPRs).  Not taken; the SDF object's primitive records, read every march
+// step and used whole, are the exception: sdf_prim_at.  profiles/r4/experiments/wide_record_loads.txt)
 // analytical.rs:166-190 == scene.rs:39-63
 RPT_DEV bool hit_sphere(const RayD& ray, v3 center, float radius, float& t)
 {
@@ -98,12 +103,30 @@ RPT_DEV float sdf_prim(const DevSdfPrim& pr, v3 p)
     return len3(q) - pr.p0;
 }
 
+// A primitive's record as the two scalar loads it is laid out for (dev_scene.h, DevSdfPrim): {cx, cy, cz, p0} and {p1, kind}, both
+// requested before anything is computed.  (Left to itself the compiler fetches the fields one by one, each right before its use and
+// each behind its own wait: it is saving scalar registers.)
+RPT_DEV float sdf_prim_at(const DevSdf& sd, uint32_t i, v3 p)
+{
+    typedef float rpt_f4 __attribute__((ext_vector_type(4)));
+    typedef float rpt_f2 __attribute__((ext_vector_type(2)));
+    const RPT_CONST_AS char* rec = (const RPT_CONST_AS char*)&sd.prims[i];
+    const rpt_f4 a = *(const RPT_CONST_AS rpt_f4*)rec;
+    const rpt_f2 b = *(const RPT_CONST_AS rpt_f2*)(rec + 16);
+    const v3 q = p - mk3(a.x, a.y, a.z);
+    if (rpt_f2u(b.y) == RPT_SDF_TORUS_Y) {
+        const float qx = fsqrt(q.x * q.x + q.z * q.z) - a.w;
+        return fsqrt(qx * qx + q.y * q.y) - b.x;
+    }
+    return len3(q) - a.w;
+}
+
 RPT_DEV float sdf_eval(const DevSdf& sd, v3 p)
 {
     const float k = sd.smooth_k;
-    float dd = sdf_prim(sd.prims[0], p);
+    float dd = sdf_prim_at(sd, 0u, p);
     for (uint32_t i = 1; i < sd.n_prims; ++i) {
-        float b = sdf_prim(sd.prims[i], p);
+        float b = sdf_prim_at(sd, i, p);
         float h = rmax(k - __builtin_fabsf(dd - b), 0.0f) * sd.inv_smooth_k;
         float m = (dd < b) ? dd : b;
         dd = m - h * h * k * 0.25f;

@@ -12,6 +12,11 @@
 
 #include "../../include/rpt.h"
 
+// the constant address space: a load through such a pointer with a wave-uniform address is a scalar load
+#ifndef RPT_CONST_AS
+#define RPT_CONST_AS __attribute__((address_space(4)))
+#endif
+
 namespace rptdev {
 
 constexpr int kMaxSpheres = 8;
@@ -73,10 +78,14 @@ struct DevBackground {
     float gamma, scale;
 };
 
+// One primitive of the SDF object, in the order a march step needs it: centre and first parameter (all a sphere takes) in one
+// 16-byte scalar load, kind and second parameter in the next.  (With `kind` first the compiler loaded a record in three pieces and
+// waited for each: two exposed scalar-cache round trips per primitive per march step.)
 struct DevSdfPrim {
+    float cx, cy, cz, p0;
+    float p1;
     uint32_t kind;
-    float cx, cy, cz;
-    float p0, p1;
+    uint32_t pad[2];
 };
 
 // The procedural SDF object (include/rpt.h, rpt_sdf): smooth union of up to 8 primitives.

@@ -20,7 +20,6 @@
 
 namespace rptdev {
 
-#define RPT_CONST_AS __attribute__((address_space(4)))
 
 struct SceneLarge {
     static constexpr bool kMedia = false;                          // dev_scene.h, WithMedia
