@@ -307,6 +307,9 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
     // A DDA crosses at most nx+ny+nz cells; the guard guarantees every wave leaves the loop.
     uint32_t k0 = 0, k1 = 0;
     if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
+    float4 pf[RPT_GRID_BATCH];                                      // the first entries of the NEXT cell's list, in flight across the loop's back edge
+#pragma unroll
+    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) pf[j] = sc.cell_spheres[k0 + j];
     if (g.alive)
     for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; guard != 0u; --guard) {
         RPT_PROF(PB_GRID_CELL);
@@ -338,10 +341,7 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
                 if (i != 0u && (t < dist || i < best)) { dist = t; best = i; RPT_HIT_SET(); }
             }
         };
-        for (uint32_t k = k0; k < k1; k += RPT_GRID_BATCH) {
-            float4 sp[RPT_GRID_BATCH];
-#pragma unroll
-            for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) sp[j] = sc.cell_spheres[k + j];     // (the array ends in RPT_GRID_BATCH - 1 spare entries: host_grid.h)
+        auto test_batch = [&](const float4* sp, uint32_t k) {
 #pragma unroll
             for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) {
                 const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
@@ -353,11 +353,20 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
                     else resolve(tca, radius2 - d2, k + j);
                 }
             }
+        };
+        test_batch(pf, k0);                                         // the list's first entries were requested a cell ago (+1.5 %, round 4)
+        for (uint32_t k = k0 + RPT_GRID_BATCH; k < k1; k += RPT_GRID_BATCH) {
+            float4 sp[RPT_GRID_BATCH];
+#pragma unroll
+            for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) sp[j] = sc.cell_spheres[k + j];     // (the array ends in spare entries: host_grid.h)
+            test_batch(sp, k);
         }
         if (RPT_PARKED()) resolve(c_tca, c_rd, c_k);
         if (RPT_HIT() && dist <= t_exit) break;                     // nothing beyond this cell can be nearer
         if (last) break;
         k0 = n0; k1 = n1;
+#pragma unroll
+        for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) pf[j] = sc.cell_spheres[k0 + j];
     }
     hit = hit_w != 0u;
 #undef RPT_HIT_SET
@@ -393,7 +402,7 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
             bool cand[RPT_GRID_BATCH_ANY];
             bool any_cand = false;
 #pragma unroll
-            for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) sp[j] = sc.cell_spheres[k + j];
+            for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) sp[j] = sc.cell_spheres[k + j];     // (requested a cell ahead as in the closest walk: -6 %)
 #pragma unroll
             for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) {
                 const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
