@@ -270,6 +270,41 @@ def cpu_baseline(width, height, budget_s=12.0):
     }
 
 
+def config1_line(rpt, torch, device, threads):
+    """BASELINE.json configs[0] exactly ("c1"): AnalyticalScene 800 x 600, ONE sample per pixel per call — one
+    reference render() — on the CPU port (glibc libm, median of 9 calls after a warm one) and on the GPU (a device-resident
+    buffer, 400 calls back to back, host clock)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    w, h = 800, 600
+    o = oracle_lib.Oracle("liboracle_libm.so")
+    desc = o.scene_analytical()
+    px = np.zeros((h, w, 4), dtype=np.float32)
+    o.render(desc, w, h, 1, seed=1, pixels=px, threads=threads)
+    times = []
+    for k in range(9):
+        t0 = time.perf_counter()
+        o.render(desc, w, h, 1, seed=1, frames_done=1 + k, pixels=px, threads=threads)
+        times.append(time.perf_counter() - t0)
+    cpu_s = sorted(times)[len(times) // 2]
+    tracer = rpt.Tracer(rpt.AnalyticalScene(), device=device, seed=1)
+    buf = rpt.DeviceColorBuffer(w, h, device="cuda:%d" % device)
+    for _ in range(8):
+        tracer.render(buf)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(400):
+        tracer.render(buf)
+    torch.cuda.synchronize()
+    gpu_s = (time.perf_counter() - t0) / 400
+    tracer.close()
+    return {"workload": "AnalyticalScene 800x600 x 1 spp per call (BASELINE.json configs[0]: one reference render())",
+            "cpu_ms_per_call": round(cpu_s * 1e3, 3), "cpu_value": round(w * h / cpu_s / 1e6, 2), "cpu_cores": threads, "cpu_kind": "port",
+            "gpu_ms_per_call": round(gpu_s * 1e3, 4), "gpu_value": round(w * h / gpu_s / 1e6, 1), "unit": "Msamples/s",
+            "gpu_kernel": "render_small_compact_dense_kernel", "gpu_over_cpu": round(cpu_s / gpu_s, 1)}
+
+
 class TorchGatherRender:
     """Insurance only (see main): the interface of tiling.TiledRender over a plain per-rank Tracer, with the tiles
     gathered to rank 0 by torch.distributed's RCCL backend and scattered by the library's untile kernel."""
@@ -580,6 +615,7 @@ def main():
             cpu = cpu_baseline(width, height)
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+            out["config1"] = config1_line(rpt, torch, local_rank, cpu["cores"])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

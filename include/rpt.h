@@ -481,9 +481,9 @@ int rpt_convert_to_u8_at_device(rpt_ctx* ctx, const float* pixels_dev, uint32_t 
  *   c' = c / (1 + c)                                       per r, g, b of every pixel (alpha is not filtered)
  *   iteration i = 0 .. iterations-1, step s = 2^i, k_i = edge_k * 4^i; for every pixel p, over the 3x3 taps
  *   q = p + s * (dx, dy), dy = -1..1 outer, dx = -1..1 inner, q inside the image:
- *       d = c'_p - c'_q;  d2 = d.r*d.r + d.g*d.g + d.b*d.b;  a tap whose d2 is NaN is skipped;
- *       t = 1 - d2 * k_i;  g = t > 0 ? t : 0;  wt = (H[dy+1] * H[dx+1]) * (g * g),  H = {0.25, 0.5, 0.25};
- *       acc += c'_q * wt;  wsum += wt
+ *       d = c'_p - c'_q;  d2 = fma(d.r, d.r, fma(d.g, d.g, d.b*d.b));  a tap whose d2 is NaN is skipped;
+ *       t = fma(-d2, k_i, 1);  g = t > 0 ? t : 0;  wt = (H[dy+1] * H[dx+1]) * (g * g),  H = {0.25, 0.5, 0.25};
+ *       acc = fma(c'_q, wt, acc);  wsum += wt          (fma: ONE rounding, written out on both sides since round 4)
  *   c'_p <- wsum > 0 ? acc / wsum : c'_p                   (all pixels at once: out of place)
  *   finally c = c' / (1 - c'), alpha = the input's; a pixel whose input r, g or b is not finite is copied through unchanged
  *   (and, being NaN in the compressed space, takes no part in its neighbours' sums).

@@ -23,14 +23,14 @@ struct DnSum {
 RPT_DEV void dn_tap(DnSum& s, v3 cp, v3 cq, float hw, float k)
 {
     const float d0 = cp.x - cq.x, d1 = cp.y - cq.y, d2c = cp.z - cq.z;
-    const float d2 = d0 * d0 + d1 * d1 + d2c * d2c;
+    const float d2 = __builtin_fmaf(d0, d0, __builtin_fmaf(d1, d1, d2c * d2c));     // (explicit fmas: the specification's, rpt.h)
     if (!(d2 == d2)) return;
-    const float t = 1.0f - d2 * k;
+    const float t = __builtin_fmaf(-d2, k, 1.0f);
     const float g = t > 0.0f ? t : 0.0f;
     const float wt = hw * (g * g);
-    s.acc.x = s.acc.x + cq.x * wt;
-    s.acc.y = s.acc.y + cq.y * wt;
-    s.acc.z = s.acc.z + cq.z * wt;
+    s.acc.x = __builtin_fmaf(cq.x, wt, s.acc.x);
+    s.acc.y = __builtin_fmaf(cq.y, wt, s.acc.y);
+    s.acc.z = __builtin_fmaf(cq.z, wt, s.acc.z);
     s.wsum = s.wsum + wt;
 }
 
@@ -52,14 +52,21 @@ RPT_DEV float4 dn_finish(const DnSum& s, v3 cp, bool last, float4 orig)
 // 2.3 per pixel) instead of nine taps each from L1 / L2, which is what bounded the first version (2.5 TB/s of HBM-equivalent at both
 // 1080p and 4K: the taps' L2 traffic, not the arithmetic).  FIRST: the source is the caller's buffer and c' = c / (1 + c) is computed
 // once per LOADED pixel (three divides), not once per tap.
+#ifndef RPT_DENOISE_TILE
+#define RPT_DENOISE_TILE 16         // pixels per side of a workgroup's tile (one thread per pixel): 16 -> 256 threads, 32 -> 1 024
+#endif
+constexpr int kDnTile = RPT_DENOISE_TILE;
+constexpr uint32_t kDnThreads = (uint32_t)(kDnTile * kDnTile);
+constexpr uint32_t kDnShift = kDnTile == 32 ? 5u : 4u;
+
 template <int STEP, bool FIRST>
-__global__ __launch_bounds__(256) void denoise_tile_kernel(const float4* __restrict__ src, const float4* __restrict__ orig_in, float4* __restrict__ out,
+__global__ __launch_bounds__(kDnThreads) void denoise_tile_kernel(const float4* __restrict__ src, const float4* __restrict__ orig_in, float4* __restrict__ out,
                                                            uint32_t w, uint32_t h, float k, uint32_t last)
 {
-    constexpr int T = 16 + 2 * STEP;
+    constexpr int T = kDnTile + 2 * STEP;
     __shared__ float s_c[3][T * T];
-    const int x0 = (int)blockIdx.x * 16, y0 = (int)blockIdx.y * 16;
-    for (uint32_t e = threadIdx.x; e < (uint32_t)(T * T); e += 256u) {
+    const int x0 = (int)blockIdx.x * kDnTile, y0 = (int)blockIdx.y * kDnTile;
+    for (uint32_t e = threadIdx.x; e < (uint32_t)(T * T); e += kDnThreads) {
         const int lx = (int)(e % (uint32_t)T), ly = (int)(e / (uint32_t)T);
         const int gx = x0 + lx - STEP, gy = y0 + ly - STEP;
         float c0 = __builtin_nanf(""), c1 = c0, c2 = c0;              // outside the image: NaN, i.e. a tap that is skipped
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void denoise_tile_kernel(const float4* __restr
         s_c[0][e] = c0; s_c[1][e] = c1; s_c[2][e] = c2;
     }
     __syncthreads();
-    const uint32_t tx = threadIdx.x & 15u, ty = threadIdx.x >> 4;
+    const uint32_t tx = threadIdx.x & (uint32_t)(kDnTile - 1), ty = threadIdx.x >> kDnShift;
     const uint32_t x = (uint32_t)x0 + tx, y = (uint32_t)y0 + ty;
     if (x >= w || y >= h) return;
     const int ce = (int)((ty + (uint32_t)STEP) * (uint32_t)T + tx + (uint32_t)STEP);
@@ -125,6 +132,7 @@ hipError_t denoise(const float* in, float* out, float* scratch, uint32_t width, 
 {
     (void)hipGetLastError();
     const dim3 grid((width + 15u) / 16u, (height + 15u) / 16u), wg(256);
+    const dim3 tgrid((width + (uint32_t)kDnTile - 1u) / (uint32_t)kDnTile, (height + (uint32_t)kDnTile - 1u) / (uint32_t)kDnTile), twg(kDnThreads);
     float k = edge_k;
     const float4* cur = nullptr;
     for (uint32_t i = 0; i < iterations; ++i) {
@@ -132,9 +140,9 @@ hipError_t denoise(const float* in, float* out, float* scratch, uint32_t width, 
         float4* dst = (float4*)(((iterations - 1u - i) & 1u) ? scratch : out);
         const float4* orig = (const float4*)in;
         const uint32_t l = last ? 1u : 0u;
-        if (i == 0) hipLaunchKernelGGL((denoise_tile_kernel<1, true>), grid, wg, 0, st, orig, orig, dst, width, height, k, l);
-        else if (i == 1) hipLaunchKernelGGL((denoise_tile_kernel<2, false>), grid, wg, 0, st, cur, orig, dst, width, height, k, l);
-        else if (i == 2) hipLaunchKernelGGL((denoise_tile_kernel<4, false>), grid, wg, 0, st, cur, orig, dst, width, height, k, l);
+        if (i == 0) hipLaunchKernelGGL((denoise_tile_kernel<1, true>), tgrid, twg, 0, st, orig, orig, dst, width, height, k, l);
+        else if (i == 1) hipLaunchKernelGGL((denoise_tile_kernel<2, false>), tgrid, twg, 0, st, cur, orig, dst, width, height, k, l);
+        else if (i == 2) hipLaunchKernelGGL((denoise_tile_kernel<4, false>), tgrid, twg, 0, st, cur, orig, dst, width, height, k, l);
         else hipLaunchKernelGGL(denoise_step_kernel, grid, wg, 0, st, cur, orig, dst, width, height, 1 << i, k, l);
         cur = dst;
         k = k * 4.0f;

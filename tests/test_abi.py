@@ -113,6 +113,8 @@ def test_multi_gpu_entry_points_validate_without_gpu(rpt):
     assert lib.rpt_create_rank(C.byref(h), 0, 0, 1, None) == A.RPT_ERR_INVALID_ARG
     assert lib.rpt_set_tile_rows(None, 2) == A.RPT_ERR_INVALID_ARG
     assert lib.rpt_set_dispatch(None, 1, 12, 64, 0) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_host_pin(None, 16) == A.RPT_ERR_INVALID_ARG and lib.rpt_host_unpin(None) == A.RPT_ERR_INVALID_ARG
+    assert lib.rpt_build_has_ab_kernels() in (0, 1)
     assert lib.rpt_debug_sched_read(None, None, 0, None) == A.RPT_ERR_INVALID_ARG
     assert lib.rpt_world(None, None, None, None) == A.RPT_ERR_INVALID_ARG
     assert lib.rpt_resident_gather_device(None, None) == A.RPT_ERR_INVALID_ARG

@@ -60,6 +60,7 @@ VARIANTS = {
     "pair_w4": ["-DRPT_LARGE_PAIR_WAVES_PER_SIMD=4"],
     "pair_w6": ["-DRPT_LARGE_PAIR_WAVES_PER_SIMD=6"],
     # round 4
+    "denoise_tile32": ["-DRPT_DENOISE_TILE=32"],              # the denoiser's LDS tiles 32 x 32 (1 024 threads) instead of 16 x 16: halos 1.32 instead of 1.69 loads per pixel
     "sdf_prims_lds": ["-DRPT_SDF_PRIMS_IN_LDS"],               # the SDF primitive records staged in LDS instead of read through the scalar cache
 }
 
