@@ -13,12 +13,12 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpt_hip.so")
-SOURCES = ["kernels.hip", "kernels_fast.hip", "denoise.hip", "capi.hip"]
-# kernels_fast.hip: the same kernels with relaxed arithmetic (RPT_RENDER_FAST_MATH); every other file is strict
-EXTRA_FLAGS = {"kernels_fast.hip": ["-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"],
+# (object, source): kernels.hip is built twice — the second time with relaxed arithmetic (RPT_RENDER_FAST_MATH); everything else is strict
+OBJECTS = [("kernels", "kernels.hip"), ("kernels_relaxed", "kernels.hip"), ("denoise", "denoise.hip"), ("capi", "capi.hip")]
+EXTRA_FLAGS = {"kernels_relaxed": ["-DRPT_RELAXED_BUILD", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"],
                # the denoiser's taps are independent multiply / add sequences: packed f32 instructions halve their issue slots there
                # (the path kernels lose from SLP: it pins register pairs)
-               "denoise.hip": ["-fslp-vectorize"]}
+               "denoise": ["-fslp-vectorize"]}
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
 # fused operations are the explicit fma calls of rpt_strict_math.h.
 # -mllvm -disable-machine-licm: MachineLICM hoists the materialisation of ~70 literal constants (the
@@ -81,9 +81,9 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="buil
     os.makedirs(objdir, exist_ok=True)
     flags = BASE_FLAGS + _tuning_flags() + (["-DRPT_AB_KERNELS"] if ab else [])
     procs, objs = [], []
-    for src in SOURCES:                                   # one object per source (each with its own flags), in parallel
-        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    for name, src in OBJECTS:                             # one object each, with its own flags, in parallel
+        obj = os.path.join(objdir, name + ".o")
+        cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(name, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))

@@ -45,7 +45,7 @@ hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t*
 
 }  // namespace rptlaunch
 
-// the relaxed-arithmetic build of the same kernels (kernels_fast.hip)
+// the relaxed-arithmetic build of the same kernels (kernels.hip under -DRPT_RELAXED_BUILD)
 namespace rptlaunch_fast {
 hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st,
                             bool media = false);
