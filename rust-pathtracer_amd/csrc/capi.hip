@@ -516,6 +516,8 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         rp.walk_refill_at = refill;
         rp.carry_wait_at = wait_at < 1u ? 1u : wait_at;
         rp.carry_walk_min = walk_min;
+        static const uint32_t walk_cap = getenv("RPT_LARGE_WALK_CAP") ? (uint32_t)atoi(getenv("RPT_LARGE_WALK_CAP")) : 0u;
+        rp.large_walk_cap = walk_cap;
     }
     if (flags & RPT_RENDER_RUSSIAN_ROULETTE) { scs.flags |= kSceneFlagRussianRoulette; scl.flags |= kSceneFlagRussianRoulette; }
     if (rp.rows_local == 0) return RPT_OK;
@@ -532,6 +534,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         else if (has_sdf && (flags & RPT_RENDER_SDF_INLINE_MARCH)) what = "RPT_RENDER_SDF_INLINE_MARCH";
         else if (has_sdf && (flags & RPT_RENDER_SDF_THREE_ROOM_MARCH)) what = "RPT_RENDER_SDF_THREE_ROOM_MARCH";
         else if (ctx->large && scl.use_accel && scl.max_depth != 0u && wavefront_wanted(flags)) what = "RPT_RENDER_LARGE_WAVEFRONT";
+        else if (ctx->large && (rp.large_pair_walk || rp.large_carry_walk || rp.large_walk_cap)) what = "selected by RPT_LARGE_MEGA / RPT_LARGE_WALK_CAP";
         if (what) {
             set_err(ctx, "render: the A/B kernel form %s is not in this build (-DRPT_AB_KERNELS: python rust-pathtracer_amd/build.py --ab)", what);
             return RPT_ERR_UNSUPPORTED;

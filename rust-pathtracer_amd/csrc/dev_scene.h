@@ -154,6 +154,7 @@ struct RenderParams {
     uint32_t large_carry_walk;     // large scenes with a grid: the megakernel whose walks are a scheduling state of the lane (kernel_large_carry.h)
     uint32_t carry_wait_at;        // ... it leaves the walk loop for the block when this many lanes are through their walks ...
     uint32_t carry_walk_min;       // ... or when fewer than this many still walk (and somebody waits)
+    uint32_t large_walk_cap;       // large scenes with a grid: cells a closest-hit walk takes per TRACE pass before it parks (0: the walk runs inside closest_hit)
     uint32_t compact;              // small scenes: the kernel that re-deals its workgroup's paths before every stage (few samples per launch)
     // Dispatch (kernels.hip, "Dispatch: units, their order, their hand-off").  A launch of the state-machine kernels is
     // n_chunks * (tiles) workgroups; each renders chunk_spp samples (the last chunk: the rest of spp) of one tile.  n_chunks == 0:

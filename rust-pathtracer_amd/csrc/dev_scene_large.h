@@ -192,6 +192,26 @@ RPT_DEV GridWalk grid_begin(const SceneLarge& sc, const RayD& ray)
     return g;
 }
 
+// What grid_begin derives from the ray alone — the steps, the increments, the tier — for a walk whose cell and exit parameters come from
+// somewhere else (a parked walk: kernels.hip, render_large_resume_body).  The same operations on the same operands: the same values.
+RPT_DEV void grid_increments(const SceneLarge& sc, const RayD& ray, GridWalk& g)
+{
+    g.coff = grid_tier(sc, ray);
+    const float d[3] = {ray.d.x, ray.d.y, ray.d.z};
+    int step[3];
+    float tdel[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const bool fwd = d[a] > 0.0f, flat = d[a] == 0.0f;
+        const float inv = __builtin_amdgcn_rcpf(flat ? 1.0f : d[a]);
+        step[a] = flat ? 0 : (fwd ? 1 : -1);
+        tdel[a] = flat ? 3.40282347e+38f : sc.cell_size[a] * __builtin_fabsf(inv);
+    }
+    g.sx = step[0]; g.sy = step[1]; g.sz = step[2];
+    g.tdx = tdel[0]; g.tdy = tdel[1]; g.tdz = tdel[2];
+    g.alive = true;
+}
+
 // cell_start[c], cell_start[c + 1] in one 8-byte load (dword-aligned)
 RPT_DEV void cell_bounds(const SceneLarge& sc, uint32_t c, uint32_t& k0, uint32_t& k1)
 {
@@ -279,99 +299,116 @@ RPT_DEV bool brute_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_ma
     return occluded;
 }
 
+// A closest-hit walk between two cells: the cell the ray is in, its list [k0, k1) and that list's first entries, already loaded.
+struct ClosestWalk {
+    GridWalk g;
+    uint32_t k0, k1;
+    float4 pf[RPT_GRID_BATCH];                                      // in flight across the loop's back edge
+};
+
+// The walk is bound by the latency of its dependent loads (cell -> list bounds -> spheres), not by arithmetic, so the next cell's
+// list bounds are requested before this cell's spheres are tested, and the first entries of the next list with them.
+RPT_DEV void closest_walk_fetch(const SceneLarge& sc, ClosestWalk& w, uint32_t cell)
+{
+    cell_bounds(sc, cell, w.k0, w.k1);
+#pragma unroll
+    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = sc.cell_spheres[w.k0 + j];     // (the array ends in spare entries: host_grid.h)
+}
+
+// One cell of the walk: true when the walk is over (nothing beyond this cell can be nearer, or the ray leaves the grid box here).
+// `hit_w` (a sphere has been accepted) and "a candidate is parked" are WORDS in vector registers: as bools the compiler keeps them as
+// lane masks in SGPRs and merges them with scalar instructions at every join of the walk's nested branches — and the scalar unit, one
+// per CU for its four SIMDs, issues one instruction for every two vector ones in this kernel (profiles/r3/c5_megakernel: 2.3e10
+// SALU + 5.5e9 branches against 4.6e10 VALU).  10 k spheres, 2048^2 x 32 spp: 2 138 -> 2 212 Msamples/s (+3.5 %), round 4.
+RPT_DEV bool closest_walk_cell(const SceneLarge& sc, const RayD& ray, ClosestWalk& w, float& dist, uint32_t& best, uint32_t& hit_w)
+{
+    RPT_PROF(PB_GRID_CELL);
+    GridWalk& g = w.g;
+    const uint32_t k0 = w.k0, k1 = w.k1;
+    const float t_exit = grid_cell_exit(g);                         // of the cell whose list is [k0, k1)
+    const bool last = t_exit > g.t_end;                             // the ray leaves the grid box in this cell
+    grid_advance(g);                                                // g is the NEXT cell from here on
+    uint32_t n0, n1;
+    cell_bounds(sc, grid_cell_index_clamped(sc, g), n0, n1);        // (also when this is the last cell: the index is always a cell's, and an unconditional load needs no exec mask)
+    // The cell's list, RPT_GRID_BATCH entries per trip: the loads go out together, hit_sphere's discriminant is computed
+    // branch-free for all of them and only candidates (the line meets the sphere: few) take its square-root half.  The
+    // acceptance rule is order-independent, so neither batching nor parking changes the winner.  (Against the plain loop
+    // over hit_sphere, 10 k spheres: two-phase test +4.6 %, 2 per trip +1.8 %, one 8-byte load for the list bounds +1.4 %;
+    // 4 per trip: more live registers than the kernel has, -6 %.)
+    // The first candidate of a cell parks hit_sphere's tca and radius2 - d2 and its square-root half runs once, behind the
+    // list, with the other lanes' (+1.4 %); further candidates of the same cell are resolved at once.
+    float c_tca = 0.0f, c_rd = 0.0f;
+    uint32_t c_k = 0xFFFFFFFFu;                                     // 0xFFFFFFFF: nothing parked
+    // hit_sphere's second half (analytical.rs:176-189) for a candidate, in selects.  Its swap of the roots is not here: thc is a
+    // square root, so t0 = tca - thc <= tca + thc = t1 unless both are NaN, and then nothing below accepts them either.  The
+    // sphere's index is loaded only for a root that can still win (t <= dist).
+    auto resolve = [&](float tca, float rd, uint32_t kk) {
+        const float thc = fsqrt(rd);
+        const float t0 = tca - thc;
+        const float t1 = tca + thc;
+        const float t = t0 < 0.0f ? t1 : t0;
+        if (!(t < 0.0f) && t <= dist) {
+            const uint32_t i = sc.cell_items[kk];
+            if (i != 0u && (t < dist || i < best)) { dist = t; best = i; hit_w = 1u; }
+        }
+    };
+    auto test_batch = [&](const float4* sp, uint32_t k) {
+#pragma unroll
+        for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) {
+            const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
+            const float tca = dot3(l, ray.d);
+            const float d2 = dot3(l, l) - tca * tca;
+            const float radius2 = sp[j].w * sp[j].w;
+            if ((k + j < k1) && !(d2 > radius2)) {
+                if (c_k == 0xFFFFFFFFu) { c_tca = tca; c_rd = radius2 - d2; c_k = k + j; }
+                else resolve(tca, radius2 - d2, k + j);
+            }
+        }
+    };
+    test_batch(w.pf, k0);                                           // the list's first entries were requested a cell ago (+1.5 %, round 4)
+    for (uint32_t k = k0 + RPT_GRID_BATCH; k < k1; k += RPT_GRID_BATCH) {
+        float4 sp[RPT_GRID_BATCH];
+#pragma unroll
+        for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) sp[j] = sc.cell_spheres[k + j];
+        test_batch(sp, k);
+    }
+    if (c_k != 0xFFFFFFFFu) resolve(c_tca, c_rd, c_k);
+    if (hit_w != 0u && dist <= t_exit) return true;
+    if (last) return true;
+    w.k0 = n0; w.k1 = n1;
+#pragma unroll
+    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = sc.cell_spheres[n0 + j];
+    return false;
+}
+
+// A DDA crosses at most nx + ny + nz cells; with this many trips as its guard every wave leaves a walk loop whatever the ray holds.
+RPT_DEV uint32_t grid_walk_guard(const SceneLarge& sc) { return sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; }
+
 RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& dist, uint32_t& best, bool& hit)
 {
     if (!grid_usable(sc, ray)) { brute_closest_sphere(sc, ray, dist, best, hit); return; }
-    // `hit` and "a candidate is parked" as WORDS in vector registers: as bools the compiler keeps them as lane masks in SGPRs and
-    // merges them with scalar instructions at every join of the walk's nested branches — and the scalar unit, one per CU for its
-    // four SIMDs, issues one instruction for every two vector ones in this kernel (profiles/r3/c5_megakernel: 2.3e10 SALU + 5.5e9
-    // branches against 4.6e10 VALU).  10 k spheres, 2048^2 x 32 spp: 2 138 -> 2 212 Msamples/s (+3.5 %), round 4.
     uint32_t hit_w = hit ? 1u : 0u;
-#define RPT_HIT_SET() (hit_w = 1u)
-#define RPT_HIT() (hit_w != 0u)
     {   // sphere 0: accepted whenever it is hit (analytical.rs:43)
         const float4 s = sphere_uniform(sc, 0);
         float t;
-        if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; RPT_HIT_SET(); }
+        if (hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t)) { dist = t; best = 0; hit_w = 1u; }
     }
     for (uint32_t j = 0; j < sc.n_oversize; ++j) {                  // the spheres that are not in the grid (wave-uniform loop)
         const uint32_t i = ((cuint_p)sc.oversize)[j];
         const float4 s = sphere_uniform(sc, i);
         float t;
-        if (i != 0u && hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (t < dist || (t == dist && i < best))) { dist = t; best = i; RPT_HIT_SET(); }
+        if (i != 0u && hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (t < dist || (t == dist && i < best))) { dist = t; best = i; hit_w = 1u; }
     }
-    GridWalk g;
-    { RPT_PROF(PB_GRID_BEGIN); g = grid_begin(sc, ray); }
-    // The walk is bound by the latency of its dependent loads (cell -> list bounds -> spheres), not by
-    // arithmetic, so the next cell's list bounds are requested before this cell's spheres are tested.
-    // A DDA crosses at most nx+ny+nz cells; the guard guarantees every wave leaves the loop.
-    uint32_t k0 = 0, k1 = 0;
-    if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
-    float4 pf[RPT_GRID_BATCH];                                      // the first entries of the NEXT cell's list, in flight across the loop's back edge
+    ClosestWalk w;
+    { RPT_PROF(PB_GRID_BEGIN); w.g = grid_begin(sc, ray); }
+    w.k0 = 0; w.k1 = 0;
+    if (w.g.alive) cell_bounds(sc, grid_cell_index(sc, w.g), w.k0, w.k1);
 #pragma unroll
-    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) pf[j] = sc.cell_spheres[k0 + j];
-    if (g.alive)
-    for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; guard != 0u; --guard) {
-        RPT_PROF(PB_GRID_CELL);
-        const float t_exit = grid_cell_exit(g);                     // of the cell whose list is [k0, k1)
-        const bool last = t_exit > g.t_end;                         // the ray leaves the grid box in this cell
-        grid_advance(g);                                            // g is the NEXT cell from here on
-        uint32_t n0, n1;
-        cell_bounds(sc, grid_cell_index_clamped(sc, g), n0, n1);    // (also when this is the last cell: the index is always a cell's, and an unconditional load needs no exec mask)
-        // The cell's list, RPT_GRID_BATCH entries per trip: the loads go out together, hit_sphere's discriminant is computed
-        // branch-free for all of them and only candidates (the line meets the sphere: few) take its square-root half.  The
-        // acceptance rule is order-independent, so neither batching nor parking changes the winner.  (Against the plain loop
-        // over hit_sphere, 10 k spheres: two-phase test +4.6 %, 2 per trip +1.8 %, one 8-byte load for the list bounds +1.4 %;
-        // 4 per trip: more live registers than the kernel has, -6 %.)
-        // The first candidate of a cell parks hit_sphere's tca and radius2 - d2 and its square-root half runs once, behind the
-        // list, with the other lanes' (+1.4 %); further candidates of the same cell are resolved at once.
-        float c_tca = 0.0f, c_rd = 0.0f;
-        uint32_t c_k = 0xFFFFFFFFu;                                 // 0xFFFFFFFF: nothing parked
-#define RPT_PARKED() (c_k != 0xFFFFFFFFu)
-        // hit_sphere's second half (analytical.rs:176-189) for a candidate, in selects.  Its swap of the roots is not here: thc is a
-        // square root, so t0 = tca - thc <= tca + thc = t1 unless both are NaN, and then nothing below accepts them either.  The
-        // sphere's index is loaded only for a root that can still win (t <= dist).
-        auto resolve = [&](float tca, float rd, uint32_t kk) {
-            const float thc = fsqrt(rd);
-            const float t0 = tca - thc;
-            const float t1 = tca + thc;
-            const float t = t0 < 0.0f ? t1 : t0;
-            if (!(t < 0.0f) && t <= dist) {
-                const uint32_t i = sc.cell_items[kk];
-                if (i != 0u && (t < dist || i < best)) { dist = t; best = i; RPT_HIT_SET(); }
-            }
-        };
-        auto test_batch = [&](const float4* sp, uint32_t k) {
-#pragma unroll
-            for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) {
-                const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
-                const float tca = dot3(l, ray.d);
-                const float d2 = dot3(l, l) - tca * tca;
-                const float radius2 = sp[j].w * sp[j].w;
-                if ((k + j < k1) && !(d2 > radius2)) {
-                    if (!RPT_PARKED()) { c_tca = tca; c_rd = radius2 - d2; c_k = k + j; }
-                    else resolve(tca, radius2 - d2, k + j);
-                }
-            }
-        };
-        test_batch(pf, k0);                                         // the list's first entries were requested a cell ago (+1.5 %, round 4)
-        for (uint32_t k = k0 + RPT_GRID_BATCH; k < k1; k += RPT_GRID_BATCH) {
-            float4 sp[RPT_GRID_BATCH];
-#pragma unroll
-            for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) sp[j] = sc.cell_spheres[k + j];     // (the array ends in spare entries: host_grid.h)
-            test_batch(sp, k);
-        }
-        if (RPT_PARKED()) resolve(c_tca, c_rd, c_k);
-        if (RPT_HIT() && dist <= t_exit) break;                     // nothing beyond this cell can be nearer
-        if (last) break;
-        k0 = n0; k1 = n1;
-#pragma unroll
-        for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) pf[j] = sc.cell_spheres[k0 + j];
-    }
+    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = sc.cell_spheres[w.k0 + j];
+    if (w.g.alive)
+    for (uint32_t guard = grid_walk_guard(sc); guard != 0u; --guard)
+        if (closest_walk_cell(sc, ray, w, dist, best, hit_w)) break;
     hit = hit_w != 0u;
-#undef RPT_HIT_SET
-#undef RPT_HIT
-#undef RPT_PARKED
 }
 
 RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max, float max_dist)

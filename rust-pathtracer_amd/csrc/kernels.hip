@@ -502,6 +502,7 @@ __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_rege
 #ifdef RPT_AB_KERNELS
 #include "ab/kernel_large_pair.h"
 #include "ab/kernel_large_carry.h"
+#include "ab/kernel_large_resume.h"
 #endif
 
 #ifdef RPT_AB_KERNELS    // the wavefront form of large scenes (RPT_RENDER_LARGE_WAVEFRONT): A/B builds only since round 4 (the megakernel is ahead at every size)
@@ -1674,6 +1675,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     else if (large && nested) hipLaunchKernelGGL(RPT_K(render_large_nested_kernel), tiles, wg, 0, st, scl, rp);
     else if (large && rp.large_pair_walk && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_pair_kernel), tiles, wg, 0, st, scl, rp);
     else if (large && rp.large_carry_walk && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_carry_kernel), tiles, wg, 0, st, scl, rp);
+    else if (large && rp.large_walk_cap != 0u && scl.use_accel) hipLaunchKernelGGL(RPT_K(render_large_resume_kernel), tiles, wg, 0, st, scl, rp);
     else if (has_sdf && nested) hipLaunchKernelGGL(RPT_K(render_sdf_nested_kernel), tiles, wg, 0, st, scs, rp);
     else if (has_sdf && rp.sdf_resumable_march == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_pool_kernel), tiles, wg, 0, st, scs, rp);
     else if (has_sdf && rp.sdf_resumable_march == 3u && scs_dev) hipLaunchKernelGGL(RPT_K(render_sdf_compact_kernel), tiles, wg, 0, st, scs_dev, rp);
