@@ -24,6 +24,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,6 +35,7 @@ FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 GPU_CLOCK_HZ = 2.4e9           # the same table's engine clock (the PMC passes measured 2.37e9 under this kernel)
 C2 = (1920, 1080, 256)         # BASELINE.json configs[1]
 C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
+SECONDARY_LIMIT_S = int(os.environ.get("RPT_BENCH_SECONDARY_LIMIT_S", "150"))        # N > 1: the legs after the headline (weak scaling, the one-GPU frame, configs[4]) may take this long together
 PROFILES = os.path.join("profiles", "r4")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
 TRAFFIC_JSON = os.path.join(PROFILES, "c2_bench", "traffic.json")
 # What a correctly rounded f32 divide / square root costs the VALU in this library (csrc/dev_math.h): a quotient is v_rcp + 2 fma
@@ -402,92 +404,74 @@ def main():
         torch.cuda.synchronize()
 
     scene = rpt.AnalyticalScene()
-    out = None
-    if world == 1:
-        # ---- one GPU: configs[1].  The frame is a torch tensor, the launches go to torch's current stream, and
-        # torch.cuda.Event pairs on that stream time each step's kernel.
-        width, height, spp = shrink(C2)
-        tracer = rpt.Tracer(scene, device=local_rank, seed=1)
-        buf = rpt.DeviceColorBuffer(width, height, device="cuda:%d" % local_rank)
-        for _ in range(args.warmup):
-            tracer.render_n(buf, spp)
-        host_fence()
-        evs = []
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()                     # torch's current stream == the stream the kernel is launched on
-            tracer.render_n(buf, spp)
-            e1.record()
-            evs.append((e0, e1))
-        host_fence()
-        elapsed = time.perf_counter() - t0
-        kernel_ms = [a.elapsed_time(b) for a, b in evs]
-        local_pixels = width * height
-        extra = {}
-    else:
-        # ---- N GPUs: configs[2], strong scaling, gather to rank 0 inside the timed region
-        width, height, spp = shrink(C3)
-        gather_mode = "library RCCL send/recv to rank 0"
-        if args.smoke_shared_gpu:
-            os.environ["RPT_GATHER"] = "p2p"
-            tracer = None
-            if rank == 0:                   # one process drives all "ranks" of cuda:0; the others only keep the barriers company
-                tracer = rpt.Tracer(scene, devices=[0] * world, seed=1)
-        else:
-            # The library's own communicator (rpt_create_rank).  If it cannot be set up on this node, every rank falls
-            # back TOGETHER to per-rank tiles + a torch.distributed (RCCL) gather, and the JSON line says so.
-            why = ""
-            try:
-                tracer = tiling.rank_tracer(scene, local_rank, seed=1)
-            except Exception as e:          # noqa: BLE001 - any failure of the collective set-up takes the fallback
-                tracer, why = None, "%s: %s" % (type(e).__name__, e)
-            ok = torch.tensor([1 if tracer else 0])
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if tracer:
-                    tracer.close()
-                tracer = rpt.Tracer(scene, device=local_rank, seed=1)
-                gather_mode = "torch.distributed RCCL gather (fallback: the library communicator failed to initialise%s)" % (
-                    ": " + why if why else " on another rank")
-        if gather_mode.startswith("torch"):
-            job_of = lambda w, h: TorchGatherRender(tracer, tiling, w, h, 2, rank, world, local_rank)     # noqa: E731
-        else:
-            job_of = lambda w, h: tiling.TiledRender(tracer, w, h, tile_rows=2) if tracer else None      # noqa: E731
-        job = job_of(width, height)
+    extra = {}                          # secondary results of the JSON line
+    emitted = []
 
-        def step():
-            if job:
-                job.render_n(spp)
-                job.gather_begin()          # enqueued behind the render on the library's streams: no host wait
+    def emit():
+        """Rank 0 prints the ONE JSON line (once, whoever asks first: the end of main or the secondary legs' timer)."""
+        if rank != 0 or emitted:
+            return
+        emitted.append(True)
+        samples = width * height * spp * args.steps
+        value = samples / elapsed / 1e6
+        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+        ops = op_counts()
+        # FP32-VALU roofline of the megakernel: this rank's pixels x spp per step over the step's measured launch time
+        launch_samples = local_pixels * spp
+        algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
+        hbm = algo_bytes / avg_kernel_s / 1e9
+        launches = 1                              # one launch whatever spp is (kernels.hip: a launch is tiles x chunks of samples)
+        kernel = "render_small_regen_kernel" if spp > 1 else "render_small_compact_kernel"     # (capi.hip: RPT_COMPACT_MAX_SPP)
+        roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels)
+        roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
+                            "rounded f32 divide or sqrt costs 8-13 VALU instructions in this library (ieee_expanded_*); kernel_ms = HIP events on the launch stream")
+        tj = os.path.join(ROOT, TRAFFIC_JSON)
+        if world == 1 and not args.small and os.path.exists(tj):
+            t = json.load(open(tj))
+            roofline["traffic"] = t["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "%s: rocprofv3 PMC passes of this command, committed (%s); bench.py cannot collect counters itself" % (
+                TRAFFIC_JSON, t["correction"])
+            if "valu_insts_per_launch" in t:
+                # How busy the vector ALUs are, from the same committed PMC passes and THIS run's kernel time: a SIMD issues one
+                # wave64 VALU instruction per quad-cycle, two when two waves have one ready (SQ_ACTIVE_INST_VALU2), which is
+                # what the 157 TFLOP/s peak assumes.  SIMD cycles = 1 024 SIMDs x kernel time x the clock.
+                simd_quads = 1024.0 * avg_kernel_s * GPU_CLOCK_HZ / 4.0
+                roofline["valu_issue"] = {
+                    "insts_per_launch": t["valu_insts_per_launch"], "lane_utilisation": round(t.get("valu_lane_utilisation", 0.0), 3),
+                    "insts_per_simd_quad_cycle": round(t["valu_insts_per_launch"] / simd_quads, 3),
+                    "frac_of_dual_issue_peak": round(t["valu_insts_per_launch"] / simd_quads / 2.0, 3),
+                    "note": "VALU wave-instructions per SIMD per 4 cycles (rocprofv3's VALUBusy / 100); 2.0 is the issue peak, "
+                            "reached only with every instruction dual-issued and no dependency or memory stall; x lane_utilisation "
+                            "= the share of the ALU lanes doing path work"}
+        out = {
+            "metric": "Msamples/s (pixels x spp) on AnalyticalScene 1920x1080 f32; 1/2/4/8-GPU scaling",
+            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak" if world == 1 else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[1])" % (width, height, spp)) if world == 1 else
+                                   ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[2]): cyclic 2-row tiles over %d GPUs, "
+                                    "RCCL gather to rank 0 + scatter per step inside the timed region" % (width, height, spp, world)),
+                       "spp_per_step": spp, "width": width, "height": height, "parallelism": "rows%d" % world,
+                       **({"gather": gather_mode} if world > 1 else {})},
+            "roofline": roofline,
+            "roofline_hbm": {"bound": "hbm", "achieved": round(hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 6),
+                             "algorithmic_bytes_per_step": algo_bytes,
+                             "note": "32/S bytes per pixel-sample: the honest signature of an ALU-bound path, not the binding roofline"},
+        }
+        out.update(extra)
+        if world == 1 and not args.headline_only:
+            out.update(other_configs(rpt, torch, local_rank, args.small))
+        if world == 1 and not args.no_cpu_baseline and not args.small:
+            cpu = cpu_baseline(width, height)
+            out["cpu_baseline"] = cpu
+            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
+            out["config1"] = config1_line(rpt, torch, local_rank, cpu["cores"])
+        print(json.dumps(out))
 
-        def drain():
-            if job:
-                job.gather_end()
-
-        if job:                             # set the communicator's connections up outside the timed region, whatever --warmup is
-            job.render_n(1)
-            job.gather()
-        for _ in range(args.warmup):
-            step()
-        drain()
-        host_fence()
-        kernel_ms = []
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-            if isinstance(job, TorchGatherRender):
-                kernel_ms.append(job.kernel_ms())
-            elif tracer:
-                kernel_ms.append(tracer.resident_kernel_ms())     # HIP events around this step's launches, on their stream
-        drain()
-        host_fence()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        local_pixels = tiling.tile_row_count(height, 2, rank, world) * width
-        extra = {}
+    def secondary_legs():
+        if os.environ.get("RPT_BENCH_TEST_STALL") == str(rank):         # tests: this rank never reaches the legs' first collective
+            time.sleep(3600)
         # secondary: fixed work per GPU (weak scaling), a few steps
         ww, wh = weak_frame(world)
         ww, wh, wspp = shrink((ww, wh, C2[2]))
@@ -558,65 +542,114 @@ def main():
             if tracer:
                 tracer._scene = scene
                 tracer.upload_scene()
-        dist.barrier()
 
-    if rank == 0:
-        samples = width * height * spp * args.steps
-        value = samples / elapsed / 1e6
-        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
-        ops = op_counts()
-        # FP32-VALU roofline of the megakernel: this rank's pixels x spp per step over the step's measured launch time
-        launch_samples = local_pixels * spp
-        algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
-        hbm = algo_bytes / avg_kernel_s / 1e9
-        launches = 1                              # one launch whatever spp is (kernels.hip: a launch is tiles x chunks of samples)
-        kernel = "render_small_regen_kernel" if spp > 1 else "render_small_compact_kernel"     # (capi.hip: RPT_COMPACT_MAX_SPP)
-        roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels)
-        roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
-                            "rounded f32 divide or sqrt costs 8-13 VALU instructions in this library (ieee_expanded_*); kernel_ms = HIP events on the launch stream")
-        tj = os.path.join(ROOT, TRAFFIC_JSON)
-        if world == 1 and not args.small and os.path.exists(tj):
-            t = json.load(open(tj))
-            roofline["traffic"] = t["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "%s: rocprofv3 PMC passes of this command, committed (%s); bench.py cannot collect counters itself" % (
-                TRAFFIC_JSON, t["correction"])
-            if "valu_insts_per_launch" in t:
-                # How busy the vector ALUs are, from the same committed PMC passes and THIS run's kernel time: a SIMD issues one
-                # wave64 VALU instruction per quad-cycle, two when two waves have one ready (SQ_ACTIVE_INST_VALU2), which is
-                # what the 157 TFLOP/s peak assumes.  SIMD cycles = 1 024 SIMDs x kernel time x the clock.
-                simd_quads = 1024.0 * avg_kernel_s * GPU_CLOCK_HZ / 4.0
-                roofline["valu_issue"] = {
-                    "insts_per_launch": t["valu_insts_per_launch"], "lane_utilisation": round(t.get("valu_lane_utilisation", 0.0), 3),
-                    "insts_per_simd_quad_cycle": round(t["valu_insts_per_launch"] / simd_quads, 3),
-                    "frac_of_dual_issue_peak": round(t["valu_insts_per_launch"] / simd_quads / 2.0, 3),
-                    "note": "VALU wave-instructions per SIMD per 4 cycles (rocprofv3's VALUBusy / 100); 2.0 is the issue peak, "
-                            "reached only with every instruction dual-issued and no dependency or memory stall; x lane_utilisation "
-                            "= the share of the ALU lanes doing path work"}
-        out = {
-            "metric": "Msamples/s (pixels x spp) on AnalyticalScene 1920x1080 f32; 1/2/4/8-GPU scaling",
-            "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[1])" % (width, height, spp)) if world == 1 else
-                                   ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[2]): cyclic 2-row tiles over %d GPUs, "
-                                    "RCCL gather to rank 0 + scatter per step inside the timed region" % (width, height, spp, world)),
-                       "spp_per_step": spp, "width": width, "height": height, "parallelism": "rows%d" % world,
-                       **({"gather": gather_mode} if world > 1 else {})},
-            "roofline": roofline,
-            "roofline_hbm": {"bound": "hbm", "achieved": round(hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 6),
-                             "algorithmic_bytes_per_step": algo_bytes,
-                             "note": "32/S bytes per pixel-sample: the honest signature of an ALU-bound path, not the binding roofline"},
-        }
-        out.update(extra)
-        if world == 1 and not args.headline_only:
-            out.update(other_configs(rpt, torch, local_rank, args.small))
-        if world == 1 and not args.no_cpu_baseline and not args.small:
-            cpu = cpu_baseline(width, height)
-            out["cpu_baseline"] = cpu
-            out["gpu_over_cpu"] = round(value / cpu["value"], 1)
-            out["config1"] = config1_line(rpt, torch, local_rank, cpu["cores"])
-        print(json.dumps(out))
+    if world == 1:
+        # ---- one GPU: configs[1].  The frame is a torch tensor, the launches go to torch's current stream, and
+        # torch.cuda.Event pairs on that stream time each step's kernel.
+        width, height, spp = shrink(C2)
+        tracer = rpt.Tracer(scene, device=local_rank, seed=1)
+        buf = rpt.DeviceColorBuffer(width, height, device="cuda:%d" % local_rank)
+        for _ in range(args.warmup):
+            tracer.render_n(buf, spp)
+        host_fence()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()                     # torch's current stream == the stream the kernel is launched on
+            tracer.render_n(buf, spp)
+            e1.record()
+            evs.append((e0, e1))
+        host_fence()
+        elapsed = time.perf_counter() - t0
+        kernel_ms = [a.elapsed_time(b) for a, b in evs]
+        local_pixels = width * height
+    else:
+        # ---- N GPUs: configs[2], strong scaling, gather to rank 0 inside the timed region
+        width, height, spp = shrink(C3)
+        gather_mode = "library RCCL send/recv to rank 0"
+        if args.smoke_shared_gpu:
+            os.environ["RPT_GATHER"] = "p2p"
+            tracer = None
+            if rank == 0:                   # one process drives all "ranks" of cuda:0; the others only keep the barriers company
+                tracer = rpt.Tracer(scene, devices=[0] * world, seed=1)
+        else:
+            # The library's own communicator (rpt_create_rank).  If it cannot be set up on this node, every rank falls
+            # back TOGETHER to per-rank tiles + a torch.distributed (RCCL) gather, and the JSON line says so.
+            why = ""
+            try:
+                tracer = tiling.rank_tracer(scene, local_rank, seed=1)
+                first = tiling.TiledRender(tracer, 64, 64, tile_rows=2)       # the communicator's first exchange, on a small frame
+                first.render_n(1)
+                first.gather()
+                del first
+            except Exception as e:          # noqa: BLE001 - any failure of the collective set-up takes the fallback
+                tracer, why = None, "%s: %s" % (type(e).__name__, e)
+            ok = torch.tensor([1 if tracer else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if tracer:
+                    tracer.close()
+                tracer = rpt.Tracer(scene, device=local_rank, seed=1)
+                gather_mode = "torch.distributed RCCL gather (fallback: the library communicator failed to initialise%s)" % (
+                    ": " + why if why else " on another rank")
+        if gather_mode.startswith("torch"):
+            job_of = lambda w, h: TorchGatherRender(tracer, tiling, w, h, 2, rank, world, local_rank)     # noqa: E731
+        else:
+            job_of = lambda w, h: tiling.TiledRender(tracer, w, h, tile_rows=2) if tracer else None      # noqa: E731
+        job = job_of(width, height)
+
+        def step():
+            if job:
+                job.render_n(spp)
+                job.gather_begin()          # enqueued behind the render on the library's streams: no host wait
+
+        def drain():
+            if job:
+                job.gather_end()
+
+        if job:                             # set the communicator's connections up outside the timed region, whatever --warmup is
+            job.render_n(1)
+            job.gather()
+        for _ in range(args.warmup):
+            step()
+        drain()
+        host_fence()
+        kernel_ms = []
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            if isinstance(job, TorchGatherRender):
+                kernel_ms.append(job.kernel_ms())
+            elif tracer:
+                kernel_ms.append(tracer.resident_kernel_ms())     # HIP events around this step's launches, on their stream
+        drain()
+        host_fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        local_pixels = tiling.tile_row_count(height, 2, rank, world) * width
+        # The headline is measured.  What follows are secondary legs on the same communicator: they must never cost the line.
+        # A leg that raises is recorded and ends the legs on this rank; ranks that then wait for it in a collective — or a leg that
+        # hangs — are cut off by a timer that emits the line with what there is and leaves.
+        def cut_off():
+            extra["secondary_legs"] = "cut off after %d s" % SECONDARY_LIMIT_S
+            emit()
+            sys.stdout.flush()
+            os._exit(0)
+
+        watchdog = threading.Timer(SECONDARY_LIMIT_S, cut_off)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            secondary_legs()
+        except Exception as e:              # noqa: BLE001
+            extra["secondary_legs"] = "stopped by %s: %s" % (type(e).__name__, e)
+        dist.barrier()
+        watchdog.cancel()
+
+    emit()
     if world > 1:
         dist.barrier()
         if tracer:

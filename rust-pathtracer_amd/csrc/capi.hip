@@ -1389,18 +1389,24 @@ static int gather_to_root(rpt_ctx* ctx, float* image_dst, float** image_out)
         RPT_HIP_CHECK(ctx, guard.to(root.device));
         for (DevState& d : ctx->devs) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(root.comm_stream, d.snap_free, 0));
     } else {
-        // RCCL over xGMI: every rank sends its snapshot to rank 0, which posts one receive per rank; one group, so the 7 incoming
-        // transfers use 7 links at once.
+        // RCCL over xGMI: every other rank sends its snapshot to rank 0, which posts one receive per sender; one group, so the 7
+        // incoming transfers use 7 links at once.  Rank 0's own tile is a device copy, not a send to itself.
         RcclApi* api = rccl_api();
         if (!api) { set_err(ctx, "gather: cannot load RCCL: %s", rccl_why()); return RPT_ERR_RCCL; }
         RPT_RCCL_CHECK(ctx, api, api->GroupStart());
         for (DevState& d : ctx->devs) {
-            if (d.rank == 0)
-                for (uint32_t r = 0; r < world; ++r)
+            if (d.rank == 0) {
+                for (uint32_t r = 1; r < world; ++r)
                     RPT_RCCL_CHECK(ctx, api, api->Recv(ctx->gathered + (size_t)r * count, count, ncclFloat, (int)r, d.comm, d.comm_stream));
-            RPT_RCCL_CHECK(ctx, api, api->Send(d.snap, count, ncclFloat, 0, d.comm, d.comm_stream));
+            } else {
+                RPT_RCCL_CHECK(ctx, api, api->Send(d.snap, count, ncclFloat, 0, d.comm, d.comm_stream));
+            }
         }
         RPT_RCCL_CHECK(ctx, api, api->GroupEnd());
+        if (ctx->is_root()) {
+            RPT_HIP_CHECK(ctx, guard.to(root.device));
+            RPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->gathered, root.snap, count * 4u, hipMemcpyDeviceToDevice, root.comm_stream));
+        }
         for (DevState& d : ctx->devs) {
             RPT_HIP_CHECK(ctx, guard.to(d.device));
             RPT_HIP_CHECK(ctx, hipEventRecord(d.snap_free, d.comm_stream));

@@ -260,3 +260,25 @@ def test_bench_runs_the_multi_gpu_control_flow_on_one_gpu(rpt, torch_cuda):
     for key in ("weak_scaling", "strong_scaling", "configs4"):
         assert key in d and (d[key].get("value", 1) > 0), key
     assert "10k spheres" in d["configs4"]["workload"]
+
+
+def test_bench_keeps_its_line_when_a_secondary_leg_hangs(rpt, torch_cuda):
+    """The legs bench.py runs after the headline (weak scaling, the one-GPU frame, configs[4]) share the communicator with it; a rank
+    that stalls there must cost those legs, not the line: a timer emits it with what there is and every rank leaves with status 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env["RPT_BENCH_SECONDARY_LIMIT_S"] = "8"
+    env["RPT_BENCH_TEST_STALL"] = "1"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--small",
+                        "--smoke-shared-gpu"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "ONE JSON line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    assert d["secondary_legs"].startswith("cut off")
