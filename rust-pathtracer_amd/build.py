@@ -13,9 +13,13 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpt_hip.so")
-# (object, source): kernels.hip is built twice — the second time with relaxed arithmetic (RPT_RENDER_FAST_MATH); everything else is strict
-OBJECTS = [("kernels", "kernels.hip"), ("kernels_relaxed", "kernels.hip"), ("denoise", "denoise.hip"), ("capi", "capi.hip")]
+# (object, source): kernels.hip is built three times (its first lines say why); everything but kernels_relaxed is strict
+OBJECTS = [("kernels", "kernels.hip"), ("kernels_perop", "kernels.hip"), ("kernels_relaxed", "kernels.hip"), ("denoise", "denoise.hip"),
+           ("capi", "capi.hip")]
+AB_SKIP = {"kernels_perop"}                               # (an A/B build holds every kernel in its one strict object)
 EXTRA_FLAGS = {"kernels_relaxed": ["-DRPT_RELAXED_BUILD", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"],
+               # large and SDF scenes' kernels: the range tests of the short divide / sqrt next to every operation (kernels.hip, top)
+               "kernels_perop": ["-DRPT_PEROP_BUILD"],
                # the denoiser's taps are independent multiply / add sequences: packed f32 instructions halve their issue slots there
                # (the path kernels lose from SLP: it pins register pairs)
                "denoise": ["-fslp-vectorize"]}
@@ -82,6 +86,8 @@ def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="buil
     flags = BASE_FLAGS + _tuning_flags() + (["-DRPT_AB_KERNELS"] if ab else [])
     procs, objs = [], []
     for name, src in OBJECTS:                             # one object each, with its own flags, in parallel
+        if (ab or "-DRPT_GUARD_PER_OP" in extra_flags) and name in AB_SKIP:
+            continue
         obj = os.path.join(objdir, name + ".o")
         cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(name, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:

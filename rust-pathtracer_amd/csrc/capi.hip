@@ -568,7 +568,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         // look at the device's "anything left?" flag every 256 (kernels.hip, render_wavefront) — a wait that would keep the one
         // host thread of a multi-device context from feeding its other devices.  Such contexts take the megakernel for deep
         // bounds unless the caller insists.
-        const uint32_t chunk_spp = spp < rptlaunch::max_spp_per_launch() ? spp : rptlaunch::max_spp_per_launch();
+        const uint32_t chunk_spp = spp < rptlaunch::max_spp_per_launch(false) ? spp : rptlaunch::max_spp_per_launch(false);
         if (!forced && ctx->devs.size() > 1 && (uint64_t)chunk_spp * scl.max_depth + 1u > kWavefrontMaxBlindIterations) wavefront = false;
     }
     if (wavefront) {
@@ -633,7 +633,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         rp.sched_sync = d.sched + lay.sync();
     }
 
-    const uint32_t max_chunk = rptlaunch::max_spp_per_launch();
+    const uint32_t max_chunk = rptlaunch::max_spp_per_launch(!ctx->large && scs.sdf.n_prims > 0);
     if (unit_kernel) {
         // ONE launch whatever spp is: the LDS tables of the state-machine kernels hold a chunk's samples, and a launch is as many
         // chunks as it takes.

@@ -1,11 +1,18 @@
 // dev_bsdf.h — Disney principled BSDF of rust-pathtracer/src/tracer.rs:223-626 and
 // spherical-light sampling (tracer.rs:173-220), device side.  Operation order is
 // the reference's; see dev_math.h for why.
-#pragma once
+#include "dev_pass.h"
+#if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_BSDF_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_BSDF_H_NORMAL))
+#ifdef RPT_PLAIN_PASS
+#define RPT_DEV_BSDF_H_PLAIN
+#else
+#define RPT_DEV_BSDF_H_NORMAL
+#endif
 
 #include "dev_math.h"
 
-namespace rptdev {
+namespace RPT_NS {
+using namespace rptscene;
 
 // Material after Material::new() + patches + finalize() (material.rs:82-131).
 struct Mat {
@@ -465,4 +472,5 @@ RPT_DEV v3 disney_eval(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3 l
     return __builtin_fabsf(l.z) * f;
 }
 
-}  // namespace rptdev
+}  // namespace RPT_NS
+#endif  // this pass

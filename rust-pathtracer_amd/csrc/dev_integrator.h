@@ -1,12 +1,24 @@
 // dev_integrator.h — scene queries and the per-sample path of
 // rust-pathtracer/src/tracer.rs:33-117 for small analytical scenes (SceneSmall).
-#pragma once
+#include "dev_pass.h"
+#if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_INTEGRATOR_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_INTEGRATOR_H_NORMAL))
+#ifdef RPT_PLAIN_PASS
+#define RPT_DEV_INTEGRATOR_H_PLAIN
+#else
+#define RPT_DEV_INTEGRATOR_H_NORMAL
+#endif
 
 #include "dev_bsdf.h"
 #include "dev_media.h"
 #include "dev_scene.h"
 
-namespace rptdev {
+namespace RPT_NS {
+using namespace rptscene;
+
+// Defined in dev_scene_large.h.  Declared here because the templates below call them and nothing in their argument types (a scene of
+// namespace rptscene, an index) leads argument-dependent lookup to this namespace.
+RPT_DEV DevLight light_at(const SceneLarge& sc, uint32_t index);
+RPT_DEV DevMedium medium_at(const SceneLarge& sc, uint32_t index);
 
 struct RayD {
     v3 o, d;
@@ -937,15 +949,16 @@ RPT_DEV bool path_bounce(const S& sc, PathRegs& p)
     return path_shade_full(sc, DirectQuery{}, p, g);
 }
 
-// One pixel-sample start to end (the nested-loop form; kept for the A/B kernel).
-template <class S>
-RPT_DEV v3 trace_sample(const S& sc, float px, float py, FrameKey fkey, uint32_t pixel_index)
+// One pixel-sample start to end: the nested-loop kernel, and (namespace rptplain) what sample_guard recomputes a sample with.
+template <bool HASHED = false, class S>
+RPT_DEV v3 trace_sample(const S& sc, float px, float py, FrameKey fkey, uint32_t pixel_index, uint32_t pixel_b = 0u)
 {
     PathRegs p;
-    path_begin(sc, p, px, py, fkey, pixel_index);
+    path_begin<HASHED>(sc, p, px, py, fkey, pixel_index, pixel_b);
     if (sc.max_depth == 0) return p.radiance;
     while (!path_bounce(sc, p)) {}
     return p.radiance;
 }
 
-}  // namespace rptdev
+}  // namespace RPT_NS
+#endif  // this pass

@@ -5,17 +5,25 @@
 // -ffp-contract=off, f32 divide and sqrt are the correctly rounded expansions
 // (hipcc default, -fhip-fp32-correctly-rounded-divide-sqrt), and transcendental
 // functions come from include/rpt_strict_math.h.
-#pragma once
+#include "dev_pass.h"
+#if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_MATH_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_MATH_H_NORMAL))
+#ifdef RPT_PLAIN_PASS
+#define RPT_DEV_MATH_H_PLAIN
+#else
+#define RPT_DEV_MATH_H_NORMAL
+#endif
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/rpt_strict_math.h"
 #include "dev_prof.h"
+#include "dev_scene.h"
 
 #define RPT_DEV __device__ __forceinline__
 
-namespace rptdev {
+namespace RPT_NS {
+using namespace rptscene;
 
 // lib.rs:8-10
 constexpr float kPi = 3.14159265358979323846f;
@@ -36,57 +44,79 @@ RPT_DEV v3 operator/(v3 a, v3 b) { return v3{fdiv(a.x, b.x), fdiv(a.y, b.y), fdi
 RPT_DEV v3 operator*(float s, v3 a) { return v3{s * a.x, s * a.y, s * a.z}; }      // fx.rs:477 (f32 * F3)
 RPT_DEV v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }                        // fx.rs:509
 RPT_DEV v3 scale3(v3 a, float f) { return v3{a.x * f, a.y * f, a.z * f}; }         // F3::mult_f, fx.rs:346
-// ---- division ------------------------------------------------------------------------------------------------
+// ---- division and square root -----------------------------------------------------------------------------------
 // The reference divides (fx.rs:307-313: normalize is THREE divides by the length; F3 / F3 is component-wise), and results are
-// compared bit for bit, so every quotient here must be the correctly rounded one.  hipcc's expansion of `a / b` is a chain of ten
-// dependent instructions (v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup) and the megakernel is bound by exactly these
-// chains (profiles/NOTES.md).  The SHORT sequence below
+// compared bit for bit, so every quotient and every root here must be the correctly rounded one.  hipcc's expansion of `a / b` is a
+// chain of ten dependent instructions (v_div_scale x2, v_rcp, five fma, v_div_fmas, v_div_fixup), its sqrtf ~14 (scaling, v_sqrt,
+// both neighbours tested with an fma each, fix-ups), and the megakernels are bound by exactly these chains (profiles/NOTES.md).
+//
+// The SHORT sequences
 //     r0 = v_rcp_f32(d);  r = fma(fma(-d, r0, 1), r0, r0);  q0 = n * r;  q = fma(fma(-d, q0, n), r, q0);  v_div_fixup(q, d, n)
-// — one Newton step on the reciprocal, shared by every numerator of one denominator, and ONE Markstein correction of the quotient —
-// returns the correctly rounded quotient for EVERY pair of significands: tools/proofs/div_exhaustive.hip compares it with hipcc's
-// divide on all 2^23 x 2^23 pairs on gfx950 (7.0e13 quotients, 0 mismatches, 40 s of one MI355X; profiles/r3/proofs/).  Every step
-// commutes exactly with scaling by powers of two and with the operands' signs as long as no intermediate leaves the normal range:
-// |d|, |n| in [2^-61, 2^60) keeps r, q0, the residual (>= 2^-46 |n|) and q (2^-121 .. 2^121) normal.  Zeros, infinities and NaNs take
-// the short path too: v_div_fixup answers them without looking at q, exactly as it does at the end of hipcc's sequence (and supplies
-// IEEE's sign of a zero quotient).  Finite operands outside that range — denormals included — take hipcc's divide in the lanes
-// concerned (a wave vote: practically never taken).
-// v_frexp_exp_i32_f32: floor(log2 |x|) + 1 for finite non-zero x (denormals included), 0 for zero, infinity and NaN — which
-// therefore pass the range test and are answered by v_div_fixup exactly as they are at the end of hipcc's own sequence.
+//     s0 = v_sqrt_f32(x);  h = 0.5 * v_rsq_f32(x);  s = fma(fma(-s0, s0, x), h, s0)
+// — one Newton step on the reciprocal, shared by every numerator of one denominator, ONE Markstein correction of the quotient; one
+// correction of the root by its residual — return the correctly rounded result for EVERY significand: tools/proofs/div_exhaustive.hip
+// compares the quotient with hipcc's on all 2^23 x 2^23 pairs (7.0e13 quotients, 0 mismatches), tools/proofs/sqrt_exhaustive.hip the
+// root with hipcc's sqrtf on all 121 * 2^23 floats of [2^-60, 2^61) (0 mismatches; the variant with v_rcp_f32(s0) has 60), both on
+// gfx950 (profiles/r3/proofs/).  Every step commutes exactly with scaling by powers of two and with the operands' signs as long as no
+// intermediate leaves the normal range: |d|, |n| in [2^-61, 2^60) keeps r, q0, the residual (>= 2^-46 |n|) and q normal.  Zero and
+// NaN numerators, and NaN denominators, are answered by v_div_fixup without looking at q, exactly as at the end of hipcc's sequence
+// (it supplies IEEE's sign of a zero quotient too).  Outside the range the sequences are WRONG, so somebody has to look:
+//
+//   RPT_MATH_MODE 2 (the shipped strict kernels): the range tests are TRACKERS.  Every operation folds its operands into two words per
+//     lane in LDS with no-return DS min / max — no VALU result to wait for, no vote, no branch: the basic block goes on — and the kernel
+//     looks at them ONCE PER SAMPLE (guard_sample_ok); a sample that saw an operand outside the range is recomputed from its camera
+//     ray with the plain operations (namespace rptplain, dev_pass.h; kernels.hip sample_guard).  Per operation that is 2 VALU + 2 DS
+//     where the vote below costs 6 VALU, 3 scalar instructions and a branch that ends the scheduler's block: configs[1] 11.7 -> 12.6
+//     Gsamples/s (round 4; without any test at all: 13.3).
+//       lo_e  min of v_frexp_exp_i32_f32 over every numerator and every root's argument: floor(log2 |x|) + 1 for finite non-zero x
+//             (denormals included), 0 for zero, infinity and NaN, which therefore pass;           the sample is good if lo_e >= -59
+//       hi_u  max, as unsigned integers, of the bit patterns of max(|n|, |d|, |1/d|) of every divide (v_max3_f32 ignores a NaN
+//             operand; d = 0 and |d| <= 2^-60 show as a huge 1/d) and of every root's argument (a negative one, an infinity or a
+//             NaN reads as a huge integer);                                                          good if hi_u < bits(2^60)
+//     so inside a good sample every n is 0, NaN or in [2^-60, 2^60), every d NaN or in (2^-60, 2^60), every root's argument +0 or in
+//     [2^-60, 2^60): inside what the proofs cover.  (+0 under the root: the residual is 0 and 0.5 / sqrt(0) infinite; clamping the
+//     latter makes the product 0.  No root of the range has 0.5 rsq above 2^30.)
+//   RPT_MATH_MODE 1 (A/B builds, -DRPT_AB_KERNELS or -DRPT_GUARD_PER_OP: the forms whose paths change lanes or kernels): the test next
+//     to the operation, operands outside the range take hipcc's sequence in the lanes concerned behind a wave vote (rounds 3-4).
+//   RPT_MATH_MODE 0 (namespace rptplain; the relaxed build, where `/` and sqrtf are hipcc's fast ones): the plain operations.
+#undef RPT_MATH_MODE
+#if defined(RPT_PLAIN_PASS) || defined(RPT_RELAXED_BUILD) || defined(RPT_PLAIN_MATH)
+#define RPT_MATH_MODE 0
+#elif defined(RPT_AB_KERNELS) || defined(RPT_GUARD_PER_OP)
+#define RPT_MATH_MODE 1
+#else
+#define RPT_MATH_MODE 2
+#endif
+
+RPT_DEV int imin3(int a, int b, int c) { int m = a < b ? a : b; return m < c ? m : c; }
+RPT_DEV int imax3(int a, int b, int c) { int m = a > b ? a : b; return m > c ? m : c; }
 RPT_DEV int div_exp(float x) { return __builtin_amdgcn_frexp_expf(x); }
-RPT_DEV bool div_exps_ok(int lo, int hi) { return lo >= -60 && hi <= 60; }
-RPT_DEV float div_rcp(float d)                                      // the shared half: 1 / d to within what the correction needs
-{
-    const float r0 = __builtin_amdgcn_rcpf(d);
-    return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
-}
+RPT_DEV float div_refine(float d, float r0) { return __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0); }   // 1 / d to within what the correction needs
 RPT_DEV float div_with_rcp(float n, float d, float r)
 {
     const float q0 = n * r;
     return __builtin_amdgcn_div_fixupf(__builtin_fmaf(__builtin_fmaf(-d, q0, n), r, q0), d, n);
 }
-#ifdef RPT_PLAIN_DIVIDES                                            // A/B build: hipcc's divide everywhere
+
+#if RPT_MATH_MODE == 0
 RPT_DEV float fdiv(float n, float d) { return n / d; }
 RPT_DEV v3 divs3(v3 a, float d) { return v3{a.x / d, a.y / d, a.z / d}; }
 RPT_DEV v3 divs3_norm(v3 a, float len) { return divs3(a, len); }
-#else
-// (A single quotient gains nothing in instructions — 7 + 6 of guard against hipcc's 11 — only in chain depth: c2 is the same with
-// either form, the large-scene kernel 1 % faster with this one; profiles/r3/experiments/short_division.txt.)
+RPT_DEV float fsqrt(float x) { return __builtin_sqrtf(x); }
+#elif RPT_MATH_MODE == 1
+RPT_DEV bool div_exps_ok(int lo, int hi) { return lo >= -60 && hi <= 60; }
+// (A single quotient gains nothing in instructions — 7 + 6 of guard against hipcc's 11 — only in chain depth.)
 RPT_DEV float fdiv(float n, float d)
 {
-#ifdef RPT_SCALAR_DIVIDES_PLAIN
-    return n / d;
-#endif
-    float q = div_with_rcp(n, d, div_rcp(d));
+    float q = div_with_rcp(n, d, div_refine(d, __builtin_amdgcn_rcpf(d)));
     const int en = div_exp(n), ed = div_exp(d);
     const bool ok = div_exps_ok(en < ed ? en : ed, en < ed ? ed : en);
     if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) q = n / d; }
     return q;
 }
-RPT_DEV int imin3(int a, int b, int c) { int m = a < b ? a : b; return m < c ? m : c; }
-RPT_DEV int imax3(int a, int b, int c) { int m = a > b ? a : b; return m > c ? m : c; }
 RPT_DEV v3 divs3(v3 a, float d)                                     // a / F3::new_x(d): three quotients, one reciprocal
 {
-    const float r = div_rcp(d);
+    const float r = div_refine(d, __builtin_amdgcn_rcpf(d));
     v3 q = v3{div_with_rcp(a.x, d, r), div_with_rcp(a.y, d, r), div_with_rcp(a.z, d, r)};
     const int ex = div_exp(a.x), ey = div_exp(a.y), ez = div_exp(a.z), ed = div_exp(d);
     const bool ok = div_exps_ok(imin3(ex, ey, ez), imax3(ex, ey, ez)) && div_exps_ok(ed, ed);
@@ -96,25 +126,13 @@ RPT_DEV v3 divs3(v3 a, float d)                                     // a / F3::n
 // normalize: the numerators cannot exceed the length, which spares the upper test
 RPT_DEV v3 divs3_norm(v3 a, float len)
 {
-    const float r = div_rcp(len);
+    const float r = div_refine(len, __builtin_amdgcn_rcpf(len));
     v3 q = v3{div_with_rcp(a.x, len, r), div_with_rcp(a.y, len, r), div_with_rcp(a.z, len, r)};
     const int ed = div_exp(len);
     const bool ok = div_exps_ok(imin3(div_exp(a.x), div_exp(a.y), div_exp(a.z)), 0) && div_exps_ok(ed, ed);
     if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) q = v3{a.x / len, a.y / len, a.z / len}; }
     return q;
 }
-#endif
-
-// ---- square root ---------------------------------------------------------------------------------------------
-// The same idea for f32::sqrt.  hipcc's correctly rounded sqrtf scales tiny arguments, takes v_sqrt_f32 (1 ulp), tests both neighbours
-// with an fma each and fixes zeros / infinities up: ~14 instructions, ~9 deep.  Inside [2^-60, 2^61)
-//     s0 = v_sqrt_f32(x);  h = 0.5 * v_rsq_f32(x);  s = fma(fma(-s0, s0, x), h, s0)
-// — one correction by the residual — is the correctly rounded root for EVERY input: tools/proofs/sqrt_exhaustive.hip compares it
-// with hipcc's sqrtf on all 121 * 2^23 floats of that range on gfx950 (0 mismatches; the variant with v_rcp_f32(s0) has 60).  Everything
-// else — zeros, negatives, infinities, NaNs, denormals, the far ends of the range — takes hipcc's sqrtf in the lanes concerned.
-#ifdef RPT_PLAIN_SQRT                                               // A/B build
-RPT_DEV float fsqrt(float x) { return __builtin_sqrtf(x); }
-#else
 RPT_DEV float fsqrt(float x)
 {
     const float s0 = __builtin_amdgcn_sqrtf(x);
@@ -122,6 +140,60 @@ RPT_DEV float fsqrt(float x)
     const bool ok = ((rpt_f2u(x) >> 23) - 67u) <= 120u;             // positive, 2^-60 <= x < 2^61
     if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) s = __builtin_sqrtf(x); }
     return s;
+}
+#else
+struct GuardCell {
+    int lo_e;
+    uint32_t hi_u;
+};
+__shared__ GuardCell g_guard[256];                                  // (2 KB of the workgroup's LDS in every kernel that divides)
+constexpr int kGuardLoE = -59;
+constexpr uint32_t kGuardHiU = 0x5D800000u;                         // bits(2^60)
+RPT_DEV void guard_note(int e, float hi)
+{
+    (void)__hip_atomic_fetch_min(&g_guard[threadIdx.x].lo_e, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    (void)__hip_atomic_fetch_max(&g_guard[threadIdx.x].hi_u, rpt_f2u(hi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+RPT_DEV GuardCell guard_clean() { return GuardCell{0, 0u}; }
+RPT_DEV void guard_reset() { g_guard[threadIdx.x] = guard_clean(); }
+RPT_DEV bool guard_cell_ok(GuardCell c) { return c.lo_e >= kGuardLoE && c.hi_u < kGuardHiU; }
+RPT_DEV bool guard_sample_ok() { return guard_cell_ok(g_guard[threadIdx.x]); }
+// a path that changes lanes (the compacting kernel) carries its trackers along: fold the lane's into `c`, leave the lane's clean
+RPT_DEV void guard_take(GuardCell& c)
+{
+    const GuardCell l = g_guard[threadIdx.x];
+    c.lo_e = l.lo_e < c.lo_e ? l.lo_e : c.lo_e;
+    c.hi_u = l.hi_u > c.hi_u ? l.hi_u : c.hi_u;
+    guard_reset();
+}
+RPT_DEV float fmax3abs(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)); }
+RPT_DEV float fdiv(float n, float d)
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    guard_note(div_exp(n), fmax3abs(n, d, r0));
+    return div_with_rcp(n, d, div_refine(d, r0));
+}
+RPT_DEV v3 divs3(v3 a, float d)                                     // a / F3::new_x(d): three quotients, one reciprocal
+{
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    guard_note(imin3(div_exp(a.x), div_exp(a.y), div_exp(a.z)), fmax3abs(fmax3abs(a.x, a.y, a.z), d, r0));
+    const float r = div_refine(d, r0);
+    return v3{div_with_rcp(a.x, d, r), div_with_rcp(a.y, d, r), div_with_rcp(a.z, d, r)};
+}
+// normalize (`len` = len3(a)): |a.i| >= 2^60 makes the sum of squares >= 2^120 and its root >= 2^60: the numerators need no upper test
+RPT_DEV v3 divs3_norm(v3 a, float len)
+{
+    const float r0 = __builtin_amdgcn_rcpf(len);
+    guard_note(imin3(div_exp(a.x), div_exp(a.y), div_exp(a.z)), __builtin_fmaxf(__builtin_fabsf(len), __builtin_fabsf(r0)));
+    const float r = div_refine(len, r0);
+    return v3{div_with_rcp(a.x, len, r), div_with_rcp(a.y, len, r), div_with_rcp(a.z, len, r)};
+}
+RPT_DEV float fsqrt(float x)
+{
+    const float s0 = __builtin_amdgcn_sqrtf(x);
+    const float h = __builtin_fminf(0.5f * __builtin_amdgcn_rsqf(x), 1.0e30f);
+    guard_note(div_exp(x), x);
+    return __builtin_fmaf(__builtin_fmaf(-s0, s0, x), h, s0);
 }
 #endif
 
@@ -176,30 +248,6 @@ RPT_DEV uint32_t pcg_hash(uint32_t v)
     uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
     return (word >> 22u) ^ word;
 }
-__host__ __device__ inline uint32_t pcg_hash_hd(uint32_t v)
-{
-    uint32_t state = v * 747796405u + 2891336453u;
-    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
-    return (word >> 22u) ^ word;
-}
-// (seed, frame) -> two independently folded words: 64 bits of key per frame
-struct FrameKey {
-    uint32_t k0, k1;
-};
-__host__ __device__ inline FrameKey frame_key_hd(uint64_t seed, uint64_t frame)
-{
-    FrameKey fk;
-    uint32_t k = pcg_hash_hd((uint32_t)(seed >> 32));
-    k = pcg_hash_hd(k ^ (uint32_t)seed);
-    k = pcg_hash_hd(k ^ (uint32_t)(frame >> 32));
-    fk.k0 = pcg_hash_hd(k ^ (uint32_t)frame);
-    uint32_t j = pcg_hash_hd((uint32_t)(seed >> 32) ^ 0x85EBCA6Bu);
-    j = pcg_hash_hd(j ^ (uint32_t)seed);
-    j = pcg_hash_hd(j ^ (uint32_t)(frame >> 32));
-    fk.k1 = pcg_hash_hd(j ^ (uint32_t)frame);
-    return fk;
-}
-
 struct Rng {
     uint32_t state;
     uint32_t inc;              // odd: the stream
@@ -231,4 +279,5 @@ RPT_DEV uint32_t rng_draws_between(Rng from, const Rng& to, uint32_t limit = 64u
     return n;
 }
 
-}  // namespace rptdev
+}  // namespace RPT_NS
+#endif  // this pass

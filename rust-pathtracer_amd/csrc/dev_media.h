@@ -5,12 +5,19 @@
 // oracle/rpt_oracle.hpp (Tracer::phase_hg, sample_hg, medium_transmittance, the media branches of sample_pixel and
 // direct_light); these functions restate it operation for operation and are compared with it bit for bit.
 // Only kernels instantiated for WithMedia<Scene> (dev_scene.h) contain any of this.
-#pragma once
+#include "dev_pass.h"
+#if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_MEDIA_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_MEDIA_H_NORMAL))
+#ifdef RPT_PLAIN_PASS
+#define RPT_DEV_MEDIA_H_PLAIN
+#else
+#define RPT_DEV_MEDIA_H_NORMAL
+#endif
 
 #include "dev_bsdf.h"
 #include "dev_scene.h"
 
-namespace rptdev {
+namespace RPT_NS {
+using namespace rptscene;
 
 struct DevMedium {
     uint32_t type;             // RPT_MEDIUM_*
@@ -78,4 +85,5 @@ RPT_DEV DevMedium medium_of(const DevMaterial& m)
                      clampf(m.medium_anisotropy, -0.9f, 0.9f)};
 }
 
-}  // namespace rptdev
+}  // namespace RPT_NS
+#endif  // this pass

@@ -8,6 +8,7 @@
 // scene").  Larger scenes use the LDS-tiled path (dev_scene_large.h).
 #pragma once
 
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "../../include/rpt.h"
@@ -17,7 +18,11 @@
 #define RPT_CONST_AS __attribute__((address_space(4)))
 #endif
 
-namespace rptdev {
+// The TYPES kernels and host share live in `rptscene`, a namespace without functions over them: the device functions (dev_math.h ...
+// dev_scene_large.h) are compiled twice into one kernel — `rptdev` with the short guarded divide / square root and `rptplain` with
+// hipcc's own (dev_pass.h) — and with no function here argument-dependent lookup cannot mix the two.  `rptdev` sees these names
+// through a using-directive, so `rptdev::SceneSmall` stays what it was.
+namespace rptscene {
 
 constexpr int kMaxSpheres = 8;
 constexpr int kMaxPlanes = 4;
@@ -129,6 +134,68 @@ struct WithMedia : Base {
     explicit WithMedia(const Base& b) : Base(b) {}
 };
 
+// Large scenes (dev_scene_large.h): the tables stay in global memory, the kernel argument holds pointers.
+struct SceneLarge {
+    static constexpr bool kMedia = false;                          // dev_scene.h, WithMedia
+    uint32_t n_spheres, n_planes, n_lights, n_materials;
+    uint32_t flags, max_depth;
+    float eps;
+    float n_lights_f;
+    DevCamera cam;
+    DevBackground bg;
+    const float4* spheres;            // xyz = centre, w = radius
+    const uint32_t* sphere_material;
+    const DevLight* lights;
+    const DevMaterial* materials;
+    DevPlane planes[kMaxPlanes];
+    // Uniform grid over the spheres (built on the host at upload, host_scene.h build_grid):
+    // cell (ix,iy,iz) -> items[cell_start[c] .. cell_start[c+1]) = indices of the spheres whose
+    // padded bounding box overlaps the cell, ascending.  use_accel == 0: brute-force streaming.
+    uint32_t use_accel;
+    uint32_t gn[3];
+    float gmin[3], gmax[3], cell_size[3], inv_cell_size[3];
+    float gcenter[3];
+    float safe_r2;                    // rays starting farther than sqrt(safe_r2) from gcenter use the brute-force loop
+    float near_r2;                    // rays starting within sqrt(near_r2) of gcenter use the second tier of cell lists (less padding:
+    uint32_t near_cell_off;           // shorter), cell_start[near_cell_off + c]; near_r2 < 0: there is none
+    const uint32_t* cell_start;
+    const uint32_t* cell_items;
+    const float4* cell_spheres;       // spheres[cell_items[k]] stored at k: a cell's spheres are one dependent load away, not two
+    uint32_t n_oversize;              // spheres kept out of the grid (far larger than the rest: host_scene.h), tested by every walk
+    const uint32_t* oversize;
+    // Scene::sample_lights' loop (closest_geom_finish): the spherical lights as {centre, radius} in index order, in whole groups of
+    // four, with their indices into `lights`; n_light_spheres == 0xFFFFFFFF: the scene has a light of another kind that acts (a
+    // rectangular one under RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES): the loop over `lights` itself runs
+    const float4* light_spheres;
+    const uint32_t* light_sphere_ids;
+    uint32_t n_light_spheres;
+};
+
+// (seed, frame) -> the key of a frame's random streams (dev_math.h, Rng): host and device
+__host__ __device__ inline uint32_t pcg_hash_hd(uint32_t v)
+{
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+// (seed, frame) -> two independently folded words: 64 bits of key per frame
+struct FrameKey {
+    uint32_t k0, k1;
+};
+__host__ __device__ inline FrameKey frame_key_hd(uint64_t seed, uint64_t frame)
+{
+    FrameKey fk;
+    uint32_t k = pcg_hash_hd((uint32_t)(seed >> 32));
+    k = pcg_hash_hd(k ^ (uint32_t)seed);
+    k = pcg_hash_hd(k ^ (uint32_t)(frame >> 32));
+    fk.k0 = pcg_hash_hd(k ^ (uint32_t)frame);
+    uint32_t j = pcg_hash_hd((uint32_t)(seed >> 32) ^ 0x85EBCA6Bu);
+    j = pcg_hash_hd(j ^ (uint32_t)seed);
+    j = pcg_hash_hd(j ^ (uint32_t)(frame >> 32));
+    fk.k1 = pcg_hash_hd(j ^ (uint32_t)frame);
+    return fk;
+}
+
 // One launch's worth of render parameters.
 struct RenderParams {
     float* pixels;             // this rank's tile buffer, rows_local * width RGBA f32
@@ -166,4 +233,7 @@ struct RenderParams {
     uint32_t* tile_start;          // development (tools/dispatch_timeline.py): each wave's start stamp, like tile_cost; NULL: not recorded
 };
 
-}  // namespace rptdev
+}  // namespace rptscene
+
+namespace rptdev { using namespace rptscene; }
+namespace rptplain { using namespace rptscene; }

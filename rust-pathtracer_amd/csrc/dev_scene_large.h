@@ -14,48 +14,19 @@
 // patches the ordered-acceptance rule of analytical.rs:36-120 reduces to "the last accepted
 // sphere's material", i.e. the nearest sphere's (first index on ties), so the result is still
 // exactly what the ordered loop gives.  Plane materials stay arbitrary patches.
-#pragma once
+#include "dev_pass.h"
+#if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_SCENE_LARGE_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_SCENE_LARGE_H_NORMAL))
+#ifdef RPT_PLAIN_PASS
+#define RPT_DEV_SCENE_LARGE_H_PLAIN
+#else
+#define RPT_DEV_SCENE_LARGE_H_NORMAL
+#endif
 
 #include "dev_integrator.h"
 
-namespace rptdev {
+namespace RPT_NS {
+using namespace rptscene;
 
-
-struct SceneLarge {
-    static constexpr bool kMedia = false;                          // dev_scene.h, WithMedia
-    uint32_t n_spheres, n_planes, n_lights, n_materials;
-    uint32_t flags, max_depth;
-    float eps;
-    float n_lights_f;
-    DevCamera cam;
-    DevBackground bg;
-    const float4* spheres;            // xyz = centre, w = radius
-    const uint32_t* sphere_material;
-    const DevLight* lights;
-    const DevMaterial* materials;
-    DevPlane planes[kMaxPlanes];
-    // Uniform grid over the spheres (built on the host at upload, host_scene.h build_grid):
-    // cell (ix,iy,iz) -> items[cell_start[c] .. cell_start[c+1]) = indices of the spheres whose
-    // padded bounding box overlaps the cell, ascending.  use_accel == 0: brute-force streaming.
-    uint32_t use_accel;
-    uint32_t gn[3];
-    float gmin[3], gmax[3], cell_size[3], inv_cell_size[3];
-    float gcenter[3];
-    float safe_r2;                    // rays starting farther than sqrt(safe_r2) from gcenter use the brute-force loop
-    float near_r2;                    // rays starting within sqrt(near_r2) of gcenter use the second tier of cell lists (less padding:
-    uint32_t near_cell_off;           // shorter), cell_start[near_cell_off + c]; near_r2 < 0: there is none
-    const uint32_t* cell_start;
-    const uint32_t* cell_items;
-    const float4* cell_spheres;       // spheres[cell_items[k]] stored at k: a cell's spheres are one dependent load away, not two
-    uint32_t n_oversize;              // spheres kept out of the grid (far larger than the rest: host_scene.h), tested by every walk
-    const uint32_t* oversize;
-    // Scene::sample_lights' loop (closest_geom_finish): the spherical lights as {centre, radius} in index order, in whole groups of
-    // four, with their indices into `lights`; n_light_spheres == 0xFFFFFFFF: the scene has a light of another kind that acts (a
-    // rectangular one under RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES): the loop over `lights` itself runs
-    const float4* light_spheres;
-    const uint32_t* light_sphere_ids;
-    uint32_t n_light_spheres;
-};
 
 // Wave-uniform table reads: plain dwords through the constant address space, which the
 // compiler merges into s_load_dwordx4/x8.
@@ -667,4 +638,5 @@ RPT_DEV bool any_hit(const SceneLarge& sc, const RayD& ray, float max_dist)
     return occluded;
 }
 
-}  // namespace rptdev
+}  // namespace RPT_NS
+#endif  // this pass

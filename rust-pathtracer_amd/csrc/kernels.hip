@@ -3,6 +3,39 @@
 //
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-licm -mllvm -amdgpu-sched-strategy=max-ilp
 // (build.py).  There is NO CPU fallback anywhere in this library.
+// build.py compiles this file three times for the shipped library:
+//   as is                   small scenes' megakernel (+ the nested-loop baseline, untile, conversions, probes): strict arithmetic (-ffp-contract=off, correctly rounded
+//                           divide / sqrt), the short sequences' range tests TRACKED (dev_math.h, RPT_MATH_MODE 2)
+//   -DRPT_PEROP_BUILD       large scenes', SDF scenes' and the compacting kernel: strict arithmetic, the range tests next to every operation
+//                           (RPT_MATH_MODE 1) — their walks and marches wait for scalar loads at every step, and such a wait (lgkmcnt)
+//                           also waits for the trackers' LDS operations: configs[3] 3 149 against 2 961 Msamples/s, configs[4] 2 898
+//                           against 2 822 (round 4; profiles/r4/experiments/range_trackers.txt)
+//   -DRPT_RELAXED_BUILD     with -fno-hip-fp32-correctly-rounded-divide-sqrt -ffp-contract=fast (v_rcp / v_rsq based divide and sqrt,
+//                           ~2.5 ulp, fused multiply-adds): what RPT_RENDER_FAST_MATH selects.  NOT bit-identical to the reference
+//                           arithmetic — an ulp now and then flips a branch and changes a sample by O(1) — so that mode is validated
+//                           statistically (tests/test_gpu_parity.py::test_fast_math_mode_is_statistically_equivalent) and never what
+//                           bench.py measures.
+// each under its own kernel-name suffix and launch namespace — and once, with every form, for A/B builds (-DRPT_AB_KERNELS:
+// RPT_MATH_MODE 1 throughout).
+#if defined(RPT_RELAXED_BUILD)
+#define RPT_RENDER_KERNELS_ONLY       // untile, the u8 conversions and the test probes have no relaxed form
+#define RPT_NO_MEDIA_KERNELS          // nor have scenes with participating media (RPT_ERR_UNSUPPORTED)
+#define RPT_K(name) name##_fast
+#define RPT_LAUNCH_NS rptlaunch_fast
+#elif defined(RPT_PEROP_BUILD)
+#define RPT_GUARD_PER_OP
+#define RPT_RENDER_KERNELS_ONLY
+#define RPT_NO_SMALL_KERNELS          // (small scenes' megakernel and nested-loop kernel: the default object)
+#define RPT_K(name) name##_perop
+#define RPT_LAUNCH_NS rptlaunch_perop
+#else
+#if !defined(RPT_AB_KERNELS) && !defined(RPT_GUARD_PER_OP)
+#define RPT_NO_LARGE_SDF_KERNELS      // (they come from the RPT_PEROP_BUILD object,
+#define RPT_NO_COMPACT_KERNELS        //  and so does the compacting kernel of one-sample launches)
+#endif
+#define RPT_K(name) name
+#define RPT_LAUNCH_NS rptlaunch
+#endif
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -15,20 +48,25 @@
 #include "ab/dev_sdf_pool.h"
 #endif
 #include "launch.h"
-
-// build.py compiles this file twice: as is (strict arithmetic: -ffp-contract=off, correctly rounded divide/sqrt) and with
-// -DRPT_RELAXED_BUILD -fno-hip-fp32-correctly-rounded-divide-sqrt -ffp-contract=fast (v_rcp / v_rsq based divide and sqrt, ~2.5 ulp,
-// and fused multiply-adds) under suffixed kernel names.  The relaxed kernels are what RPT_RENDER_FAST_MATH selects; they are NOT
-// bit-identical to the reference arithmetic — an ulp now and then flips a branch and changes a sample by O(1) — so that mode is
-// validated statistically (tests/test_gpu_parity.py::test_fast_math_mode_is_statistically_equivalent) and never what bench.py measures.
-#ifdef RPT_RELAXED_BUILD
-#define RPT_RENDER_KERNELS_ONLY       // untile, the u8 conversions and the test probes have no relaxed form
-#define RPT_NO_MEDIA_KERNELS          // nor have scenes with participating media (RPT_ERR_UNSUPPORTED)
-#define RPT_K(name) name##_fast
-#define RPT_LAUNCH_NS rptlaunch_fast
-#else
-#define RPT_K(name) name
-#define RPT_LAUNCH_NS rptlaunch
+#ifndef RPT_RENDER_KERNELS_ONLY
+#include "dev_probes.h"
+#endif
+#if RPT_MATH_MODE == 2
+// The device functions a second time, over hipcc's own divide and sqrtf (namespace rptplain, dev_pass.h): what sample_guard
+// recomputes a sample with.  (The block profiler's scopes stay in the normal pass.)
+#define RPT_PLAIN_PASS
+#pragma push_macro("RPT_PROF")
+#undef RPT_PROF
+#define RPT_PROF(id) do { } while (0)
+#include "dev_scene_large.h"
+#ifndef RPT_RENDER_KERNELS_ONLY
+#include "dev_probes.h"
+#endif
+#pragma pop_macro("RPT_PROF")
+#undef RPT_PLAIN_PASS
+#include "dev_pass.h"
+#undef RPT_MATH_MODE
+#define RPT_MATH_MODE 2
 #endif
 
 using namespace rptdev;
@@ -192,6 +230,35 @@ RPT_DEV void blend(float4& acc, v3 rad, float v)
     acc.w = (1.0f - v) * acc.w + 1.0f * v;
 }
 
+// A sample is over (its radiance complete, not yet blended): under RPT_MATH_MODE 2 the short divide / square-root sequences did not
+// test their operands, they tracked them (dev_math.h).  If this lane's trackers left the range since the last look, what it computed
+// may be off by an ulp somewhere: the sample is computed again from its camera ray with the plain operations — the same draws (the
+// stream is keyed by pixel and frame), the same arithmetic in hipcc's own divide and sqrtf — and the trackers start clean.  A vote,
+// because the second computation is long and practically never needed (configs[1]: about 1 sample in 10^6, a root of exactly -0 or
+// a quotient of an infinity).  HASHED as in path_begin.
+template <bool HASHED, class S>
+RPT_DEV void sample_guard(const S& sc, v3& radiance, float px, float py, FrameKey fkey, uint32_t pixel, uint32_t pixel_b = 0u)
+{
+#if RPT_MATH_MODE == 2
+    const bool ok = guard_sample_ok();
+    if (__builtin_expect(__ballot(!ok) != 0ull, 0)) {
+        if (!ok) {
+            const rptplain::v3 r = rptplain::trace_sample<HASHED>(sc, px, py, fkey, pixel, pixel_b);
+            radiance = mk3(r.x, r.y, r.z);
+            guard_reset();
+        }
+    }
+#else
+    (void)sc; (void)radiance; (void)px; (void)py; (void)fkey; (void)pixel; (void)pixel_b;
+#endif
+}
+RPT_DEV void sample_guard_begin()                                   // once per lane before its first sample
+{
+#if RPT_MATH_MODE == 2
+    guard_reset();
+#endif
+}
+
 // Megakernel, one thread per pixel, `spp` samples per launch, nested-loop form
 // (sample loop outside, bounce loop inside; lanes whose path ended idle until the
 // wave's longest path ends).  Kept as the A/B baseline for the regenerating kernel.
@@ -208,11 +275,13 @@ RPT_DEV void render_nested_body(const S& sc, const RenderParams& launch)
     if (!ps.valid) return;
     float4* pix = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
     float4 acc = *pix;
+    sample_guard_begin();
     for (uint32_t s = 0; s < rp.spp; ++s) {
         const uint64_t frames = rp.frames_done + s;
         const FrameKey fkey = frame_key_hd(rp.seed, frames);
         const float v = 1.0f / (float)(frames + 1);                 // tracer.rs:115
-        const v3 rad = trace_sample(sc, ps.px, ps.py, fkey, ps.pixel_index);
+        v3 rad = trace_sample(sc, ps.px, ps.py, fkey, ps.pixel_index);
+        sample_guard<false>(sc, rad, ps.px, ps.py, fkey, ps.pixel_index);
         blend(acc, rad, v);
     }
     *pix = acc;
@@ -239,7 +308,9 @@ RPT_DEV const S& kernarg_scene(const S& by_value) { return by_value; }
 
 // The shipped library holds ONE nested-loop kernel, the baseline of the reference's own scene class; the other scene classes' only
 // in A/B builds (-DRPT_AB_KERNELS, build.py --ab), where the parity tests run every form against the oracle.
+#ifndef RPT_NO_SMALL_KERNELS
 __global__ __launch_bounds__(256) void RPT_K(render_small_nested_kernel)(const SceneSmall sc, const RenderParams rp) { render_nested_body(kernarg_scene(sc), rp); }
+#endif
 #ifdef RPT_AB_KERNELS
 __global__ __launch_bounds__(256) void RPT_K(render_large_nested_kernel)(const SceneLarge sc, const RenderParams rp) { render_nested_body(kernarg_scene(sc), rp); }
 __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_nested_body(kernarg_scene(sc), rp); }
@@ -266,6 +337,9 @@ __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_media_kernel)(con
 #define RPT_MAX_SPP_PER_LAUNCH 512
 #endif
 constexpr uint32_t kMaxSppPerLaunch = RPT_MAX_SPP_PER_LAUNCH;
+// ... of the SDF march kernel: its workgroup also parks three float4 per lane, and with the range trackers' 2 KB (dev_math.h) 512
+// entries would put it 24 bytes over the 32 KB that let five workgroups share a CU's LDS
+constexpr uint32_t kMaxSppPerLaunchSdf = RPT_MAX_SPP_PER_LAUNCH < 480 ? RPT_MAX_SPP_PER_LAUNCH : 480;
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd argument of
 // __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
@@ -319,6 +393,7 @@ RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderPa
     lt.acc[threadIdx.x] = *pixel;
     const uint32_t pix_a = pcg_hash(ps.pixel_index);
     lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(pix_a), rpt_u2f(pcg_hash(pix_a)));
+    sample_guard_begin();
     return true;
 }
 
@@ -383,6 +458,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch)
             }
             RPT_PROF(PB_FINISH);
             float4 acc = s_acc[tid];
+            { const float4 c = s_pix[tid]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
             blend(acc, p.radiance, s_weight[s]);
             s_acc[tid] = acc;
             s += 1;
@@ -432,6 +508,7 @@ RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& launch)
             // the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
             RPT_PROF(PB_FINISH);
             float4 acc = s_acc[tid];
+            { const float4 c = s_pix[tid]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
             blend(acc, p.radiance, s_weight[s]);
             s_acc[tid] = acc;
             s += 1;
@@ -476,7 +553,9 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
     render_regen_body(s_scene, rp);
 }
 #else
+#ifndef RPT_NO_SMALL_KERNELS
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(kernarg_scene(sc), rp); }
+#endif
 #endif
 // Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).  5 waves per SIMD: 96 VGPRs, 12 of them
 // spilled (44 B of scratch per lane).  With the two tiers of cell lists 5 / 6 / 7 waves run at 1 881 / 1 874 / 1 858 Msamples/s (10 k
@@ -486,14 +565,20 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 #ifndef RPT_LARGE_WAVES_PER_SIMD
 #define RPT_LARGE_WAVES_PER_SIMD 5
 #endif
+#ifndef RPT_NO_LARGE_SDF_KERNELS
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_kernel)(const SceneLarge sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
+#endif
 #ifdef RPT_AB_KERNELS
 // Small scenes with the procedural SDF object, the sphere march inside closest_hit / any_hit (RPT_RENDER_SDF_INLINE_MARCH): A/B builds.
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_regen_body_tf(kernarg_scene(sc), rp); }
 #endif
 #ifndef RPT_NO_MEDIA_KERNELS
+#ifndef RPT_NO_SMALL_KERNELS
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_regen_body(kernarg_scene(sc), rp); }
+#endif
+#ifndef RPT_NO_LARGE_SDF_KERNELS
 __global__ __launch_bounds__(256, RPT_LARGE_WAVES_PER_SIMD) void RPT_K(render_large_regen_media_kernel)(const WithMedia<SceneLarge> sc, const RenderParams rp) { render_regen_body_tf(sc, rp); }
+#endif
 #ifdef RPT_AB_KERNELS
 __global__ __launch_bounds__(256, RPT_WAVES_PER_SIMD) void RPT_K(render_sdf_regen_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_regen_body_tf(kernarg_scene(sc), rp); }
 #endif
@@ -800,7 +885,10 @@ __global__ __launch_bounds__(256, RPT_WF_SHADE_WAVES_PER_SIMD) void RPT_K(wf_sha
 //                                                                   surface -> S
 //   SHADE  thread t < |S|: entry t of the shade list: material, light sample, BSDF; path over -> blend, next sample -> next T;
 //                                                                   otherwise -> next T
-// Same device functions, same per-pixel order of samples: bit-identical to the other kernels.
+// Same device functions, same per-pixel order of samples: bit-identical to the other kernels.  Built in the RPT_PEROP_BUILD object: its
+// paths change lanes between stages, range trackers would have to travel with them, and its stages are bound by their barriers, not by
+// instruction issue (1080p x 1 spp 0.277 ms with trackers carried in the path records, 0.2755 with the tests per operation; 800x600
+// 0.0852 against 0.0808).
 #ifndef RPT_COMPACT_WAVES_PER_SIMD
 #define RPT_COMPACT_WAVES_PER_SIMD 5
 #endif
@@ -911,14 +999,20 @@ RPT_DEV void render_compact_body(const S& sc, const RenderParams& launch)
     if (rp.tile_cost && (tid & 63u) == 0u) rp.tile_cost[block_tile(rp) * 4u + (tid >> 6)] = cost_clock() - t0;
 }
 
+#ifndef RPT_NO_COMPACT_KERNELS
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
+#endif
 // Frames of a few thousand workgroups (the reference's 800x600 window: 1 875) are a question of how many ROUNDS of workgroups the
 // chip needs: six resident per CU make that 1.2 instead of 1.5 rounds.  The price is 80 VGPRs, 35 of the kernel's ~100 live values
 // in scratch (116 B per lane, L1/L2-resident at this launch size) — and it is worth it: 800x600 x 1 spp 0.0809 ms against 0.0914
 // with five per CU and no spill to speak of (round 4, tools/compact_time.py); from 1080p up the five-per-CU build is 1 % faster.
+#ifndef RPT_NO_COMPACT_KERNELS
 __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
+#endif
 #ifndef RPT_NO_MEDIA_KERNELS
+#ifndef RPT_NO_COMPACT_KERNELS
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
+#endif
 #endif
 
 #ifdef RPT_AB_KERNELS
@@ -1057,8 +1151,8 @@ template <class S>
 RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch)
 {
     RPT_PROF_INIT();
-    __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
-    __shared__ float s_weight[kMaxSppPerLaunch];
+    __shared__ FrameKey s_fkey[kMaxSppPerLaunchSdf];
+    __shared__ float s_weight[kMaxSppPerLaunchSdf];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
 #ifdef RPT_SDF_PRIMS_IN_LDS
@@ -1175,6 +1269,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch)
             if (over && !pending) {                                 // blend, next sample of the pixel (or retire)
                 RPT_PROF(PB_FINISH);
                 float4 acc = s_acc[tid];
+                { const float4 c = s_pix[tid]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
                 blend(acc, p.radiance, s_weight[s]);
                 s_acc[tid] = acc;
                 s += 1;
@@ -1208,10 +1303,14 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch)
     lane_finish(rp, s_acc[tid]);
 }
 
+#ifndef RPT_NO_LARGE_SDF_KERNELS
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) 
 void RPT_K(render_sdf_march2_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body(kernarg_scene(sc), rp); }
+#endif
 #ifndef RPT_NO_MEDIA_KERNELS
+#ifndef RPT_NO_LARGE_SDF_KERNELS
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march2_body(kernarg_scene(sc), rp); }
+#endif
 #endif
 
 #ifdef RPT_AB_KERNELS
@@ -1479,50 +1578,38 @@ __global__ __launch_bounds__(256) void RPT_K(convert_to_u8_at_kernel)(const floa
     }
 }
 
+// The test probes (dev_probes.h holds the bodies).  RPT_MATH_MODE 2: like a sample of the render kernels, a record whose operands left
+// the range of the short sequences is computed again with the plain operations.
+RPT_DEV bool probe_begin()
+{
+#if RPT_MATH_MODE == 2
+    guard_reset();
+#endif
+    return true;
+}
+RPT_DEV bool probe_redo()
+{
+#if RPT_MATH_MODE == 2
+    return !guard_sample_ok();
+#else
+    return false;
+#endif
+}
+#if RPT_MATH_MODE == 2
+#define RPT_PROBE_PLAIN(call) rptplain::call
+#else
+#define RPT_PROBE_PLAIN(call) call
+#endif
+
 __global__ __launch_bounds__(256) void RPT_K(probe_math_kernel)(uint32_t fn, const float* __restrict__ a, const float* __restrict__ b,
                                                          float* __restrict__ out, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float r = 0.0f;
-    switch (fn) {
-    case RPT_PROBE_SIN: r = rpt_sinf(a[i]); break;
-    case RPT_PROBE_COS: r = rpt_cosf(a[i]); break;
-    case RPT_PROBE_LOG2: r = rpt_log2f(a[i]); break;
-    case RPT_PROBE_POW: r = rpt_powf(a[i], b[i]); break;
-    case RPT_PROBE_DIV: r = fdiv(a[i], b[i]); break;                 // the library's divide (dev_math.h), not hipcc's
-    case RPT_PROBE_DIV3: {                                            // three quotients by one denominator: divs3 / normalize's form
-        const v3 q = (i & 4u) ? divs3_norm(mk3(a[i], 0.5f * b[i], 0.0f), b[i]) : divs3(mk3(a[i], -b[i], 0.75f * a[i]), b[i]);
-        r = (i % 3u == 0u) ? q.x : ((i % 3u == 1u) ? q.y : q.z);
-        break;
-    }
-    case RPT_PROBE_SQRT: r = fsqrt(a[i]); break;                     // the library's square root (dev_math.h)
-    case RPT_PROBE_EXP: r = rpt_expf(a[i]); break;
-    case RPT_PROBE_LOG: r = rpt_logf(a[i]); break;
-    case RPT_PROBE_RNG: {                                            // a = seed bits, b = frame bits, i = pixel; first draw
-        Rng rng;
-        rng.init(frame_key_hd((uint64_t)rpt_f2u(a[i]), (uint64_t)rpt_f2u(b[i])), (uint32_t)i);
-        r = rng.gen();
-        break;
-    }
-    default: break;
-    }
+    probe_begin();
+    float r = probe_math_body(fn, a[i], b[i], i);
+    if (probe_redo()) r = RPT_PROBE_PLAIN(probe_math_body(fn, a[i], b[i], i));
     out[i] = r;
-}
-
-// One integrator function per record (include/rpt.h, rpt_probe_fn): the same device functions the megakernel inlines.
-struct ProbeLightScene {                                             // what sample_light reads of a scene
-    float n_lights_f;
-    uint32_t flags;
-};
-
-RPT_DEV void probe_material(const float* r, Mat& m)
-{
-    m.rgb = mk3(r[0], r[1], r[2]); m.emission = mk3(r[3], r[4], r[5]);
-    m.anisotropic = r[6]; m.metallic = r[7]; m.roughness = r[8]; m.subsurface = r[9]; m.specular_tint = r[10];
-    m.sheen = r[11]; m.sheen_tint = r[12]; m.clearcoat = r[13]; m.clearcoat_gloss = r[14]; m.spec_trans = r[15]; m.ior = r[16];
-    m.clearcoat_roughness = 0.0f; m.ax = 0.0f; m.ay = 0.0f;
-    mat_finalize(m);
 }
 
 __global__ __launch_bounds__(256) void RPT_K(probe_fn_kernel)(uint32_t fn, const DevCamera cam, const float* __restrict__ in, float* __restrict__ out, uint64_t n)
@@ -1531,98 +1618,18 @@ __global__ __launch_bounds__(256) void RPT_K(probe_fn_kernel)(uint32_t fn, const
     if (i >= n) return;
     const float* r = in + i * RPT_PROBE_IN_STRIDE;
     float* o = out + i * RPT_PROBE_OUT_STRIDE;
-    for (int k = 0; k < RPT_PROBE_OUT_STRIDE; ++k) o[k] = 0.0f;
-    switch (fn) {
-    case RPT_PROBE_FN_GEN_RAY: {
-        const RayD ray = camera_ray(cam, r[0], r[1], r[2], r[3]);
-        o[0] = ray.o.x; o[1] = ray.o.y; o[2] = ray.o.z; o[3] = ray.d.x; o[4] = ray.d.y; o[5] = ray.d.z;
-        break;
-    }
-    case RPT_PROBE_FN_HIT_SPHERE: {
-        float t = 0.0f;
-        const bool h = hit_sphere(RayD{mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])}, mk3(r[6], r[7], r[8]), r[9], t);
-        o[0] = h ? 1.0f : 0.0f; o[1] = h ? t : 0.0f;
-        break;
-    }
-    case RPT_PROBE_FN_HIT_PLANE: {
-        float t = 0.0f;
-        const DevPlane p{r[6], r[7], r[8], r[9], r[10], r[11], r[12], 0u, r[13]};
-        const bool h = hit_plane(RayD{mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])}, p, t);
-        o[0] = h ? 1.0f : 0.0f; o[1] = h ? t : 0.0f;
-        break;
-    }
-    case RPT_PROBE_FN_SAMPLE_LIGHT: {
-        const DevLight L{rpt_f2u(r[0]), r[1], r[2], r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10], r[11], r[12], r[13], r[14]};
-        const ProbeLightScene sc{r[18], rpt_f2u(r[19])};
-        Rng rng;
-        rng.state = rpt_f2u(r[20]);
-        rng.inc = rpt_f2u(r[21]) | 1u;
-        const Rng rng0 = rng;
-        LightSample ls;
-        sample_light(sc, L, mk3(r[15], r[16], r[17]), ls, rng);
-        o[0] = ls.normal.x; o[1] = ls.normal.y; o[2] = ls.normal.z;
-        o[3] = ls.emission.x; o[4] = ls.emission.y; o[5] = ls.emission.z;
-        o[6] = ls.direction.x; o[7] = ls.direction.y; o[8] = ls.direction.z;
-        o[9] = ls.dist; o[10] = ls.pdf; o[11] = (float)rng_draws_between(rng0, rng);
-        break;
-    }
-    case RPT_PROBE_FN_DISNEY_EVAL: {
-        Mat m;
-        probe_material(r, m);
-        const float eta = r[17];
-        const v3 v = mk3(r[18], r[19], r[20]), nn = mk3(r[21], r[22], r[23]), l = mk3(r[24], r[25], r[26]);
-        const ShadeFrame fr = make_frame(m, eta, v, nn);
-        float pdf;
-        const v3 f = disney_eval(m, eta, fr, nn, l, pdf);
-        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
-        break;
-    }
-    case RPT_PROBE_FN_DISNEY_SAMPLE: {
-        Mat m;
-        probe_material(r, m);
-        const float eta = r[17];
-        const v3 v = mk3(r[18], r[19], r[20]), nn = mk3(r[21], r[22], r[23]);
-        v3 l = mk3(r[24], r[25], r[26]);
-        Rng rng;
-        rng.state = rpt_f2u(r[27]);
-        rng.inc = rpt_f2u(r[28]) | 1u;
-        const Rng rng0 = rng;
-        const ShadeFrame fr = make_frame(m, eta, v, nn);
-        float pdf;
-        const v3 f = disney_sample(m, eta, fr, nn, l, pdf, rng);
-        o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = l.x; o[4] = l.y; o[5] = l.z; o[6] = pdf; o[7] = (float)rng_draws_between(rng0, rng);
-        break;
-    }
-    default: break;
-    }
+    probe_begin();
+    probe_fn_body(fn, cam, r, o);
+    if (probe_redo()) RPT_PROBE_PLAIN(probe_fn_body(fn, cam, r, o));
 }
 
 __global__ __launch_bounds__(256) void RPT_K(probe_rays_kernel)(const SceneLarge sc, const float* __restrict__ rays, uint32_t* __restrict__ out, uint64_t n)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float* r = rays + i * 7;
-    RayD ray{mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5])};
-    float dist = 3.40282347e+38f;
-    uint32_t best = 0xFFFFFFFFu;
-    bool hit = false;
-    bool any;
-    if (sc.use_accel) {
-        grid_closest_sphere(sc, ray, dist, best, hit);
-        any = grid_any_sphere(sc, ray, true, r[6]);
-    } else {
-        any = false;
-        for (uint32_t k = 0; k < sc.n_spheres; ++k) {
-            const float4 s = sphere_uniform(sc, k);
-            float t;
-            bool h = hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t);
-            if (h && (k == 0 || t < dist)) { dist = t; best = k; hit = true; }
-            any = any || (h && t < r[6]);
-        }
-    }
-    out[i * 3 + 0] = rpt_f2u(dist);
-    out[i * 3 + 1] = best;
-    out[i * 3 + 2] = any ? 1u : 0u;
+    probe_begin();
+    probe_rays_body(sc, rays + i * 7, out, i);
+    if (probe_redo()) RPT_PROBE_PLAIN(probe_rays_body(sc, rays + i * 7, out, i));
 }
 
 #endif  // RPT_RENDER_KERNELS_ONLY
@@ -1632,7 +1639,7 @@ __global__ __launch_bounds__(256) void RPT_K(probe_rays_kernel)(const SceneLarge
 // ---------------------------------------------------------------------------
 namespace RPT_LAUNCH_NS {
 
-uint32_t max_spp_per_launch() { return kMaxSppPerLaunch; }
+uint32_t max_spp_per_launch(bool sdf_object) { return sdf_object ? kMaxSppPerLaunchSdf : kMaxSppPerLaunch; }
 
 // Which forms a build holds: the shipped library the default form of every scene class, the compacting kernel of one-sample
 // launches and ONE nested-loop baseline (small scenes without media); builds with -DRPT_AB_KERNELS every form ever measured.
@@ -1645,6 +1652,12 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     const dim3 tiles(nblocks), wg(256);
     (void)hipGetLastError();                                         // the thread's sticky error may be somebody else's (a host process's own HIP calls)
     (void)scs_dev;
+#ifdef RPT_NO_LARGE_SDF_KERNELS
+    if (large || has_sdf || (rp.compact && !nested)) return rptlaunch_perop::render(scs, scl, large, nested, rp, nblocks, st, scs_dev, media);   // (the RPT_PEROP_BUILD object)
+#endif
+#ifdef RPT_NO_SMALL_KERNELS
+    if (!large && !has_sdf && !(rp.compact && !nested)) return hipErrorNotSupported;
+#endif
     if (media) {
 #ifndef RPT_NO_MEDIA_KERNELS
         // scenes with participating media: the same forms, instantiated for WithMedia<Scene> (csrc/ab/ has none)
@@ -1661,10 +1674,16 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #else
         else if (nested || (has_sdf && rp.sdf_resumable_march != 4u)) return hipErrorNotSupported;
 #endif
+#ifndef RPT_NO_LARGE_SDF_KERNELS
         else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_media_kernel), tiles, wg, 0, st, mscl, rp);
         else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, mscs, rp);
+#endif
+#ifndef RPT_NO_COMPACT_KERNELS
         else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_media_kernel), tiles, wg, 0, st, msc, rp);
+#endif
+#ifndef RPT_NO_SMALL_KERNELS
         else hipLaunchKernelGGL(RPT_K(render_small_regen_media_kernel), tiles, wg, 0, st, msc, rp);
+#endif
         return hipGetLastError();
 #else
         return hipErrorNotSupported;
@@ -1684,17 +1703,25 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #else
     else if ((nested && (large || has_sdf)) || (has_sdf && rp.sdf_resumable_march != 4u)) return hipErrorNotSupported;
 #endif
+#ifndef RPT_NO_LARGE_SDF_KERNELS
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), tiles, wg, 0, st, scl, rp);
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_march2_kernel), tiles, wg, 0, st, scs, rp);
+#endif
+#ifndef RPT_NO_SMALL_KERNELS
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
+#endif
+#ifndef RPT_NO_COMPACT_KERNELS
     else if (rp.compact && nblocks <= 3072u) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
     else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_kernel), tiles, wg, 0, st, sc, rp);
+#endif
+#ifndef RPT_NO_SMALL_KERNELS
     else {
         // RPT_DEBUG_EXTRA_LDS (bytes, experiments only): pads the workgroup's LDS so that fewer waves fit a CU — how the
         // kernel's throughput depends on resident waves per SIMD (occupancy sensitivity)
         static const unsigned extra_lds = getenv("RPT_DEBUG_EXTRA_LDS") ? (unsigned)atoi(getenv("RPT_DEBUG_EXTRA_LDS")) : 0u;
         hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, extra_lds, st, sc, rp);
     }
+#endif
     return hipGetLastError();
 }
 

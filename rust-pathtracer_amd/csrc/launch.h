@@ -12,7 +12,7 @@
 
 namespace rptlaunch {
 
-uint32_t max_spp_per_launch();      // samples one launch of the regenerating kernel can hold in its LDS tables
+uint32_t max_spp_per_launch(bool sdf_object);      // samples a chunk of the state-machine kernels can hold in its LDS tables (scenes with an SDF object: fewer)
 
 // One launch of the megakernel on `nblocks` 16x16 tiles: picks the instantiation (small / SDF / large,
 // regenerating or nested) from the scene.  `small_scene_dev`: the same small scene in device memory (only the compacting SDF
@@ -53,3 +53,10 @@ hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneL
                   const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr,
                   bool media = false);
 }  // namespace rptlaunch_fast
+
+// large scenes' and SDF scenes' kernels of the shipped library (kernels.hip under -DRPT_PEROP_BUILD); rptlaunch::render forwards to it
+namespace rptlaunch_perop {
+hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
+                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr,
+                  bool media = false);
+}  // namespace rptlaunch_perop
