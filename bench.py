@@ -39,11 +39,13 @@ SECONDARY_LIMIT_S = int(os.environ.get("RPT_BENCH_SECONDARY_LIMIT_S", "150"))   
 PROFILES = os.path.join("profiles", "r4")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
 TRAFFIC_JSON = os.path.join(PROFILES, "c2_bench", "traffic.json")
 # What a correctly rounded f32 divide / square root costs the VALU in this library (csrc/dev_math.h): a quotient is v_rcp + 2 fma
-# shared by the numerators of one denominator, then mul + 2 fma + v_div_fixup each, plus the range guard's v_frexp_exp / min /
-# max / compare — 7.7 instructions per quotient in normalize's three-quotient form, 13 for a lone one: 9 is used; a root is
-# v_sqrt + v_rsq + mul + 2 fma + 3 of guard.  (Rounds 1-3 priced them at hipcc's expansions, 12 and 15, which the library no
-# longer executes.)
+# shared by the numerators of one denominator, then mul + 2 fma + v_div_fixup each; a root is v_sqrt + v_rsq + mul + 2 fma; plus
+# the range test.  Small scenes' megakernel tracks the operands (v_frexp_exp + v_max3 per divide, v_frexp_exp + v_min per root; the
+# two DS operations each are not VALU work): 9 for a lone quotient, 6.3 per quotient of a normalize — 8 is used — and 7 for a root.
+# The other kernels test next to the operation (v_frexp_exp / min / max / compare): 13 / 7.7 — 9 is used — and 8.  (Rounds 1-3 priced
+# both at hipcc's expansions, 12 and 15, which the library no longer executes.)
 DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS = 9, 8
+DIV_INSTRUCTIONS_TRACKED, SQRT_INSTRUCTIONS_TRACKED = 8, 7
 
 
 def weak_frame(n_gpus):
@@ -85,13 +87,14 @@ def op_counts(desc=None, frame=(240, 136, 4), skip_missed_sphere_tests=False):
     return out
 
 
-def roofline_block(ops, launch_samples, kernel_s, kernel, launches, pixels):
+def roofline_block(ops, launch_samples, kernel_s, kernel, launches, pixels, tracked=False):
     """FP32-VALU roofline of one config (no dense contraction, HBM is not the limiter): algorithmic flops per
     step = flops per sample (oracle op counts) x samples per step, over the measured duration of the step's launches."""
     tfl = ops["flops_per_sample"] * launch_samples / kernel_s / 1e12
     # the same work with every correctly rounded divide / sqrt counted at the VALU instructions this library issues for it
     # (one operation per instruction, an fma as one): what the VALU actually has to issue for the algorithmic flops
-    expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (DIV_INSTRUCTIONS - 1) + ops["sqrts_per_sample"] * (SQRT_INSTRUCTIONS - 1)
+    div_i, sqrt_i = (DIV_INSTRUCTIONS_TRACKED, SQRT_INSTRUCTIONS_TRACKED) if tracked else (DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS)
+    expanded = ops["flops_per_sample"] + ops["divides_per_sample"] * (div_i - 1) + ops["sqrts_per_sample"] * (sqrt_i - 1)
     hbm = 32.0 * pixels / kernel_s / 1e9
     return {"bound": "fp32_valu", "achieved": round(tfl, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tfl / FP32_PEAK_TFLOPS, 5), "traffic": None,
@@ -99,7 +102,7 @@ def roofline_block(ops, launch_samples, kernel_s, kernel, launches, pixels):
             "algorithmic_flops_per_step": ops["flops_per_sample"] * launch_samples, **ops,
             "ieee_expanded_flops_per_sample": round(expanded, 1),
             "ieee_expanded_frac": round(expanded * launch_samples / kernel_s / 1e12 / FP32_PEAK_TFLOPS, 5),
-            "ieee_expanded_note": "flops with a divide counted as %d and a square root as %d operations: the instructions of csrc/dev_math.h's correctly rounded sequences" % (DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS),
+            "ieee_expanded_note": "flops with a divide counted as %d and a square root as %d operations: the instructions of csrc/dev_math.h's correctly rounded sequences" % (div_i, sqrt_i),
             "hbm_algorithmic_GBs": round(hbm, 3), "hbm_frac": round(hbm / HBM_PEAK_GBS, 6)}
 
 
@@ -183,7 +186,7 @@ def other_configs(rpt, torch, device, small):
     sdf = scenes.sdf_scene()
     w, h, spp = 1920 // div, 1080 // div, 64 // (4 if small else 1)
     t = run(sdf, w, h, spp, 3)
-    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march2_kernel", 1, w * h)
+    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march2_kernel_perop", 1, w * h)
     blk.update({"workload": "SDF sphere-march scene %dx%d x %d spp per step (BASELINE.json configs[3])" % (w, h, spp),
                 "value": round(w * h * spp / t / 1e6, 2), "value_unit": "Msamples/s"})
     if not small:
@@ -194,13 +197,13 @@ def other_configs(rpt, torch, device, small):
     w = h = 4096 // div
     full = 512 // (16 if small else 1)
     t_full = run(big, w, h, full, 1)
-    blk = roofline_block(ops, w * h * full, t_full, "render_large_regen_kernel", 1, w * h)
+    blk = roofline_block(ops, w * h * full, t_full, "render_large_regen_kernel_perop", 1, w * h)
     blk.update({"workload": "10k spheres + 16 lights %dx%d x %d spp in one call (BASELINE.json configs[4], the whole frame on one GPU)" % (w, h, full),
                 "value": round(w * h * full / t_full / 1e6, 2), "value_unit": "Msamples/s",
                 "note": "flops per sample exclude ray/sphere tests that missed (brute_force_flops_per_sample is the oracle's loop); "
                         "the grid walk's own arithmetic is not algorithmic work and is not counted"})
     t8 = run(big, w, h, 8, 2)
-    blk["progressive_8spp"] = {"kernel": "render_large_regen_kernel",
+    blk["progressive_8spp"] = {"kernel": "render_large_regen_kernel_perop",
                                "kernel_ms": round(t8 * 1e3, 3), "value": round(w * h * 8 / t8 / 1e6, 2),
                                "frac": round(ops["flops_per_sample"] * w * h * 8 / t8 / 1e12 / FP32_PEAK_TFLOPS, 5)}
     if not small:
@@ -304,7 +307,7 @@ def config1_line(rpt, torch, device, threads):
     return {"workload": "AnalyticalScene 800x600 x 1 spp per call (BASELINE.json configs[0]: one reference render())",
             "cpu_ms_per_call": round(cpu_s * 1e3, 3), "cpu_value": round(w * h / cpu_s / 1e6, 2), "cpu_cores": threads, "cpu_kind": "port",
             "gpu_ms_per_call": round(gpu_s * 1e3, 4), "gpu_value": round(w * h / gpu_s / 1e6, 1), "unit": "Msamples/s",
-            "gpu_kernel": "render_small_compact_dense_kernel", "gpu_over_cpu": round(cpu_s / gpu_s, 1)}
+            "gpu_kernel": "render_small_compact_dense_kernel_perop", "gpu_over_cpu": round(cpu_s / gpu_s, 1)}
 
 
 class TorchGatherRender:
@@ -421,8 +424,8 @@ def main():
         algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
         hbm = algo_bytes / avg_kernel_s / 1e9
         launches = 1                              # one launch whatever spp is (kernels.hip: a launch is tiles x chunks of samples)
-        kernel = "render_small_regen_kernel" if spp > 1 else "render_small_compact_kernel"     # (capi.hip: RPT_COMPACT_MAX_SPP)
-        roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels)
+        kernel = "render_small_regen_kernel" if spp > 1 else "render_small_compact_kernel_perop"     # (capi.hip: RPT_COMPACT_MAX_SPP)
+        roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels, tracked=spp > 1)
         roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
                             "rounded f32 divide or sqrt costs 8-13 VALU instructions in this library (ieee_expanded_*); kernel_ms = HIP events on the launch stream")
         tj = os.path.join(ROOT, TRAFFIC_JSON)
