@@ -1,6 +1,8 @@
 """Per-block lane utilisation and time shares of the megakernel (csrc/dev_prof.h).
 
-  python tools/block_profile.py build      # here: cross-compile librpt_hip_prof.so (-DRPT_PROFILE_BLOCKS)
+  python tools/block_profile.py build      # here: cross-compile librpt_hip_prof.so (-DRPT_PROFILE_BLOCKS) and librpt_hip_prof_perop.so
+                                           # (the same with -DRPT_GUARD_PER_OP: one object, the range tests next to every operation —
+                                           # how the shipped large / SDF kernels are built; the counters live in one object only)
   python tools/block_profile.py [spp] [c2|c4|c5]   # on the GPU box: render that config with it and print the table
 """
 import ctypes as C
@@ -20,9 +22,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     print(b.build(force=True, extra_flags=["-DRPT_PROFILE_BLOCKS"], lib=PROF_LIB, objdir_name="build_prof"))
+    print(b.build(force=True, extra_flags=["-DRPT_PROFILE_BLOCKS", "-DRPT_GUARD_PER_OP"], lib=PROF_LIB.replace(".so", "_perop.so"), objdir_name="build_prof_perop"))
     sys.exit(0)
 
-os.environ["RPT_LIB"] = PROF_LIB
+# small scenes' megakernel is profiled as shipped (range trackers); every other config in the one-object per-operation build
+os.environ["RPT_LIB"] = PROF_LIB if (len(sys.argv) <= 2 or sys.argv[2] == "c2") else PROF_LIB.replace(".so", "_perop.so")
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import conftest  # noqa: E402
 import torch  # noqa: E402
