@@ -24,8 +24,9 @@ RPT_DEV float probe_math_body(uint32_t fn, float a, float b, uint64_t i)
     case RPT_PROBE_LOG2: r = rpt_log2f(a); break;
     case RPT_PROBE_POW: r = rpt_powf(a, b); break;
     case RPT_PROBE_DIV: r = fdiv(a, b); break;                 // the library's divide (dev_math.h), not hipcc's
-    case RPT_PROBE_DIV3: {                                            // three quotients by one denominator: divs3 / normalize's form
-        const v3 q = (i & 4u) ? divs3_norm(mk3(a, 0.5f * b, 0.0f), b) : divs3(mk3(a, -b, 0.75f * a), b);
+    case RPT_PROBE_DIV3: {                                            // three quotients by one denominator (divs3; normalize's own form
+                                                                      // takes only len3 of its numerators: the integrator probes cover it)
+        const v3 q = (i & 4u) ? divs3(mk3(a, 0.5f * b, 0.0f), b) : divs3(mk3(a, -b, 0.75f * a), b);
         r = (i % 3u == 0u) ? q.x : ((i % 3u == 1u) ? q.y : q.z);
         break;
     }
