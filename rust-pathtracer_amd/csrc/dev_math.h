@@ -104,32 +104,36 @@ RPT_DEV v3 divs3(v3 a, float d) { return v3{a.x / d, a.y / d, a.z / d}; }
 RPT_DEV v3 divs3_norm(v3 a, float len) { return divs3(a, len); }
 RPT_DEV float fsqrt(float x) { return __builtin_sqrtf(x); }
 #elif RPT_MATH_MODE == 1
-RPT_DEV bool div_exps_ok(int lo, int hi) { return lo >= -60 && hi <= 60; }
-// (A single quotient gains nothing in instructions — 7 + 6 of guard against hipcc's 11 — only in chain depth.)
+RPT_DEV float fmax3abs(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), __builtin_fabsf(c)); }
+// The range tests next to the operation, in the operands the short sequence has anyway: everything below 2^60 is one v_max3_f32 over
+// |n|, |d| and |1 / d| (a tiny d is a huge reciprocal; a NaN is ignored unless all three are: then the compare fails and hipcc's divide
+// answers), the numerators' lower end is v_frexp_exp >= -59 (zero, infinity and NaN read 0 and pass).  4 VALU for a lone quotient where
+// the exponents of both operands took 6, 2 for a root where the exponent field took 3 (round 4: configs[3] +2.6 %, configs[4] +1.3 %,
+// one-sample launches +2 %).
 RPT_DEV float fdiv(float n, float d)
 {
-    float q = div_with_rcp(n, d, div_refine(d, __builtin_amdgcn_rcpf(d)));
-    const int en = div_exp(n), ed = div_exp(d);
-    const bool ok = div_exps_ok(en < ed ? en : ed, en < ed ? ed : en);
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    float q = div_with_rcp(n, d, div_refine(d, r0));
+    const bool ok = (fmax3abs(n, d, r0) < 0x1p60f) && (div_exp(n) >= -59);
     if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) q = n / d; }
     return q;
 }
 RPT_DEV v3 divs3(v3 a, float d)                                     // a / F3::new_x(d): three quotients, one reciprocal
 {
-    const float r = div_refine(d, __builtin_amdgcn_rcpf(d));
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float r = div_refine(d, r0);
     v3 q = v3{div_with_rcp(a.x, d, r), div_with_rcp(a.y, d, r), div_with_rcp(a.z, d, r)};
-    const int ex = div_exp(a.x), ey = div_exp(a.y), ez = div_exp(a.z), ed = div_exp(d);
-    const bool ok = div_exps_ok(imin3(ex, ey, ez), imax3(ex, ey, ez)) && div_exps_ok(ed, ed);
+    const bool ok = (fmax3abs(fmax3abs(a.x, a.y, a.z), d, r0) < 0x1p60f) && (imin3(div_exp(a.x), div_exp(a.y), div_exp(a.z)) >= -59);
     if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) q = v3{a.x / d, a.y / d, a.z / d}; }
     return q;
 }
-// normalize: the numerators cannot exceed the length, which spares the upper test
+// normalize (`len` = len3(a)): |a.i| >= 2^60 makes the sum of squares >= 2^120 and its root >= 2^60: the numerators need no upper test
 RPT_DEV v3 divs3_norm(v3 a, float len)
 {
-    const float r = div_refine(len, __builtin_amdgcn_rcpf(len));
+    const float r0 = __builtin_amdgcn_rcpf(len);
+    const float r = div_refine(len, r0);
     v3 q = v3{div_with_rcp(a.x, len, r), div_with_rcp(a.y, len, r), div_with_rcp(a.z, len, r)};
-    const int ed = div_exp(len);
-    const bool ok = div_exps_ok(imin3(div_exp(a.x), div_exp(a.y), div_exp(a.z)), 0) && div_exps_ok(ed, ed);
+    const bool ok = (__builtin_fmaxf(__builtin_fabsf(len), __builtin_fabsf(r0)) < 0x1p60f) && (imin3(div_exp(a.x), div_exp(a.y), div_exp(a.z)) >= -59);
     if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) q = v3{a.x / len, a.y / len, a.z / len}; }
     return q;
 }
@@ -137,7 +141,7 @@ RPT_DEV float fsqrt(float x)
 {
     const float s0 = __builtin_amdgcn_sqrtf(x);
     float s = __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * __builtin_amdgcn_rsqf(x), s0);
-    const bool ok = ((rpt_f2u(x) >> 23) - 67u) <= 120u;             // positive, 2^-60 <= x < 2^61
+    const bool ok = (rpt_f2u(x) - 0x21800000u) < (0x5E000000u - 0x21800000u);      // positive, 2^-60 <= x < 2^61
     if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) s = __builtin_sqrtf(x); }
     return s;
 }
