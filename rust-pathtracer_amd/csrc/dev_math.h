@@ -52,12 +52,13 @@ RPT_DEV v3 scale3(v3 a, float f) { return v3{a.x * f, a.y * f, a.z * f}; }      
 //
 // The SHORT sequences
 //     r0 = v_rcp_f32(d);  r = fma(fma(-d, r0, 1), r0, r0);  q0 = n * r;  q = fma(fma(-d, q0, n), r, q0);  v_div_fixup(q, d, n)
-//     s0 = v_sqrt_f32(x);  h = 0.5 * v_rsq_f32(x);  s = fma(fma(-s0, s0, x), h, s0)
+//     y = v_rsq_f32(x);  s0 = x * y;  s = fma(fma(-s0, s0, x), 0.5 * y, s0)
 // — one Newton step on the reciprocal, shared by every numerator of one denominator, ONE Markstein correction of the quotient; one
 // correction of the root by its residual — return the correctly rounded result for EVERY significand: tools/proofs/div_exhaustive.hip
 // compares the quotient with hipcc's on all 2^23 x 2^23 pairs (7.0e13 quotients, 0 mismatches), tools/proofs/sqrt_exhaustive.hip the
-// root with hipcc's sqrtf on all 121 * 2^23 floats of [2^-60, 2^61) (0 mismatches; the variant with v_rcp_f32(s0) has 60), both on
-// gfx950 (profiles/r3/proofs/).  Every step commutes exactly with scaling by powers of two and with the operands' signs as long as no
+// root with hipcc's sqrtf on all 121 * 2^23 floats of [2^-60, 2^61) (0 mismatches, also for round 3's form with v_sqrt_f32 AND v_rsq_f32 —
+// transcendental instructions issue at a quarter of the rate, so the one saved is worth three others —; the variant with v_rcp_f32(s0)
+// has 60), both on gfx950 (profiles/r3/proofs/, profiles/r4/proofs/).  Every step commutes exactly with scaling by powers of two and with the operands' signs as long as no
 // intermediate leaves the normal range: |d|, |n| in [2^-61, 2^60) keeps r, q0, the residual (>= 2^-46 |n|) and q normal.  Zero and
 // NaN numerators, and NaN denominators, are answered by v_div_fixup without looking at q, exactly as at the end of hipcc's sequence
 // (it supplies IEEE's sign of a zero quotient too).  Outside the range the sequences are WRONG, so somebody has to look:
@@ -74,8 +75,8 @@ RPT_DEV v3 scale3(v3 a, float f) { return v3{a.x * f, a.y * f, a.z * f}; }      
 //             operand; d = 0 and |d| <= 2^-60 show as a huge 1/d) and of every root's argument (a negative one, an infinity or a
 //             NaN reads as a huge integer);                                                          good if hi_u < bits(2^60)
 //     so inside a good sample every n is 0, NaN or in [2^-60, 2^60), every d NaN or in (2^-60, 2^60), every root's argument +0 or in
-//     [2^-60, 2^60): inside what the proofs cover.  (+0 under the root: the residual is 0 and 0.5 / sqrt(0) infinite; clamping the
-//     latter makes the product 0.  No root of the range has 0.5 rsq above 2^30.)
+//     [2^-60, 2^60): inside what the proofs cover.  (+0 under the root: 0 x rsq(0) would be 0 x inf; with rsq clamped it is 0, and so
+//     is the correction.)
 //   RPT_MATH_MODE 1 (A/B builds, -DRPT_AB_KERNELS or -DRPT_GUARD_PER_OP: the forms whose paths change lanes or kernels): the test next
 //     to the operation, operands outside the range take hipcc's sequence in the lanes concerned behind a wave vote (rounds 3-4).
 //   RPT_MATH_MODE 0 (namespace rptplain; the relaxed build, where `/` and sqrtf are hipcc's fast ones): the plain operations.
@@ -139,8 +140,9 @@ RPT_DEV v3 divs3_norm(v3 a, float len)
 }
 RPT_DEV float fsqrt(float x)
 {
-    const float s0 = __builtin_amdgcn_sqrtf(x);
-    float s = __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * __builtin_amdgcn_rsqf(x), s0);
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float s0 = x * y;
+    float s = __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * y, s0);
     const bool ok = (rpt_f2u(x) - 0x21800000u) < (0x5E000000u - 0x21800000u);      // positive, 2^-60 <= x < 2^61
     if (__builtin_expect(__ballot(!ok) != 0ull, 0)) { if (!ok) s = __builtin_sqrtf(x); }
     return s;
@@ -203,10 +205,10 @@ RPT_DEV v3 divs3_norm(v3 a, float len)
 }
 RPT_DEV float fsqrt(float x)
 {
-    const float s0 = __builtin_amdgcn_sqrtf(x);
-    const float h = __builtin_fminf(0.5f * __builtin_amdgcn_rsqf(x), 1.0e30f);
+    const float y = __builtin_fminf(__builtin_amdgcn_rsqf(x), 1.0e30f);   // (x = +0: 0 x 1e30 = 0 where 0 x inf would be a NaN; no root of the range has rsq above 2^30)
+    const float s0 = x * y;
     guard_note(div_exp(x), x);
-    return __builtin_fmaf(__builtin_fmaf(-s0, s0, x), h, s0);
+    return __builtin_fmaf(__builtin_fmaf(-s0, s0, x), 0.5f * y, s0);
 }
 #endif
 
