@@ -39,12 +39,12 @@ SECONDARY_LIMIT_S = int(os.environ.get("RPT_BENCH_SECONDARY_LIMIT_S", "150"))   
 PROFILES = os.path.join("profiles", "r4")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
 TRAFFIC_JSON = os.path.join(PROFILES, "c2_bench", "traffic.json")
 # What a correctly rounded f32 divide / square root costs the VALU in this library (csrc/dev_math.h): a quotient is v_rcp + 2 fma
-# shared by the numerators of one denominator, then mul + 2 fma + v_div_fixup each; a root is v_sqrt + v_rsq + mul + 2 fma; plus
-# the range test.  Small scenes' megakernel tracks the operands (v_frexp_exp + v_max3 per divide, v_frexp_exp + v_min per root; the
-# two DS operations each are not VALU work): 9 for a lone quotient, 6.3 per quotient of a normalize — 8 is used — and 7 for a root.
-# The other kernels test next to the operation (v_frexp_exp / min / max / compare): 13 / 7.7 — 9 is used — and 8.  (Rounds 1-3 priced
-# both at hipcc's expansions, 12 and 15, which the library no longer executes.)
-DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS = 9, 8
+# shared by the numerators of one denominator, then mul + 2 fma + v_div_fixup each; a root is v_rsq + 2 mul + 2 fma; plus the range
+# test.  Small scenes' megakernel tracks the operands (v_frexp_exp + v_max3 per divide, v_frexp_exp + v_min per root; the two DS
+# operations each are not VALU work): 9 for a lone quotient, 6 per quotient of a normalize — 8 is used — and 7 for a root.  The
+# other kernels test next to the operation (v_max3, v_frexp_exp, two compares; subtract + compare for a root): 11 / 7.3 — 9 is used —
+# and 7.  (Rounds 1-3 priced both at hipcc's expansions, 12 and 15, which the library no longer executes.)
+DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS = 9, 7
 DIV_INSTRUCTIONS_TRACKED, SQRT_INSTRUCTIONS_TRACKED = 8, 7
 
 
