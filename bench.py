@@ -365,6 +365,7 @@ def main():
     ap.add_argument("--smoke-shared-gpu", action="store_true",
                     help="TEST ONLY: every rank drives cuda:0 and the tiles are gathered with peer copies (RCCL rejects "
                          "duplicate devices), to exercise the N>1 control flow on a 1-GPU box; the numbers mean nothing")
+    ap.add_argument("--force-multi", action="store_true", help="TEST ONLY: take the N > 1 path with however many ranks there are (one, without a launcher)")
     ap.add_argument("--small", action="store_true", help="TEST ONLY: 1/8-size frames and 1/16 of the samples (control-flow rehearsals)")
     args = ap.parse_args()
 
@@ -376,13 +377,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # TEST ONLY: the N > 1 code path (library communicator, tiles, gather beside the render, secondary legs) with a world of ONE rank on
+    # one GPU — what a test box can run of it for real (tests/test_gpu_multi.py); the numbers mean nothing
+    multi = world > 1 or args.force_multi
+    if args.force_multi and world == 1:
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("MASTER_PORT", "29531")
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if args.smoke_shared_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane only (the data path's RCCL lives in the library).  Gloo announces its connections on stdout from
@@ -402,7 +408,7 @@ def main():
         return (cfg[0] // 8, cfg[1] // 8, max(1, cfg[2] // 16)) if args.small else cfg
 
     def host_fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -429,7 +435,7 @@ def main():
         roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
                             "rounded f32 divide or sqrt costs 8-13 VALU instructions in this library (ieee_expanded_*); kernel_ms = HIP events on the launch stream")
         tj = os.path.join(ROOT, TRAFFIC_JSON)
-        if world == 1 and not args.small and os.path.exists(tj):
+        if not multi and not args.small and os.path.exists(tj):
             t = json.load(open(tj))
             roofline["traffic"] = t["hbm_bytes_per_launch"]
             roofline["traffic_source"] = "%s: rocprofv3 PMC passes of this command, committed (%s); bench.py cannot collect counters itself" % (
@@ -450,22 +456,22 @@ def main():
             "metric": "Msamples/s (pixels x spp) on AnalyticalScene 1920x1080 f32; 1/2/4/8-GPU scaling",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak" if world == 1 else "strong",
+            "scaling": "weak" if not multi else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[1])" % (width, height, spp)) if world == 1 else
+            "config": {"workload": ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[1])" % (width, height, spp)) if not multi else
                                    ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[2]): cyclic 2-row tiles over %d GPUs, "
                                     "RCCL gather to rank 0 + scatter per step inside the timed region" % (width, height, spp, world)),
                        "spp_per_step": spp, "width": width, "height": height, "parallelism": "rows%d" % world,
-                       **({"gather": gather_mode} if world > 1 else {})},
+                       **({"gather": gather_mode} if multi else {})},
             "roofline": roofline,
             "roofline_hbm": {"bound": "hbm", "achieved": round(hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 6),
                              "algorithmic_bytes_per_step": algo_bytes,
                              "note": "32/S bytes per pixel-sample: the honest signature of an ALU-bound path, not the binding roofline"},
         }
         out.update(extra)
-        if world == 1 and not args.headline_only:
+        if not multi and not args.headline_only:
             out.update(other_configs(rpt, torch, local_rank, args.small))
-        if world == 1 and not args.no_cpu_baseline and not args.small:
+        if not multi and not args.no_cpu_baseline and not args.small:
             cpu = cpu_baseline(width, height)
             out["cpu_baseline"] = cpu
             out["gpu_over_cpu"] = round(value / cpu["value"], 1)
@@ -546,7 +552,7 @@ def main():
                 tracer._scene = scene
                 tracer.upload_scene()
 
-    if world == 1:
+    if not multi:
         # ---- one GPU: configs[1].  The frame is a torch tensor, the launches go to torch's current stream, and
         # torch.cuda.Event pairs on that stream time each step's kernel.
         width, height, spp = shrink(C2)
@@ -653,7 +659,7 @@ def main():
         watchdog.cancel()
 
     emit()
-    if world > 1:
+    if multi:
         dist.barrier()
         if tracer:
             tracer.close()

@@ -282,3 +282,29 @@ def test_bench_keeps_its_line_when_a_secondary_leg_hangs(rpt, torch_cuda):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0
     assert d["secondary_legs"].startswith("cut off")
+
+
+def test_bench_multi_gpu_path_with_the_library_communicator_and_one_rank(rpt, torch_cuda):
+    """bench.py's N > 1 path for real — tiling.rank_tracer (unique id over the job's gloo group, ncclCommInitRank), the first exchange,
+    configs[2]'s steps with the gather beside the next render, the secondary legs, the configs[4] leg — with the one rank a one-GPU box
+    can give it (--force-multi): everything but a second peer.  The line must name the library's gather, not the fallback."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env["MASTER_ADDR"] = "127.0.0.1"
+    env["MASTER_PORT"] = "29533"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--small", "--force-multi"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "ONE JSON line"
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["config"]["gather"].startswith("library RCCL"), d["config"]
+    for key in ("weak_scaling", "strong_scaling", "configs4"):
+        assert key in d and d[key].get("value", d[key].get("speedup", 1)) > 0, (key, d.get("secondary_legs"))
+    assert "secondary_legs" not in d
