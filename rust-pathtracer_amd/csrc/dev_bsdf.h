@@ -1,7 +1,9 @@
 // dev_bsdf.h — Disney principled BSDF of rust-pathtracer/src/tracer.rs:223-626 and
 // spherical-light sampling (tracer.rs:173-220), device side.  Operation order is
 // the reference's; see dev_math.h for why.
-#include "dev_pass.h"
+#ifndef RPT_NS                        // (the namespace of this pass: dev_math.h, "two passes")
+#define RPT_NS rptdev
+#endif
 #if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_BSDF_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_BSDF_H_NORMAL))
 #ifdef RPT_PLAIN_PASS
 #define RPT_DEV_BSDF_H_PLAIN

@@ -1,6 +1,8 @@
 // dev_integrator.h — scene queries and the per-sample path of
 // rust-pathtracer/src/tracer.rs:33-117 for small analytical scenes (SceneSmall).
-#include "dev_pass.h"
+#ifndef RPT_NS                        // (the namespace of this pass: dev_math.h, "two passes")
+#define RPT_NS rptdev
+#endif
 #if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_INTEGRATOR_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_INTEGRATOR_H_NORMAL))
 #ifdef RPT_PLAIN_PASS
 #define RPT_DEV_INTEGRATOR_H_PLAIN

@@ -5,7 +5,9 @@
 // oracle/rpt_oracle.hpp (Tracer::phase_hg, sample_hg, medium_transmittance, the media branches of sample_pixel and
 // direct_light); these functions restate it operation for operation and are compared with it bit for bit.
 // Only kernels instantiated for WithMedia<Scene> (dev_scene.h) contain any of this.
-#include "dev_pass.h"
+#ifndef RPT_NS                        // (the namespace of this pass: dev_math.h, "two passes")
+#define RPT_NS rptdev
+#endif
 #if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_MEDIA_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_MEDIA_H_NORMAL))
 #ifdef RPT_PLAIN_PASS
 #define RPT_DEV_MEDIA_H_PLAIN

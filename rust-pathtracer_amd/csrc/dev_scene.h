@@ -20,7 +20,7 @@
 
 // The TYPES kernels and host share live in `rptscene`, a namespace without functions over them: the device functions (dev_math.h ...
 // dev_scene_large.h) are compiled twice into one kernel — `rptdev` with the short guarded divide / square root and `rptplain` with
-// hipcc's own (dev_pass.h) — and with no function here argument-dependent lookup cannot mix the two.  `rptdev` sees these names
+// hipcc's own (dev_math.h, "two passes") — and with no function here argument-dependent lookup cannot mix the two.  `rptdev` sees these names
 // through a using-directive, so `rptdev::SceneSmall` stays what it was.
 namespace rptscene {
 

@@ -14,7 +14,9 @@
 // patches the ordered-acceptance rule of analytical.rs:36-120 reduces to "the last accepted
 // sphere's material", i.e. the nearest sphere's (first index on ties), so the result is still
 // exactly what the ordered loop gives.  Plane materials stay arbitrary patches.
-#include "dev_pass.h"
+#ifndef RPT_NS                        // (the namespace of this pass: dev_math.h, "two passes")
+#define RPT_NS rptdev
+#endif
 #if (defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_SCENE_LARGE_H_PLAIN)) || (!defined(RPT_PLAIN_PASS) && !defined(RPT_DEV_SCENE_LARGE_H_NORMAL))
 #ifdef RPT_PLAIN_PASS
 #define RPT_DEV_SCENE_LARGE_H_PLAIN

@@ -52,9 +52,11 @@
 #include "dev_probes.h"
 #endif
 #if RPT_MATH_MODE == 2
-// The device functions a second time, over hipcc's own divide and sqrtf (namespace rptplain, dev_pass.h): what sample_guard
+// The device functions a second time, over hipcc's own divide and sqrtf (namespace rptplain; dev_math.h, "two passes"): what sample_guard
 // recomputes a sample with.  (The block profiler's scopes stay in the normal pass.)
 #define RPT_PLAIN_PASS
+#undef RPT_NS
+#define RPT_NS rptplain
 #pragma push_macro("RPT_PROF")
 #undef RPT_PROF
 #define RPT_PROF(id) do { } while (0)
@@ -64,7 +66,8 @@
 #endif
 #pragma pop_macro("RPT_PROF")
 #undef RPT_PLAIN_PASS
-#include "dev_pass.h"
+#undef RPT_NS
+#define RPT_NS rptdev
 #undef RPT_MATH_MODE
 #define RPT_MATH_MODE 2
 #endif
