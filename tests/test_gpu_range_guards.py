@@ -88,3 +88,23 @@ def test_a_scaled_scene_with_chunks_and_roulette(rpt, oracle, torch_cuda):
     torch_cuda.cuda.synchronize()
     assert_bit_identical(buf.pixels.cpu().numpy(), want, "x 2^-30, one-sample chunks, roulette")
     t.close()
+
+
+@pytest.mark.parametrize("seed", [3, 7, 11, 14, 23, 31, 42, 57])
+def test_random_scaled_scenes_match_the_oracle(rpt, oracle, torch_cuda, seed):
+    """Random small scenes (glass, clearcoat, metal, several lights, depth up to 8, roulette) scaled by a random power of two in
+    2^-33 ... 2^33 (tests/scene_fuzz.py): whatever share of the samples takes the second computation, the frame is the oracle's.
+    (tools/range_soak.py runs 60 of these at larger sizes against the library with per-operation tests.)"""
+    from scene_fuzz import random_small_scene
+    s, log2_k, flags, rng = random_small_scene(rpt, seed)
+    w, h, spp = 72, 48, 5
+    want = oracle.render(s.describe(), w, h, spp, seed=seed, render_flags=flags & rpt._abi.RPT_RENDER_RUSSIAN_ROULETTE)
+    t = rpt.Tracer(s, device=0, seed=seed)
+    t.flags = flags
+    buf = rpt.DeviceColorBuffer(w, h)
+    t.render_n(buf, 2)
+    t.render_n(buf, 3)
+    torch_cuda.cuda.synchronize()
+    got = buf.pixels.cpu().numpy()
+    t.close()
+    assert_bit_identical(got, want, "random scene %d x 2^%d" % (seed, log2_k))
