@@ -1,0 +1,12 @@
+set -e
+O=gpurun_out/r4bb; mkdir -p $O
+python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
+tail -2 $O/tests.log
+RPT_LIB=$PWD/rust-pathtracer_amd/librpt_hip_ab.so python -m pytest tests -m gpu -x -q > $O/tests_ab.log 2>&1 || { tail -40 $O/tests_ab.log; exit 1; }
+tail -2 $O/tests_ab.log
+python bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail -20 $O/bench_default.err; exit 1; }
+python -c "
+import json
+d=json.loads([l for l in open('$O/bench_default.json') if l.startswith('{')][-1])
+print('default bench:', d['value'], d['steps'], d['warmup'], d['roofline']['frac'], d['roofline']['traffic'], d['roofline_c4']['value'], d['roofline_c4']['traffic'], d['roofline_c5']['value'], d['cpu_baseline']['value'])
+"
