@@ -6,7 +6,7 @@ launch sequence over the whole frame, on a frame that is already resident in HBM
 
 N = 1   BASELINE.json configs[1]: AnalyticalScene 1920x1080, 256 spp per step, f32.
 N > 1   BASELINE.json configs[2] EXACTLY: AnalyticalScene 3840x2160, 1024 spp per step, the image row-tiled over the N
-        GPUs (cyclic 2-row blocks), one process per GPU; every step ends with the RCCL gather of the tiles to rank 0
+        GPUs (cyclic 8-row blocks), one process per GPU; every step ends with the RCCL gather of the tiles to rank 0
         and the scatter into the full image on rank 0's device, inside the timed region.  STRONG scaling: the frame
         is the same for every N; rank 0 also renders it alone after the timed region, so the line carries the
         measured 1-GPU time of the same frame next to the N-GPU time.  Fixed work per GPU (weak scaling) is a
@@ -35,6 +35,11 @@ FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
 GPU_CLOCK_HZ = 2.4e9           # the same table's engine clock (the PMC passes measured 2.37e9 under this kernel)
 C2 = (1920, 1080, 256)         # BASELINE.json configs[1]
 C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
+# Rows per block of the cyclic row tiling for N > 1.  One rank's share of configs[2] on one GPU (tools/tile_rows_time.py, 8 virtual ranks,
+# 1 024 spp): blocks of 1 / 2 / 4 / 8 / 16 rows -> slowest rank 84.7 / 84.7 / 83.6 / 82.5 / 82.0 ms, the eight ranks within 1.9 / 1.8 /
+# 1.2 / 2.3 / 7.3 % of each other: with 8 rows a wave's 8 x 8 pixels are one piece of the image again (coherent paths), and the
+# ranks still balance.
+TILE_ROWS = 8
 SECONDARY_LIMIT_S = int(os.environ.get("RPT_BENCH_SECONDARY_LIMIT_S", "150"))        # N > 1: the legs after the headline (weak scaling, the one-GPU frame, configs[4]) may take this long together
 PROFILES = os.path.join("profiles", "r4")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
 TRAFFIC_JSON = os.path.join(PROFILES, "c2_bench", "traffic.json")
@@ -459,8 +464,8 @@ def main():
             "scaling": "weak" if not multi else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[1])" % (width, height, spp)) if not multi else
-                                   ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[2]): cyclic 2-row tiles over %d GPUs, "
-                                    "RCCL gather to rank 0 + scatter per step inside the timed region" % (width, height, spp, world)),
+                                   ("AnalyticalScene %dx%d x %d spp per step, f32, seed 1 (BASELINE.json configs[2]): cyclic %d-row tiles over %d GPUs, "
+                                    "RCCL gather to rank 0 + scatter per step inside the timed region" % (width, height, spp, TILE_ROWS, world)),
                        "spp_per_step": spp, "width": width, "height": height, "parallelism": "rows%d" % world,
                        **({"gather": gather_mode} if multi else {})},
             "roofline": roofline,
@@ -520,7 +525,7 @@ def main():
                                        "speedup": round(ts / (elapsed / args.steps), 3), "n_gpus": world,
                                        "note": "same configs[2] frame rendered by rank 0 alone after the timed region (1 step)"}
         # secondary: BASELINE.json configs[4] as written — 10 k spheres + 16 lights, 4096 x 4096 x 512 spp, row-tiled over the N GPUs
-        # (cyclic 2-row blocks), gathered to rank 0: one step, host clock, max over ranks.  The same contexts and communicator: the
+        # (cyclic TILE_ROWS-row blocks), gathered to rank 0: one step, host clock, max over ranks.  The same contexts and communicator: the
         # scene is swapped (Tracer.scene() + upload_scene()).
         if not isinstance(job, TorchGatherRender):
             from rust_pathtracer_amd import scenes
@@ -543,11 +548,11 @@ def main():
             tb = time.perf_counter() - tb
             t = torch.tensor([tb], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            extra["configs4"] = {"workload": "10k spheres + 16 lights %dx%d x %d spp in one step, cyclic 2-row tiles over %d GPUs, gather to rank 0 inside the "
-                                             "timed region (BASELINE.json configs[4])" % (bw, bh, bspp, world),
+            extra["configs4"] = {"workload": "10k spheres + 16 lights %dx%d x %d spp in one step, cyclic %d-row tiles over %d GPUs, gather to rank 0 inside the "
+                                             "timed region (BASELINE.json configs[4])" % (bw, bh, bspp, TILE_ROWS, world),
                                  "steps": 1, "ms_per_step": round(float(t.item()) * 1e3, 3),
                                  "value": round(bw * bh * bspp / float(t.item()) / 1e6, 2), "unit": "Msamples/s",
-                                 "note": "render_large_regen_kernel; the one-GPU figure of the same frame is roofline_c5.value of the N = 1 line"}
+                                 "note": "render_large_regen_kernel_perop; the one-GPU figure of the same frame is roofline_c5.value of the N = 1 line"}
             if tracer:
                 tracer._scene = scene
                 tracer.upload_scene()
@@ -588,7 +593,7 @@ def main():
             why = ""
             try:
                 tracer = tiling.rank_tracer(scene, local_rank, seed=1)
-                first = tiling.TiledRender(tracer, 64, 64, tile_rows=2)       # the communicator's first exchange, on a small frame
+                first = tiling.TiledRender(tracer, 64, 64, tile_rows=TILE_ROWS)       # the communicator's first exchange, on a small frame
                 first.render_n(1)
                 first.gather()
                 del first
@@ -603,9 +608,9 @@ def main():
                 gather_mode = "torch.distributed RCCL gather (fallback: the library communicator failed to initialise%s)" % (
                     ": " + why if why else " on another rank")
         if gather_mode.startswith("torch"):
-            job_of = lambda w, h: TorchGatherRender(tracer, tiling, w, h, 2, rank, world, local_rank)     # noqa: E731
+            job_of = lambda w, h: TorchGatherRender(tracer, tiling, w, h, TILE_ROWS, rank, world, local_rank)     # noqa: E731
         else:
-            job_of = lambda w, h: tiling.TiledRender(tracer, w, h, tile_rows=2) if tracer else None      # noqa: E731
+            job_of = lambda w, h: tiling.TiledRender(tracer, w, h, tile_rows=TILE_ROWS) if tracer else None      # noqa: E731
         job = job_of(width, height)
 
         def step():
@@ -638,7 +643,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        local_pixels = tiling.tile_row_count(height, 2, rank, world) * width
+        local_pixels = tiling.tile_row_count(height, TILE_ROWS, rank, world) * width
         # The headline is measured.  What follows are secondary legs on the same communicator: they must never cost the line.
         # A leg that raises is recorded and ends the legs on this rank; ranks that then wait for it in a collective — or a leg that
         # hangs — are cut off by a timer that emits the line with what there is and leaves.
