@@ -156,3 +156,65 @@ def test_set_dispatch_validates(rpt, torch_cuda):
     assert rpt.lib().rpt_set_dispatch(t._h, 7, 0, 0, 0) == A.RPT_ERR_INVALID_ARG
     assert rpt.lib().rpt_set_dispatch(None, 1, 12, 64, 0) == A.RPT_ERR_INVALID_ARG
     t.close()
+
+
+def test_kernels_that_know_the_table_sizes_equal_the_general_ones(rpt, oracle, torch_cuda):
+    """Scenes with the reference scene's table sizes (2 spheres, 1 plane, 1 light, 3 material patches) take instantiations of the
+    megakernel and of the compacting kernel that know those sizes (kernels.hip, sized_scene); RPT_NO_SIZED_KERNELS=1 takes the general
+    kernels.  Same frames, and the oracle's: for the reference's scene and for one that shares nothing with it but the sizes."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import conftest, torch
+rpt = conftest.load_package()
+from rust_pathtracer_amd import scenes
+def other():
+    s = rpt.AnalyticalScene()
+    s.materials = [scenes.full_material(rgb=(0.9, 0.9, 1.0), roughness=0.03, spec_trans=1.0, ior=1.45),
+                   scenes.full_material(rgb=(0.2, 0.7, 0.3), roughness=0.6, sheen=0.8, subsurface=0.4, emission=(0.3, 0.1, 0.0)),
+                   rpt.Material(rgb=(0.7, 0.7, 0.7), roughness=0.4, metallic=1.0)]
+    s.spheres = [((-0.7, 0.2, 0.4), 0.8, 1), ((0.9, -0.3, -0.2), 0.7, 0)]
+    s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2, 30.0)]
+    s.lights = [rpt.AnalyticalLight.spherical((-2.0, 3.0, 1.0), 0.6, (6.0, 5.0, 4.0))]
+    s.max_depth = 6
+    s.any_hit_uses_max_dist = True
+    return s
+for name, scene in (("reference", rpt.AnalyticalScene()), ("other", other())):
+    t = rpt.Tracer(scene, device=0, seed=3)
+    buf = rpt.DeviceColorBuffer(208, 112)
+    for n in (1, 1, 6, 9):
+        t.render_n(buf, n)
+    torch.cuda.synchronize()
+    print("HASH", name, hashlib.sha1(buf.pixels.cpu().numpy().tobytes()).hexdigest())
+    t.close()
+""" % here
+    out = {}
+    for no_sized in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RPT_NO_SIZED_KERNELS=no_sized), timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[no_sized] = [l for l in r.stdout.splitlines() if l.startswith("HASH")]
+        assert len(out[no_sized]) == 2
+    assert out["0"] == out["1"], "kernels with and without the table sizes differ: %r vs %r" % (out["0"], out["1"])
+    # and against the oracle, in this process (the sized kernels: the default)
+    from rust_pathtracer_amd import scenes
+    s = rpt.AnalyticalScene()
+    s.materials = [scenes.full_material(rgb=(0.9, 0.9, 1.0), roughness=0.03, spec_trans=1.0, ior=1.45),
+                   scenes.full_material(rgb=(0.2, 0.7, 0.3), roughness=0.6, sheen=0.8, subsurface=0.4, emission=(0.3, 0.1, 0.0)),
+                   rpt.Material(rgb=(0.7, 0.7, 0.7), roughness=0.4, metallic=1.0)]
+    s.spheres = [((-0.7, 0.2, 0.4), 0.8, 1), ((0.9, -0.3, -0.2), 0.7, 0)]
+    s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2, 30.0)]
+    s.lights = [rpt.AnalyticalLight.spherical((-2.0, 3.0, 1.0), 0.6, (6.0, 5.0, 4.0))]
+    s.max_depth = 6
+    s.any_hit_uses_max_dist = True
+    want = oracle.render(s.describe(), 120, 72, 7, seed=1)
+    t = rpt.Tracer(s, device=0, seed=1)
+    buf = rpt.DeviceColorBuffer(120, 72)
+    for n in (1, 6):
+        t.render_n(buf, n)
+    torch_cuda.cuda.synchronize()
+    assert_bit_identical(buf.pixels.cpu().numpy(), want, "a scene of the reference's table sizes and nothing else in common")
+    t.close()
