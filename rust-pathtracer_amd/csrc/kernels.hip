@@ -36,6 +36,9 @@
 #define RPT_K(name) name
 #define RPT_LAUNCH_NS rptlaunch
 #endif
+#ifndef RPT_RELAXED_BUILD
+#define RPT_HAS_SIZED_KERNELS         // the instantiations that know table sizes (sized_scene, below): strict builds only
+#endif
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 
@@ -309,24 +312,34 @@ template <class S>
 RPT_DEV const S& kernarg_scene(const S& by_value) { return by_value; }
 #endif
 
-// Table sizes known at compile time.  A small scene's tables are loops over n_spheres / n_planes / n_lights / n_materials entries of
-// the kernarg segment: wave-uniform loops, each entry fetched with scalar loads whose offsets the loop computes and each fetch waited
-// for where it is used.  A kernel that KNOWS the sizes (an assumption on the loaded counts; the host launches it only for scenes that
-// have exactly these sizes) unrolls the loops, merges the loads of neighbouring entries and keeps no loop state: the reference's own
-// scene — 2 spheres, 1 plane, 1 light, 3 material patches (analytical.rs) — has such instantiations of the megakernel and of the
-// compacting kernel; every other small scene takes the kernels with the sizes as data.  Nothing about the arithmetic changes: the
-// same functions run on the same values in the same order.  configs[1] 13.15 -> 13.65 Gsamples/s, no spilled SGPR left (26 before);
-// RPT_NO_SIZED_KERNELS=1 takes the general kernels (tests compare the two).
-template <uint32_t NS, uint32_t NP, uint32_t NL, uint32_t NM>
+// Table sizes known at compile time.  A small scene's tables are loops over n_spheres / n_planes / n_lights entries of the kernarg
+// segment: wave-uniform loops, each entry fetched with scalar loads whose offsets the loop computes and each fetch waited for where it
+// is used.  A kernel that KNOWS the sizes (an assumption on the loaded counts; the host launches it only for scenes that have exactly
+// these sizes) unrolls the loops, merges the loads of neighbouring entries and keeps no loop state:
+//   * 2 spheres, 1 plane, 1 light — the reference's own scene (analytical.rs:15-16, 41, 70, 194) — for the megakernel and the compacting
+//     kernel: configs[1] 13.15 -> 13.65 Gsamples/s, no spilled SGPR left (26 before), one-sample launches +4 ... 6 %.  (Each count
+//     matters: lights alone 13.27, lights + planes 13.48; the number of material patches does not: it stays data.)
+//   * an SDF object of 1, 2, 3 or 4 primitives over 1 plane under 1 light, for the SDF march kernel, whose every march step loops over
+//     the primitives: configs[3] 3.38 -> 3.64 (the primitives alone 3.53).
+// Every other scene takes the kernels with the sizes as data.  Nothing about the arithmetic changes: the same functions run on the same
+// values in the same order.  RPT_NO_SIZED_KERNELS=1 takes the general kernels (tests compare the two).
+template <uint32_t NS, uint32_t NP, uint32_t NL>
 RPT_DEV const SceneSmall& sized_scene(const SceneSmall& s)
 {
     __builtin_assume(s.n_spheres == NS);
     __builtin_assume(s.n_planes == NP);
     __builtin_assume(s.n_lights == NL);
-    __builtin_assume(s.n_materials == NM);
     return s;
 }
-#define RPT_REFERENCE_SIZES 2u, 1u, 1u, 3u                          // AnalyticalScene: analytical.rs:15-16, 41, 70, 194
+#define RPT_REFERENCE_SIZES 2u, 1u, 1u
+template <uint32_t NPRIMS, class S>
+RPT_DEV const S& sized_sdf_scene(const S& s)
+{
+    __builtin_assume(s.sdf.n_prims == NPRIMS);
+    __builtin_assume(s.n_planes == 1u);
+    __builtin_assume(s.n_lights == 1u);
+    return s;
+}
 
 // The shipped library holds ONE nested-loop kernel, the baseline of the reference's own scene class; the other scene classes' only
 // in A/B builds (-DRPT_AB_KERNELS, build.py --ab), where the parity tests run every form against the oracle.
@@ -579,10 +592,12 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(kernarg_scene(sc), rp); }
 #endif
 #ifndef RPT_NO_SMALL_KERNELS
+#ifdef RPT_HAS_SIZED_KERNELS
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_sized_kernel)(const SceneSmall sc, const RenderParams rp)
 {
     render_regen_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
 }
+#endif
 #endif
 #endif
 // Large scenes: same schedule; the scene tables are streamed from HBM (dev_scene_large.h).  5 waves per SIMD: 96 VGPRs, 12 of them
@@ -1036,6 +1051,7 @@ __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_
 // with five per CU and no spill to speak of (round 4, tools/compact_time.py); from 1080p up the five-per-CU build is 1 % faster.
 #ifndef RPT_NO_COMPACT_KERNELS
 __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
+#ifdef RPT_HAS_SIZED_KERNELS
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_sized_kernel)(const SceneSmall sc, const RenderParams rp)
 {
     render_compact_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
@@ -1044,6 +1060,7 @@ __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_sized
 {
     render_compact_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
 }
+#endif
 #endif
 #ifndef RPT_NO_MEDIA_KERNELS
 #ifndef RPT_NO_COMPACT_KERNELS
@@ -1342,6 +1359,11 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch)
 #ifndef RPT_NO_LARGE_SDF_KERNELS
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) 
 void RPT_K(render_sdf_march2_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body(kernarg_scene(sc), rp); }
+#ifdef RPT_HAS_SIZED_KERNELS
+template <uint32_t NPRIMS>
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD)
+void RPT_K(render_sdf_march2_sized_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body(sized_sdf_scene<NPRIMS>(kernarg_scene(sc)), rp); }
+#endif
 #endif
 #ifndef RPT_NO_MEDIA_KERNELS
 #ifndef RPT_NO_LARGE_SDF_KERNELS
@@ -1690,10 +1712,11 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     (void)scs_dev;
     // the kernels that know the reference scene's table sizes (sized_scene, above)
     static const bool no_sized = getenv("RPT_NO_SIZED_KERNELS") && atoi(getenv("RPT_NO_SIZED_KERNELS")) != 0;
-    constexpr uint32_t ref_sizes[4] = {RPT_REFERENCE_SIZES};
+    constexpr uint32_t ref_sizes[3] = {RPT_REFERENCE_SIZES};
     const bool sized = !no_sized && !media && !large && !has_sdf && !nested && sc.n_spheres == ref_sizes[0] && sc.n_planes == ref_sizes[1] &&
-                       sc.n_lights == ref_sizes[2] && sc.n_materials == ref_sizes[3];
-    (void)sized;
+                       sc.n_lights == ref_sizes[2];
+    const uint32_t sized_sdf = (!no_sized && !media && has_sdf && !nested && sc.n_planes == 1u && sc.n_lights == 1u && scs.sdf.n_prims <= 4u) ? scs.sdf.n_prims : 0u;
+    (void)sized; (void)sized_sdf;
 #ifdef RPT_NO_LARGE_SDF_KERNELS
     if (large || has_sdf || (rp.compact && !nested)) return rptlaunch_perop::render(scs, scl, large, nested, rp, nblocks, st, scs_dev, media);   // (the RPT_PEROP_BUILD object)
 #endif
@@ -1747,14 +1770,22 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #endif
 #ifndef RPT_NO_LARGE_SDF_KERNELS
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), tiles, wg, 0, st, scl, rp);
+#ifdef RPT_HAS_SIZED_KERNELS
+    else if (sized_sdf == 1u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<1u>, tiles, wg, 0, st, scs, rp);
+    else if (sized_sdf == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<2u>, tiles, wg, 0, st, scs, rp);
+    else if (sized_sdf == 3u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<3u>, tiles, wg, 0, st, scs, rp);
+    else if (sized_sdf == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<4u>, tiles, wg, 0, st, scs, rp);
+#endif
     else if (has_sdf) hipLaunchKernelGGL(RPT_K(render_sdf_march2_kernel), tiles, wg, 0, st, scs, rp);
 #endif
 #ifndef RPT_NO_SMALL_KERNELS
     else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
 #endif
 #ifndef RPT_NO_COMPACT_KERNELS
+#ifdef RPT_HAS_SIZED_KERNELS
     else if (rp.compact && nblocks <= 3072u && sized) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_sized_kernel), tiles, wg, 0, st, sc, rp);
     else if (rp.compact && sized) hipLaunchKernelGGL(RPT_K(render_small_compact_sized_kernel), tiles, wg, 0, st, sc, rp);
+#endif
     else if (rp.compact && nblocks <= 3072u) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
     else if (rp.compact) hipLaunchKernelGGL(RPT_K(render_small_compact_kernel), tiles, wg, 0, st, sc, rp);
 #endif
@@ -1763,8 +1794,11 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
         // RPT_DEBUG_EXTRA_LDS (bytes, experiments only): pads the workgroup's LDS so that fewer waves fit a CU — how the
         // kernel's throughput depends on resident waves per SIMD (occupancy sensitivity)
         static const unsigned extra_lds = getenv("RPT_DEBUG_EXTRA_LDS") ? (unsigned)atoi(getenv("RPT_DEBUG_EXTRA_LDS")) : 0u;
+#ifdef RPT_HAS_SIZED_KERNELS
         if (sized) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_kernel), tiles, wg, extra_lds, st, sc, rp);
-        else hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, extra_lds, st, sc, rp);
+        else
+#endif
+        hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, extra_lds, st, sc, rp);
     }
 #endif
     return hipGetLastError();

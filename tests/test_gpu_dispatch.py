@@ -159,9 +159,10 @@ def test_set_dispatch_validates(rpt, torch_cuda):
 
 
 def test_kernels_that_know_the_table_sizes_equal_the_general_ones(rpt, oracle, torch_cuda):
-    """Scenes with the reference scene's table sizes (2 spheres, 1 plane, 1 light, 3 material patches) take instantiations of the
-    megakernel and of the compacting kernel that know those sizes (kernels.hip, sized_scene); RPT_NO_SIZED_KERNELS=1 takes the general
-    kernels.  Same frames, and the oracle's: for the reference's scene and for one that shares nothing with it but the sizes."""
+    """Scenes with the reference scene's table sizes (2 spheres, 1 plane, 1 light) take instantiations of the megakernel and of the
+    compacting kernel that know those sizes, SDF objects of 1-4 primitives over one plane under one light instantiations of the march
+    kernel (kernels.hip, sized_scene); RPT_NO_SIZED_KERNELS=1 takes the general kernels.  Same frames — for the reference's scene, for
+    one that shares nothing with it but the sizes, for SDF objects of 1 ... 5 primitives (5: general either way) — and the oracle's."""
     import os
     import subprocess
     import sys
@@ -183,7 +184,15 @@ def other():
     s.max_depth = 6
     s.any_hit_uses_max_dist = True
     return s
-for name, scene in (("reference", rpt.AnalyticalScene()), ("other", other())):
+def blob(n_prims):
+    s = scenes.sdf_scene()
+    prims = list(s.sdf["prims"])
+    A = rpt._abi
+    more = [(A.RPT_SDF_SPHERE, (0.6, 0.5, -0.4), (0.4, 0.0)), (A.RPT_SDF_TORUS_Y, (0.2, 0.3, 0.0), (0.7, 0.12)), (A.RPT_SDF_SPHERE, (-0.2, 0.8, 0.3), (0.3, 0.0))]
+    s.sdf["prims"] = (prims + more)[:n_prims]
+    return s
+cases = [("reference", rpt.AnalyticalScene()), ("other", other())] + [("sdf " + str(n), blob(n)) for n in (1, 2, 3, 4, 5)]
+for name, scene in cases:
     t = rpt.Tracer(scene, device=0, seed=3)
     buf = rpt.DeviceColorBuffer(208, 112)
     for n in (1, 1, 6, 9):
@@ -197,7 +206,7 @@ for name, scene in (("reference", rpt.AnalyticalScene()), ("other", other())):
         r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RPT_NO_SIZED_KERNELS=no_sized), timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         out[no_sized] = [l for l in r.stdout.splitlines() if l.startswith("HASH")]
-        assert len(out[no_sized]) == 2
+        assert len(out[no_sized]) == 7
     assert out["0"] == out["1"], "kernels with and without the table sizes differ: %r vs %r" % (out["0"], out["1"])
     # and against the oracle, in this process (the sized kernels: the default)
     from rust_pathtracer_amd import scenes
@@ -218,3 +227,14 @@ for name, scene in (("reference", rpt.AnalyticalScene()), ("other", other())):
     torch_cuda.cuda.synchronize()
     assert_bit_identical(buf.pixels.cpu().numpy(), want, "a scene of the reference's table sizes and nothing else in common")
     t.close()
+    for n_prims in (1, 2, 4):                                         # (3: scenes.sdf_scene itself, in test_gpu_parity)
+        s = scenes.sdf_scene()
+        A = rpt._abi
+        s.sdf["prims"] = (list(s.sdf["prims"]) + [(A.RPT_SDF_SPHERE, (0.6, 0.5, -0.4), (0.4, 0.0))])[:n_prims]
+        want = oracle.render(s.describe(), 96, 56, 4, seed=1)
+        t = rpt.Tracer(s, device=0, seed=1)
+        buf = rpt.DeviceColorBuffer(96, 56)
+        t.render_n(buf, 4)
+        torch_cuda.cuda.synchronize()
+        assert_bit_identical(buf.pixels.cpu().numpy(), want, "SDF object of %d primitives" % n_prims)
+        t.close()
