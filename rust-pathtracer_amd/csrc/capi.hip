@@ -1027,6 +1027,8 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         const size_t sz_lsph = sizeof(float) * lsph.size(), sz_lids = (sizeof(uint32_t) * lids.size() + 15) & ~(size_t)15;
         const size_t sz_tables = sz_sph + sz_smat + sz_lights + sz_mats + sz_lsph + sz_lids;
         const size_t sz_accel = accel.bytes();
+        // every table is addressed with 32-bit byte offsets from its own base (dev_scene_large.h, gather32)
+        if ((uint64_t)sz_tables + sz_accel >= (1ull << 32)) { set_err(ctx, "rpt_upload_scene: the scene's tables exceed 4 GiB"); return RPT_ERR_UNSUPPORTED; }
         std::vector<unsigned char> host(sz_tables + sz_accel, 0);
         float4* h_sph = reinterpret_cast<float4*>(host.data());
         uint32_t* h_smat = reinterpret_cast<uint32_t*>(host.data() + sz_sph);

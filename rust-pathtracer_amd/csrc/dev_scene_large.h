@@ -35,6 +35,21 @@ using namespace rptscene;
 typedef const RPT_CONST_AS float* cfloat_p;
 typedef const RPT_CONST_AS uint32_t* cuint_p;
 
+// A per-lane gather from one of the scene's tables with a 32-BIT byte offset: `base + zext(index * sizeof(T))` is what a global load with
+// a scalar base and a vector offset addresses (global_load ... v_off, s[base:base+1]) — one 32-bit multiply / shift and ONE address
+// register per lane.  `table[index]` is base + zext(index) * sizeof(T), 34 and more bits, so the compiler builds a 64-bit address in
+// two registers with v_lshl_add_u64 behind a v_mov 0 for every load of a walk.  The tables are far below 4 GiB (rpt_upload_scene checks).
+template <class T>
+RPT_DEV T gather32(const T* table, uint32_t index)
+{
+#ifdef RPT_GATHER_PLAIN
+    return table[index];
+#else
+    const uint32_t off = index * (uint32_t)sizeof(T);
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(table) + off);
+#endif
+}
+
 RPT_DEV float4 sphere_uniform(const SceneLarge& sc, uint32_t i)     // i wave-uniform -> scalar load
 {
     cfloat_p p = (cfloat_p)sc.spheres + 4u * i;
@@ -73,7 +88,7 @@ RPT_DEV DevMaterial material_uniform(const SceneLarge& sc, uint32_t i)
 
 RPT_DEV DevLight light_at(const SceneLarge& sc, uint32_t index)     // per-lane index -> gather
 {
-    return sc.lights[index];
+    return gather32(sc.lights, index);
 }
 
 // ---------------------------------------------------------------------------
@@ -192,7 +207,7 @@ RPT_DEV void cell_bounds(const SceneLarge& sc, uint32_t c, uint32_t& k0, uint32_
     k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1];
 #else
     struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
-    const Pair r = *reinterpret_cast<const Pair*>(sc.cell_start + c);
+    const Pair r = *reinterpret_cast<const Pair*>(reinterpret_cast<const char*>(sc.cell_start) + c * 4u);      // (a 32-bit byte offset: gather32)
     k0 = r.a; k1 = r.b;
 #endif
 }
@@ -285,7 +300,7 @@ RPT_DEV void closest_walk_fetch(const SceneLarge& sc, ClosestWalk& w, uint32_t c
 {
     cell_bounds(sc, cell, w.k0, w.k1);
 #pragma unroll
-    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = sc.cell_spheres[w.k0 + j];     // (the array ends in spare entries: host_grid.h)
+    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = gather32(sc.cell_spheres, w.k0 + j);     // (the array ends in spare entries: host_grid.h)
 }
 
 // One cell of the walk: true when the walk is over (nothing beyond this cell can be nearer, or the ray leaves the grid box here).
@@ -321,7 +336,7 @@ RPT_DEV bool closest_walk_cell(const SceneLarge& sc, const RayD& ray, ClosestWal
         const float t1 = tca + thc;
         const float t = t0 < 0.0f ? t1 : t0;
         if (!(t < 0.0f) && t <= dist) {
-            const uint32_t i = sc.cell_items[kk];
+            const uint32_t i = gather32(sc.cell_items, kk);
             if (i != 0u && (t < dist || i < best)) { dist = t; best = i; hit_w = 1u; }
         }
     };
@@ -342,7 +357,7 @@ RPT_DEV bool closest_walk_cell(const SceneLarge& sc, const RayD& ray, ClosestWal
     for (uint32_t k = k0 + RPT_GRID_BATCH; k < k1; k += RPT_GRID_BATCH) {
         float4 sp[RPT_GRID_BATCH];
 #pragma unroll
-        for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) sp[j] = sc.cell_spheres[k + j];
+        for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) sp[j] = gather32(sc.cell_spheres, k + j);
         test_batch(sp, k);
     }
     if (c_k != 0xFFFFFFFFu) resolve(c_tca, c_rd, c_k);
@@ -350,7 +365,7 @@ RPT_DEV bool closest_walk_cell(const SceneLarge& sc, const RayD& ray, ClosestWal
     if (last) return true;
     w.k0 = n0; w.k1 = n1;
 #pragma unroll
-    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = sc.cell_spheres[n0 + j];
+    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = gather32(sc.cell_spheres, n0 + j);
     return false;
 }
 
@@ -377,7 +392,7 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
     w.k0 = 0; w.k1 = 0;
     if (w.g.alive) cell_bounds(sc, grid_cell_index(sc, w.g), w.k0, w.k1);
 #pragma unroll
-    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = sc.cell_spheres[w.k0 + j];
+    for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) w.pf[j] = gather32(sc.cell_spheres, w.k0 + j);
     if (w.g.alive)
     for (uint32_t guard = grid_walk_guard(sc); guard != 0u; --guard)
         if (closest_walk_cell(sc, ray, w, dist, best, hit_w)) break;
@@ -412,7 +427,7 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
             bool cand[RPT_GRID_BATCH_ANY];
             bool any_cand = false;
 #pragma unroll
-            for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) sp[j] = sc.cell_spheres[k + j];     // (requested a cell ahead as in the closest walk: -6 %)
+            for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) sp[j] = gather32(sc.cell_spheres, k + j);     // (requested a cell ahead as in the closest walk: -6 %)
 #pragma unroll
             for (uint32_t j = 0; j < RPT_GRID_BATCH_ANY; ++j) {
                 const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
@@ -543,7 +558,7 @@ RPT_DEV void material_large(const SceneLarge& sc, const RayD& ray, uint32_t code
     const uint32_t accepted_planes = code >> 28;
     mat_defaults(mat);
     if (best != kNoSphere) {                                        // the nearest sphere's full patch
-        const DevMaterial m = sc.materials[sc.sphere_material[best]];
+        const DevMaterial m = gather32(sc.materials, gather32(sc.sphere_material, best));
         mat.rgb = mk3(m.rgb[0], m.rgb[1], m.rgb[2]);
         mat.emission = mk3(m.emission[0], m.emission[1], m.emission[2]);
         mat.anisotropic = m.anisotropic; mat.metallic = m.metallic; mat.roughness = m.roughness;
@@ -563,7 +578,7 @@ RPT_DEV v3 hit_emission(const SceneLarge& sc, const GeomHit& g)
     const uint32_t accepted_planes = g.code >> 28;
     v3 em = mk3(0.0f, 0.0f, 0.0f);
     if (best != kNoSphere) {
-        const DevMaterial& m = sc.materials[sc.sphere_material[best]];
+        const DevMaterial m = gather32(sc.materials, gather32(sc.sphere_material, best));
         em = mk3(m.emission[0], m.emission[1], m.emission[2]);
     }
     for (uint32_t k = 0; k < sc.n_planes; ++k) {
@@ -587,7 +602,7 @@ RPT_DEV v3 normal_large(const SceneLarge& sc, const RayD& ray, float dist, const
     const bool win_plane = accepted_planes != 0u;
     v3 c = mk3(0.0f, 0.0f, 0.0f);
     if (!win_plane && best != kNoSphere) {
-        const float4 s = sc.spheres[best];                          // per-lane gather
+        const float4 s = gather32(sc.spheres, best);                    // per-lane gather
         c = mk3(s.x, s.y, s.z);
     }
     v3 hp = ray.o + dist * ray.d;
@@ -603,7 +618,7 @@ RPT_DEV uint32_t hit_medium_index(const SceneLarge& sc, const GeomHit& g)
     const uint32_t accepted_planes = g.code >> 28;
     uint32_t idx = kNoMediumIdx;
     if (best != kNoSphere) {
-        const uint32_t mi = sc.sphere_material[best];
+        const uint32_t mi = gather32(sc.sphere_material, best);
         if (sc.materials[mi].mask & RPT_MAT_MEDIUM) idx = mi;
     }
     for (uint32_t k = 0; k < sc.n_planes; ++k) {
