@@ -4,7 +4,7 @@ python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -40 $O/tests.l
 tail -2 $O/tests.log
 RPT_LIB=$PWD/rust-pathtracer_amd/librpt_hip_ab.so python -m pytest tests -m gpu -x -q > $O/tests_ab.log 2>&1 || { tail -40 $O/tests_ab.log; exit 1; }
 tail -2 $O/tests_ab.log
-python tools/tile_rows_time.py 1024 2 > $O/tile_rows.txt 2>&1
+for tr in 1 2 4 8 16; do python tools/tile_rows_time.py 1024 $tr >> $O/tile_rows.txt 2>&1; done
 python tools/launch_size_time.py > $O/launch_size.txt 2>&1
 python tools/host_path_time.py > $O/host_path.txt 2>&1
 python tools/compact_time.py 800 600 1 400 > $O/compact.txt 2>&1
