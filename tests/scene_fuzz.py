@@ -5,8 +5,9 @@ library's short divide / square root are proven for (csrc/dev_math.h)."""
 import numpy as np
 
 
-def random_small_scene(rpt, seed):
-    """-> (scene, log2 of its scale, render flags, rng)"""
+def random_small_scene(rpt, seed, n_spheres=None, n_lights=None):
+    """-> (scene, log2 of its scale, render flags, rng).  n_spheres / n_lights: fixed table sizes (the reference's are 2 and 1: scenes that
+    take the kernels which know those sizes, kernels.hip sized_scene); None: random."""
     from rust_pathtracer_amd import scenes
     from rust_pathtracer_amd.api import Pinhole, Scene
     A = rpt._abi
@@ -26,10 +27,10 @@ def random_small_scene(rpt, seed):
                                                 sheen=float(rng.uniform(0, 1)), subsurface=float(rng.uniform(0, 1))))
     s.materials.append(rpt.Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1)))
     s.spheres = [((f(rng.uniform(-2.5, 2.5)), f(rng.uniform(-0.5, 1.5)), f(rng.uniform(-2.5, 1.0))), f(rng.uniform(0.3, 1.0)), int(rng.integers(0, len(s.materials) - 1)))
-                 for _ in range(int(rng.integers(1, 9)))]
+                 for _ in range(n_spheres if n_spheres else int(rng.integers(1, 9)))]
     s.planes = [((0.0, 1.0, 0.0), (0.0, f(-1.0), 0.0), 0.0001, len(s.materials) - 1)]
     s.lights = [rpt.AnalyticalLight.spherical((f(rng.uniform(-4, 4)), f(rng.uniform(2, 5)), f(rng.uniform(-2, 4))), f(rng.uniform(0.3, 1.2)),
-                                              tuple(float(x) for x in rng.uniform(1.0, 6.0, 3))) for _ in range(int(rng.integers(1, 5)))]
+                                              tuple(float(x) for x in rng.uniform(1.0, 6.0, 3))) for _ in range(n_lights if n_lights else int(rng.integers(1, 5)))]
     s.eps = f(0.005)
     s.max_depth = int(rng.integers(1, 9))
     s.any_hit_uses_max_dist = bool(rng.random() < 0.5)
