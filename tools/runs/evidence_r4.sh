@@ -1,5 +1,5 @@
 set -e
-O=gpurun_out/r4av; mkdir -p $O
+O=gpurun_out/evidence_r4; mkdir -p $O
 python -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
 RPT_LIB=$PWD/rust-pathtracer_amd/librpt_hip_ab.so python -m pytest tests -m gpu -x -q > $O/tests_ab.log 2>&1 || { tail -40 $O/tests_ab.log; exit 1; }
