@@ -50,6 +50,9 @@ TRAFFIC_JSON = os.path.join(PROFILES, "c2_bench", "traffic.json")
 # other kernels test next to the operation (v_max3, v_frexp_exp, two compares; subtract + compare for a root): 11 / 7.3 — 9 is used —
 # and 7.  (Rounds 1-3 priced both at hipcc's expansions, 12 and 15, which the library no longer executes.)
 DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS = 9, 7
+# VALU wave-instructions per SIMD per quad-cycle (at 2.4 GHz) of a kernel of nothing but independent v_fma_f32 chains at 5 waves per SIMD:
+# what the hardware issues at the render kernels' occupancy (tools/microbench/valu_issue_peak.hip, profiles/r4/valu_issue_peak.txt)
+VALU_ISSUE_CEILING = 1.48
 DIV_INSTRUCTIONS_TRACKED, SQRT_INSTRUCTIONS_TRACKED = 8, 7
 
 
@@ -454,9 +457,11 @@ def main():
                     "insts_per_launch": t["valu_insts_per_launch"], "lane_utilisation": round(t.get("valu_lane_utilisation", 0.0), 3),
                     "insts_per_simd_quad_cycle": round(t["valu_insts_per_launch"] / simd_quads, 3),
                     "frac_of_dual_issue_peak": round(t["valu_insts_per_launch"] / simd_quads / 2.0, 3),
-                    "note": "VALU wave-instructions per SIMD per 4 cycles (rocprofv3's VALUBusy / 100); 2.0 is the issue peak, "
-                            "reached only with every instruction dual-issued and no dependency or memory stall; x lane_utilisation "
-                            "= the share of the ALU lanes doing path work"}
+                    "measured_fma_only_ceiling": VALU_ISSUE_CEILING,
+                    "frac_of_measured_ceiling": round(t["valu_insts_per_launch"] / simd_quads / VALU_ISSUE_CEILING, 3),
+                    "note": "VALU wave-instructions per SIMD per 4 cycles (rocprofv3's VALUBusy / 100); 2.0 is the nominal issue peak; a "
+                            "kernel of nothing but independent fused multiply-adds reaches measured_fma_only_ceiling at this occupancy "
+                            "(profiles/r4/valu_issue_peak.txt); x lane_utilisation = the share of the ALU lanes doing path work"}
         out = {
             "metric": "Msamples/s (pixels x spp) on AnalyticalScene 1920x1080 f32; 1/2/4/8-GPU scaling",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
