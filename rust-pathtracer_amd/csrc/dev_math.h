@@ -234,13 +234,14 @@ RPT_DEV v3 mix3(v3 a, v3 b, float v)                                            
 }
 RPT_DEV float mixf(float a, float b, float v) { return (1.0f - v) * a + b * v; }   // tracer.rs:229
 
-// f32::max: a NaN operand yields the other one.
+// f32::max as the oracle restates it: a NaN operand yields the other one; equal operands (+0 and -0 too) yield `other`.
+// (self > other) ? self : other already answers a NaN `self` (the compare fails: other); a NaN `other` needs the second select — unless
+// `self` is a literal, where (other >= self) ? other : self does both in one compare: two instructions instead of six.
 RPT_DEV float rmax(float self, float other)
 {
-    float r = (self > other) ? self : other;
-    r = (other != other) ? self : r;
-    r = (self != self) ? other : r;
-    return r;
+    if (__builtin_constant_p(self) && self == self) return (other >= self) ? other : self;
+    const float r = (self > other) ? self : other;
+    return (other != other) ? self : r;
 }
 // f32::clamp(0, 1): NaN stays NaN.
 RPT_DEV float clamp01(float x)
