@@ -86,6 +86,21 @@ RPT_HD float rpt_sinf(float x) { float s, c; rpt_sincosf(x, &s, &c); return s; }
 RPT_HD float rpt_cosf(float x) { float s, c; rpt_sincosf(x, &s, &c); return c; }
 RPT_HD float rpt_tanf(float x) { float s, c; rpt_sincosf(x, &s, &c); return s / c; }
 
+/* One Horner step p * f + c with a literal coefficient.  On the device the coefficient is asked for in a SCALAR register pair: left to
+ * itself the compiler takes v_fmac_f64, whose addend is the destination, and fills that with two v_mov_b32 per coefficient — vector
+ * instructions that do no arithmetic (two per f64 step of every log2 / exp2; the render kernels are bound by vector instruction issue
+ * and the scalar unit has room).  The same fused multiply-add on the same values either way. */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RPT_STRICT_MATH_PLAIN_HORNER)
+static __device__ __forceinline__ double rpt_horner(double p, double f, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(f), "s"(c));
+    return r;
+}
+#else
+#define rpt_horner(p, f, c) __builtin_fma((p), (f), (c))
+#endif
+
 /* ---- log2 core in f64 ------------------------------------------------------
  * x > 0 finite.  x = m * 2^e with m in [sqrt(1/2), sqrt(2)), f = m - 1,
  * log2(x) = e + f * P(f), P of degree 13 (abs error 1.5e-12).               */
@@ -102,19 +117,19 @@ RPT_HD double rpt_log2_core(float x)
     float m = rpt_u2f(ix - ((uint32_t)e << 23));
     double f = (double)m - 1.0;
     double p = -0x1.16c9192143833p-4;
-    p = __builtin_fma(p, f, 0x1.0c91c8ec04459p-3);
-    p = __builtin_fma(p, f, -0x1.140c67e94fcdep-3);
-    p = __builtin_fma(p, f, 0x1.0b872a83448f7p-3);
-    p = __builtin_fma(p, f, -0x1.23e34ff2dfed7p-3);
-    p = __builtin_fma(p, f, 0x1.480da32d9077ap-3);
-    p = __builtin_fma(p, f, -0x1.7186b110dbb40p-3);
-    p = __builtin_fma(p, f, 0x1.a61c50cd4bc62p-3);
-    p = __builtin_fma(p, f, -0x1.ec6f47f38905dp-3);
-    p = __builtin_fma(p, f, 0x1.2776b48f57946p-2);
-    p = __builtin_fma(p, f, -0x1.7154784e5d08ep-2);
-    p = __builtin_fma(p, f, 0x1.ec709de7df48dp-2);
-    p = __builtin_fma(p, f, -0x1.71547651d9376p-1);
-    p = __builtin_fma(p, f, 0x1.71547652b5270p+0);
+    p = rpt_horner(p, f, 0x1.0c91c8ec04459p-3);
+    p = rpt_horner(p, f, -0x1.140c67e94fcdep-3);
+    p = rpt_horner(p, f, 0x1.0b872a83448f7p-3);
+    p = rpt_horner(p, f, -0x1.23e34ff2dfed7p-3);
+    p = rpt_horner(p, f, 0x1.480da32d9077ap-3);
+    p = rpt_horner(p, f, -0x1.7186b110dbb40p-3);
+    p = rpt_horner(p, f, 0x1.a61c50cd4bc62p-3);
+    p = rpt_horner(p, f, -0x1.ec6f47f38905dp-3);
+    p = rpt_horner(p, f, 0x1.2776b48f57946p-2);
+    p = rpt_horner(p, f, -0x1.7154784e5d08ep-2);
+    p = rpt_horner(p, f, 0x1.ec709de7df48dp-2);
+    p = rpt_horner(p, f, -0x1.71547651d9376p-1);
+    p = rpt_horner(p, f, 0x1.71547652b5270p+0);
     return __builtin_fma(p, f, (double)(e + eadj));
 }
 
@@ -127,15 +142,15 @@ RPT_HD float rpt_exp2_core(double t)
     int32_t n = (int32_t)kd;                            /* |kd| <= 200: exact */
     double r = t - kd;                                  /* r in [-0.5, 0.5] */
     double p = 0x1.b6571de2f2351p-24;
-    p = __builtin_fma(p, r, 0x1.63ef969a64d3cp-20);
-    p = __builtin_fma(p, r, 0x1.ffcb76789860fp-17);
-    p = __builtin_fma(p, r, 0x1.43088e257f341p-13);
-    p = __builtin_fma(p, r, 0x1.5d87fe908f88ap-10);
-    p = __builtin_fma(p, r, 0x1.3b2ab72b175eep-7);
-    p = __builtin_fma(p, r, 0x1.c6b08d7044119p-5);
-    p = __builtin_fma(p, r, 0x1.ebfbdff8149f2p-3);
-    p = __builtin_fma(p, r, 0x1.62e42fefa39f7p-1);
-    p = __builtin_fma(p, r, 0x1.000000000003dp+0);
+    p = rpt_horner(p, r, 0x1.63ef969a64d3cp-20);
+    p = rpt_horner(p, r, 0x1.ffcb76789860fp-17);
+    p = rpt_horner(p, r, 0x1.43088e257f341p-13);
+    p = rpt_horner(p, r, 0x1.5d87fe908f88ap-10);
+    p = rpt_horner(p, r, 0x1.3b2ab72b175eep-7);
+    p = rpt_horner(p, r, 0x1.c6b08d7044119p-5);
+    p = rpt_horner(p, r, 0x1.ebfbdff8149f2p-3);
+    p = rpt_horner(p, r, 0x1.62e42fefa39f7p-1);
+    p = rpt_horner(p, r, 0x1.000000000003dp+0);
     uint64_t bits = rpt_d2u(p) + ((uint64_t)(int64_t)n << 52);   /* exact scaling by 2^n */
     return (float)rpt_u2d(bits);                        /* single rounding to f32 (inf / subnormal handled by the conversion) */
 }

@@ -36,6 +36,11 @@
 #define RPT_K(name) name
 #define RPT_LAUNCH_NS rptlaunch
 #endif
+#if defined(RPT_PEROP_BUILD) || defined(RPT_AB_KERNELS) || defined(RPT_RELAXED_BUILD) || defined(RPT_GUARD_PER_OP)
+// (include/rpt_strict_math.h: the f64 polynomials' coefficients as literals.  In scalar registers they save small scenes' megakernel two
+// vector moves per step, +2.2 %; the large-scene kernel, short of scalar registers and scalar issue as it is, loses 5 % with them.)
+#define RPT_STRICT_MATH_PLAIN_HORNER
+#endif
 #ifndef RPT_RELAXED_BUILD
 #define RPT_HAS_SIZED_KERNELS         // the instantiations that know table sizes (sized_scene, below): strict builds only
 #endif
