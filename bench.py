@@ -438,7 +438,7 @@ def main():
         algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
         hbm = algo_bytes / avg_kernel_s / 1e9
         launches = 1                              # one launch whatever spp is (kernels.hip: a launch is tiles x chunks of samples)
-        kernel = "render_small_regen_sized_kernel" if spp > 1 else "render_small_compact_sized_kernel_perop"     # (capi.hip: RPT_COMPACT_MAX_SPP; kernels.hip: sized_scene)
+        kernel = "render_small_regen_sized_table_kernel" if spp > 1 else "render_small_compact_sized_kernel_perop"     # (capi.hip: RPT_COMPACT_MAX_SPP; kernels.hip: sized_scene)
         roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels, tracked=spp > 1)
         roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
                             "rounded f32 divide or sqrt costs 8-13 VALU instructions in this library (ieee_expanded_*); kernel_ms = HIP events on the launch stream")

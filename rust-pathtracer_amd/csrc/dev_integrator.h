@@ -79,7 +79,7 @@ RPT_DEV bool hit_plane(const RayD& ray, const DevPlane& p, float& t)
 // Overlay one material patch on `m` for the lanes where `on` holds: the field
 // writes of analytical.rs:56-58 / 82-85 / 115-116.  The patch and its mask are
 // wave-uniform (SGPRs); only the select is per lane.
-RPT_DEV void apply_patch(Mat& m, const DevMaterial& p, bool on, v3 dir)
+RPT_DEV void apply_patch_fields(Mat& m, const DevMaterial& p, bool on)
 {
     if (p.mask & RPT_MAT_RGB) { m.rgb.x = on ? p.rgb[0] : m.rgb.x; m.rgb.y = on ? p.rgb[1] : m.rgb.y; m.rgb.z = on ? p.rgb[2] : m.rgb.z; }
     if (p.mask & RPT_MAT_EMISSION) { m.emission.x = on ? p.emission[0] : m.emission.x; m.emission.y = on ? p.emission[1] : m.emission.y; m.emission.z = on ? p.emission[2] : m.emission.z; }
@@ -94,13 +94,33 @@ RPT_DEV void apply_patch(Mat& m, const DevMaterial& p, bool on, v3 dir)
     if (p.mask & RPT_MAT_CLEARCOAT_GLOSS) m.clearcoat_gloss = on ? p.clearcoat_gloss : m.clearcoat_gloss;
     if (p.mask & RPT_MAT_SPEC_TRANS) m.spec_trans = on ? p.spec_trans : m.spec_trans;
     if (p.mask & RPT_MAT_IOR) m.ior = on ? p.ior : m.ior;
+}
+// The checker of analytical.rs:107-115 along a ray's direction: true on the squares of the SECOND colour (proc_params[3]).
+RPT_DEV bool checker_second(const DevMaterial& p, v3 dir)
+{
+    float x = fdiv(dir.x, dir.y) * p.proc_params[0] + p.proc_params[1];
+    float y = fdiv(dir.z, dir.y) * p.proc_params[0] + p.proc_params[1];
+    float x1 = rem2(__builtin_floorf(x));
+    float y1 = rem2(__builtin_floorf(y));
+    return !(rem2(x1 + y1) < 1.0f);
+}
+RPT_DEV void apply_patch(Mat& m, const DevMaterial& p, bool on, v3 dir)
+{
+    apply_patch_fields(m, p, on);
     if (p.proc_kind == RPT_PROC_CHECKER_DIR) {                      // analytical.rs:107-115
         if (on) {
-            float x = fdiv(dir.x, dir.y) * p.proc_params[0] + p.proc_params[1];
-            float y = fdiv(dir.z, dir.y) * p.proc_params[0] + p.proc_params[1];
-            float x1 = rem2(__builtin_floorf(x));
-            float y1 = rem2(__builtin_floorf(y));
-            float c = (rem2(x1 + y1) < 1.0f) ? p.proc_params[2] : p.proc_params[3];
+            float c = checker_second(p, dir) ? p.proc_params[3] : p.proc_params[2];
+            m.rgb = mk3(c, c, c);
+        }
+    }
+}
+// The same patch for a row of a material table (MaterialTable, below): which of the checker's two colours is the row's, not the ray's.
+RPT_DEV void apply_patch_row(Mat& m, const DevMaterial& p, bool on, bool second)
+{
+    apply_patch_fields(m, p, on);
+    if (p.proc_kind == RPT_PROC_CHECKER_DIR) {
+        if (on) {
+            float c = second ? p.proc_params[3] : p.proc_params[2];
             m.rgb = mk3(c, c, c);
         }
     }
@@ -651,6 +671,73 @@ struct DirectQuery {
     RPT_DEV void park(v3) const {}
 };
 
+// Where SHADE takes the material of a hit from.  The reference builds it at every hit: Material::new(), the accepted primitives'
+// writes, State::finalize, and then — in disney_sample and again in disney_eval — the specular and sheen colours (material_small,
+// mat_finalize, get_spec_color).  All of it is a function of WHICH primitives were accepted, of which colour of a checker the ray
+// looks at, and of the side the ray comes from (eta): a handful of cases when the scene has a handful of primitives.
+struct MaterialPerHit {
+    static constexpr bool kTable = false;
+};
+// A kernel for NS spheres and NP planes (kernels.hip, sized_scene) computes every case once per workgroup, with the same functions,
+// into 2^(NS + NP + 2) rows of LDS (material_table_build) and SHADE reads its row: 8 x ds_read_b128 for what was ~45 selects behind
+// uniform branches on the patches' masks, a square root and nine divides.  The checker itself stays per ray.
+// Row index: accepted spheres | accepted planes << NS | second colour << (NS + NP) | (normal . ray < 0) << (NS + NP + 1).
+// The host launches such a kernel only when at most ONE primitive's material is procedural (one bit for "second colour").
+constexpr uint32_t kMatRowFloat4s = 8u;
+template <uint32_t NS, uint32_t NP>
+struct MaterialTable {
+    static constexpr bool kTable = true;
+    static constexpr uint32_t kRows = 1u << (NS + NP + 2u);
+    const float4* rows;
+    template <class S>
+    RPT_DEV void fetch(const S& sc, const RayD& ray, uint32_t accepted, bool ndd_negative, Mat& m, float& eta, v3& spec_col, v3& sheen_col) const
+    {
+        bool second = false;
+        for (uint32_t i = 0; i < NS; ++i) {
+            const DevMaterial& pm = sc.materials[sc.spheres[i].material];
+            if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { if ((accepted >> i) & 1u) second = checker_second(pm, ray.d); }
+        }
+        for (uint32_t k = 0; k < NP; ++k) {
+            const DevMaterial& pm = sc.materials[sc.planes[k].material];
+            if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { if ((accepted >> (kMaxSpheres + k)) & 1u) second = checker_second(pm, ray.d); }
+        }
+        const uint32_t row = (accepted & ((1u << NS) - 1u)) | (((accepted >> kMaxSpheres) & ((1u << NP) - 1u)) << NS) |
+                             ((second ? 1u : 0u) << (NS + NP)) | ((ndd_negative ? 1u : 0u) << (NS + NP + 1u));
+        const float4* r = rows + row * kMatRowFloat4s;
+        const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6];
+        m.rgb = mk3(a.x, a.y, a.z);                 m.metallic = a.w;
+        m.emission = mk3(b.x, b.y, b.z);            m.roughness = b.w;
+        spec_col = mk3(c.x, c.y, c.z);              m.subsurface = c.w;
+        sheen_col = mk3(d.x, d.y, d.z);             m.sheen = d.w;
+        m.clearcoat = e.x; m.clearcoat_roughness = e.y; m.spec_trans = e.z; m.ior = e.w;
+        m.ax = f.x; m.ay = f.y; eta = f.z; m.specular_tint = f.w;
+        m.sheen_tint = g.x; m.anisotropic = g.y; m.clearcoat_gloss = g.z;
+    }
+};
+// One row of that table (the lane that owns it calls this; any pass's functions: the row holds their results).
+template <uint32_t NS, uint32_t NP, class S>
+RPT_DEV void material_table_row(const S& sc, uint32_t row, float4* rows)
+{
+    const bool second = (row >> (NS + NP)) & 1u, ndd_negative = (row >> (NS + NP + 1u)) & 1u;
+    Mat m;
+    mat_defaults(m);
+    for (uint32_t i = 0; i < NS; ++i) apply_patch_row(m, sc.materials[sc.spheres[i].material], (row >> i) & 1u, second);
+    for (uint32_t k = 0; k < NP; ++k) apply_patch_row(m, sc.materials[sc.planes[k].material], (row >> (NS + k)) & 1u, second);
+    mat_finalize(m);
+    const float eta = ndd_negative ? fdiv(1.0f, m.ior) : m.ior;
+    v3 spec_col, sheen_col;
+    get_spec_color(m, eta, spec_col, sheen_col);
+    float4* r = rows + row * kMatRowFloat4s;
+    r[0] = make_float4(m.rgb.x, m.rgb.y, m.rgb.z, m.metallic);
+    r[1] = make_float4(m.emission.x, m.emission.y, m.emission.z, m.roughness);
+    r[2] = make_float4(spec_col.x, spec_col.y, spec_col.z, m.subsurface);
+    r[3] = make_float4(sheen_col.x, sheen_col.y, sheen_col.z, m.sheen);
+    r[4] = make_float4(m.clearcoat, m.clearcoat_roughness, m.spec_trans, m.ior);
+    r[5] = make_float4(m.ax, m.ay, eta, m.specular_tint);
+    r[6] = make_float4(m.sheen_tint, m.anisotropic, m.clearcoat_gloss, 0.0f);
+    r[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
 // Head of direct_light (tracer.rs:130-145): pick a light, sample it.  Returns the facing test of tracer.rs:147.
 // OFFSET false: the estimate is taken at a point inside a medium (media, dev_media.h): scatter_pos is `fhp` itself.
 template <bool OFFSET = true, class S>
@@ -886,8 +973,9 @@ RPT_DEV bool path_shade_medium(const S& sc, const Q& q, PathRegs& p, const volat
 // `n_pre`: the normal when the caller already has it (the march kernel needs it before the shadow march); `cold`: the
 // hit point parked in LDS when p.ray.o no longer holds the path's origin (the march kernel lends it to the shadow
 // march).  Both null: everything is rebuilt from the unchanged ray and p.ps.hit_dist.
-template <class S, class Q>
-RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit& g, const v3* n_pre = nullptr, const volatile float4* cold = nullptr)
+template <class S, class Q, class M = MaterialPerHit>
+RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit& g, const v3* n_pre = nullptr, const volatile float4* cold = nullptr,
+                             const M& materials = M{})
 {
     if constexpr (S::kMedia) {
         if (p.medium & kMediumScatterNow) return path_shade_medium(sc, q, p, cold);
@@ -898,7 +986,12 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
     const v3 ffnormal = mk3(front ? normal.x : -normal.x, front ? normal.y : -normal.y, front ? normal.z : -normal.z);
     Mat mat;
     float eta;
-    {
+    ShadeFrame fr;
+    if constexpr (M::kTable) {
+        RPT_PROF(PB_FINALIZE);
+        materials.fetch(sc, p.ray, g.code, ndd < 0.0f, mat, eta, fr.spec_col, fr.sheen_col);
+        p.radiance = p.radiance + mat.emission * p.throughput;
+    } else {
         RPT_PROF(PB_FINALIZE);
         hit_material(sc, p.ray, g, mat);
         mat_finalize(mat);
@@ -906,8 +999,14 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
         p.radiance = p.radiance + mat.emission * p.throughput;
     }
     const v3 fhp = cold ? mk3(cold->x, cold->y, cold->z) : (p.ray.o + p.ps.hit_dist * p.ray.d);
-    ShadeFrame fr;
-    { RPT_PROF(PB_FRAME); fr = make_frame(mat, eta, -p.ray.d, ffnormal); }
+    if constexpr (M::kTable) {
+        RPT_PROF(PB_FRAME);
+        onb(ffnormal, fr.t, fr.b);
+        fr.v = to_local(fr.t, fr.b, ffnormal, -p.ray.d);
+    } else {
+        RPT_PROF(PB_FRAME);
+        fr = make_frame(mat, eta, -p.ray.d, ffnormal);
+    }
     {
         NeeQuery nq = nee_query(sc, q, fhp, ffnormal, p.rng, p.throughput);
         if constexpr (S::kMedia) {

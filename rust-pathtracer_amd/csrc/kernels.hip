@@ -81,6 +81,11 @@
 #endif
 
 using namespace rptdev;
+#if RPT_MATH_MODE == 2
+#define RPT_ROW_NS rptplain           // (material_table_row: see render_small_regen_sized_table_kernel)
+#else
+#define RPT_ROW_NS rptdev
+#endif
 
 
 // ---------------------------------------------------------------------------
@@ -453,8 +458,8 @@ enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u, ST
 // otherwise the fuller of the two (nobody can trace while both wait).  Round 2 ran FINISH un-voted at the top of every pass,
 // with 34 % of the lanes, and the background inside TRACE with 46 % (profiles/r2/block_profile_c2.txt); replayed over the oracle's
 // path events (tools/sched_sim2.py, sim_finish_room) thresholds 56 / 24 cost 5 % less than that.
-template <class S>
-RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch)
+template <class M = MaterialPerHit, class S>
+RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch, const M& materials = M{})
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunch];
@@ -488,7 +493,7 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch)
         if (n_shade >= rp.shade_threshold || (n_fin < rp.finish_threshold && n_shade >= n_fin)) {
             if (state == ST_SHADE) {
                 RPT_PROF(PB_SHADE);
-                state = path_shade_full(sc, DirectQuery{}, p, g) ? ST_FINISH : ST_TRACE;
+                state = path_shade_full(sc, DirectQuery{}, p, g, nullptr, nullptr, materials) ? ST_FINISH : ST_TRACE;
             }
         } else if (state >= ST_FINISH) {
             // one site for the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
@@ -598,6 +603,19 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 #endif
 #ifndef RPT_NO_SMALL_KERNELS
 #ifdef RPT_HAS_SIZED_KERNELS
+// ... and that reads a hit's material from a table of the 2^(2 + 1 + 2) cases there are (dev_integrator.h, MaterialTable), built here by
+// the workgroup's first 32 lanes with the functions SHADE would have called (over hipcc's own divide and sqrtf where this object
+// tracks operand ranges instead of testing them: a row is built outside any sample).  RPT_NO_MATERIAL_TABLE=1: the kernel below it.
+__global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_sized_table_kernel)(const SceneSmall sc, const RenderParams rp)
+{
+    constexpr uint32_t sizes[3] = {RPT_REFERENCE_SIZES};
+    typedef MaterialTable<sizes[0], sizes[1]> Table;
+    __shared__ float4 s_rows[Table::kRows * kMatRowFloat4s];
+    const SceneSmall& s = sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc));
+    if (threadIdx.x < Table::kRows) RPT_ROW_NS::material_table_row<sizes[0], sizes[1]>(s, threadIdx.x, s_rows);
+    __syncthreads();
+    render_regen_body(s, rp, Table{s_rows});
+}
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_sized_kernel)(const SceneSmall sc, const RenderParams rp)
 {
     render_regen_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
@@ -1721,7 +1739,13 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     const bool sized = !no_sized && !media && !large && !has_sdf && !nested && sc.n_spheres == ref_sizes[0] && sc.n_planes == ref_sizes[1] &&
                        sc.n_lights == ref_sizes[2];
     const uint32_t sized_sdf = (!no_sized && !media && has_sdf && !nested && sc.n_planes == 1u && sc.n_lights == 1u && scs.sdf.n_prims <= 4u) ? scs.sdf.n_prims : 0u;
-    (void)sized; (void)sized_sdf;
+    // ... and that read materials from a table: at most one primitive with a procedural material (MaterialTable)
+    static const bool no_table = getenv("RPT_NO_MATERIAL_TABLE") && atoi(getenv("RPT_NO_MATERIAL_TABLE")) != 0;
+    uint32_t n_procedural = 0;
+    for (uint32_t i = 0; i < sc.n_spheres && i < (uint32_t)kMaxSpheres; ++i) n_procedural += sc.materials[sc.spheres[i].material].proc_kind != 0u;
+    for (uint32_t k = 0; k < sc.n_planes && k < (uint32_t)kMaxPlanes; ++k) n_procedural += sc.materials[sc.planes[k].material].proc_kind != 0u;
+    const bool one_procedural = n_procedural <= 1u;
+    (void)sized; (void)sized_sdf; (void)no_table; (void)one_procedural;
 #ifdef RPT_NO_LARGE_SDF_KERNELS
     if (large || has_sdf || (rp.compact && !nested)) return rptlaunch_perop::render(scs, scl, large, nested, rp, nblocks, st, scs_dev, media);   // (the RPT_PEROP_BUILD object)
 #endif
@@ -1800,7 +1824,8 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
         // kernel's throughput depends on resident waves per SIMD (occupancy sensitivity)
         static const unsigned extra_lds = getenv("RPT_DEBUG_EXTRA_LDS") ? (unsigned)atoi(getenv("RPT_DEBUG_EXTRA_LDS")) : 0u;
 #ifdef RPT_HAS_SIZED_KERNELS
-        if (sized) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_kernel), tiles, wg, extra_lds, st, sc, rp);
+        if (sized && one_procedural && !no_table) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_table_kernel), tiles, wg, extra_lds, st, sc, rp);
+        else if (sized) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_kernel), tiles, wg, extra_lds, st, sc, rp);
         else
 #endif
         hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, extra_lds, st, sc, rp);

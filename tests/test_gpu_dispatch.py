@@ -238,3 +238,97 @@ for name, scene in cases:
         torch_cuda.cuda.synchronize()
         assert_bit_identical(buf.pixels.cpu().numpy(), want, "SDF object of %d primitives" % n_prims)
         t.close()
+
+
+def _table_scene(rpt, which):
+    """Scenes of the reference's table sizes for the material table (dev_integrator.h, MaterialTable): what a row depends on."""
+    from rust_pathtracer_amd import scenes
+    from scene_fuzz import random_small_scene
+    if isinstance(which, int):                                        # random materials, random scale (2^-33 ... 2^33), roulette or not
+        s, _, flags, _ = random_small_scene(rpt, which, n_spheres=2, n_lights=1)
+        return s, flags
+    s = rpt.AnalyticalScene()
+    if which == "overlapping patches":
+        # two spheres through each other whose patches write DIFFERENT fields: a hit on the second after the first was accepted
+        # keeps the first one's fields (analytical.rs:56-58 writes field by field), i.e. rows with both sphere bits set
+        s.materials = [rpt.Material(rgb=(0.9, 0.3, 0.2), clearcoat=1.0, clearcoat_gloss=0.7, emission=(0.05, 0.0, 0.1)),
+                       rpt.Material(roughness=0.15, metallic=1.0, anisotropic=0.6, sheen=0.5, sheen_tint=0.4, specular_tint=0.7),
+                       rpt.Material(roughness=0.8, checker_dir=(0.5, 100.0, 0.25, 0.1))]
+        s.spheres = [((0.2, 0.0, -0.6), 1.0, 0), ((-0.3, 0.1, 0.2), 0.9, 1)]
+        s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2)]
+    elif which == "camera inside glass":
+        # the first hit comes from inside (normal . ray > 0: eta = ior, the rows of the other side)
+        s.materials = [scenes.full_material(rgb=(0.95, 0.95, 1.0), roughness=0.02, spec_trans=1.0, ior=1.5),
+                       rpt.Material(rgb=(0.8, 0.6, 0.1), roughness=0.3, subsurface=0.5),
+                       rpt.Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1))]
+        o = s.camera.origin
+        s.spheres = [((o[0], o[1], o[2] - 0.5), 1.2, 0), ((0.0, 0.0, 0.0), 0.8, 1)]
+        s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2)]
+        s.max_depth = 7
+    elif which == "checker on a sphere":
+        # the one procedural material on a sphere, a plain floor
+        s.materials = [rpt.Material(roughness=0.5, checker_dir=(2.0, 7.0, 0.9, 0.05)), rpt.Material(rgb=(0.2, 0.5, 0.8), metallic=1.0, roughness=0.2),
+                       rpt.Material(rgb=(0.6, 0.6, 0.6), roughness=0.9)]
+        s.spheres = [((-0.8, 0.0, 0.0), 1.0, 0), ((0.9, 0.0, 0.3), 0.8, 1)]
+        s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2)]
+    elif which == "two checkers":
+        # two procedural materials: the table has one bit for "the checker's second colour": the kernel without a table renders this one
+        s.materials = [rpt.Material(roughness=0.5, checker_dir=(2.0, 7.0, 0.9, 0.05)), rpt.Material(rgb=(0.2, 0.5, 0.8), metallic=1.0, roughness=0.2),
+                       rpt.Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1))]
+        s.spheres = [((-0.8, 0.0, 0.0), 1.0, 0), ((0.9, 0.0, 0.3), 0.8, 1)]
+        s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2)]
+    else:
+        assert which == "reference"
+    return s, 0
+
+
+_TABLE_CASES = ["reference", "overlapping patches", "camera inside glass", "checker on a sphere", "two checkers", 2, 5, 9, 13, 17, 21, 26, 33]
+
+
+def test_the_material_table_holds_what_every_hit_would_compute(rpt, oracle, torch_cuda):
+    """The megakernel for scenes of the reference's table sizes reads a hit's finalized material, eta and the specular / sheen colours
+    from a table of the 32 cases (accepted primitives x checker colour x side), built once per workgroup
+    (kernels.hip, render_small_regen_sized_table_kernel); RPT_NO_MATERIAL_TABLE=1 takes the kernel that computes them at every hit.
+    Same frames, and the oracle's: patches that write different fields on overlapping spheres, a camera inside a glass sphere, the
+    procedural material on a sphere, two of them (no table), random materials at random scales with and without roulette."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import conftest, torch
+rpt = conftest.load_package()
+import test_gpu_dispatch as T
+for which in T._TABLE_CASES:
+    scene, flags = T._table_scene(rpt, which)
+    t = rpt.Tracer(scene, device=0, seed=5)
+    t.flags = flags
+    buf = rpt.DeviceColorBuffer(176, 96)
+    for n in (2, 7):
+        t.render_n(buf, n)
+    torch.cuda.synchronize()
+    print("HASH", which, hashlib.sha1(buf.pixels.cpu().numpy().tobytes()).hexdigest())
+    t.close()
+""" % here
+    out = {}
+    for no_table in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, RPT_NO_MATERIAL_TABLE=no_table), timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        out[no_table] = [l for l in r.stdout.splitlines() if l.startswith("HASH")]
+        assert len(out[no_table]) == len(_TABLE_CASES)
+    assert out["0"] == out["1"], "frames with and without the material table differ: %r vs %r" % (out["0"], out["1"])
+    for which in _TABLE_CASES:                                        # and against the oracle, in this process (the table: the default)
+        s, flags = _table_scene(rpt, which)
+        w, h, spp = 88, 56, 5
+        want = oracle.render(s.describe(), w, h, spp, seed=2, render_flags=flags & rpt._abi.RPT_RENDER_RUSSIAN_ROULETTE)
+        t = rpt.Tracer(s, device=0, seed=2)
+        t.flags = flags
+        buf = rpt.DeviceColorBuffer(w, h)
+        t.render_n(buf, 2)
+        t.render_n(buf, 3)
+        torch_cuda.cuda.synchronize()
+        got = buf.pixels.cpu().numpy()
+        t.close()
+        assert_bit_identical(got, want, "material table, scene %r" % (which,))
