@@ -204,6 +204,18 @@ RPT_HD float rpt_powf(float x, float y)
     return (yint == 1) ? -r : r;
 }
 
+/* rpt_powf(x, y) for a caller that already holds lx = rpt_log2_core(x) of an x in (0, inf) (for any other x, lx is not read): the same
+ * operations on the same values.  (The library's material tables keep the logarithm of a roughness that many samples raise to a power.) */
+RPT_HD float rpt_powf_log2x(float x, double lx, float y)
+{
+    uint32_t ix = rpt_f2u(x), iy = rpt_f2u(y);
+    if ((ix - 1u < 0x7f7fffffu) && ((iy & 0x7fffffffu) < 0x7f800000u)) {
+        if (ix == 0x3f800000u) return 1.0f;
+        return rpt_exp2_core((double)y * lx);
+    }
+    return rpt_powf(x, y);
+}
+
 /* expf / logf (natural): Rust f32::exp / f32::ln semantics for the special cases; the same f64 cores, so <= 0.5001 ulp.
  * Only the project-defined participating media use them (include/rpt.h): the reference's tracer calls neither. */
 RPT_HD float rpt_expf(float x)

@@ -145,6 +145,78 @@ RPT_DEV v3 cosine_sample_hemisphere(float r1, float r2)             // tracer.rs
     return dir;
 }
 
+// What a row of a material table holds beyond the finalized material (dev_integrator.h, MaterialTable): the values the code below
+// computes from the material ALONE at every hit — twice where disney_eval and disney_sample both do.  The functions that need one ask
+// for it through mat_*(m): computed on the spot for a Mat, read for a MatRow; the operations that produced the value are the same.
+struct MatRowValues {
+    float lum;                        // luminance(rgb)
+    float w_diffuse, w_clearcoat;     // get_lobe_probabilities: the diffuse and clearcoat weights before they are normalised
+    float one_m_metallic;             // 1 - metallic
+    float dm;                         // eval_diffuse: (1 - metallic) * (1 - spec_trans)
+    float gtr1_a2m1, gtr1_k;          // gtr1 of a = clearcoat_roughness: a^2 - 1, pi * log2(a^2)
+    float cc_a2, cc_one_m_a2;         // sample_gtr1 of a = max(0.001, clearcoat_roughness): a^2, 1 - a^2
+    double cc_log2_a2;                // ... and rpt_log2_core(a^2), the first half of powf(a^2, 1 - r1)
+};
+// The finalized material in registers, the derived values left in the row (LDS) until the code that needs one reads it: kept in
+// registers from the row's fetch on they cost more in spills than they save (measured: +0.3 % instead of the values below).
+constexpr int kMatRowSpecCol = -5, kMatRowSheenCol = -4;      // (relative to MatRow::more: rows 2 and 3 of dev_integrator.h's layout)
+struct MatRow : Mat {
+    const float4* more;               // {lum, w_diffuse, w_clearcoat, one_m_metallic}, {dm, gtr1_a2m1, gtr1_k, cc_a2}, {cc_one_m_a2, -, cc_log2_a2}
+};
+RPT_DEV float mat_lum(const Mat& m) { return luminance(m.rgb); }
+RPT_DEV float mat_lum(const MatRow& m) { return m.more[0].x; }
+RPT_DEV float mat_one_m_metallic(const Mat& m) { return 1.0f - m.metallic; }
+RPT_DEV float mat_one_m_metallic(const MatRow& m) { return m.more[0].w; }
+RPT_DEV float mat_w_diffuse(const Mat& m, float lum) { return lum * (1.0f - m.metallic) * (1.0f - m.spec_trans); }
+RPT_DEV float mat_w_diffuse(const MatRow& m, float) { return m.more[0].y; }
+RPT_DEV float mat_w_clearcoat(const Mat& m) { return 0.25f * m.clearcoat * (1.0f - m.metallic); }
+RPT_DEV float mat_w_clearcoat(const MatRow& m) { return m.more[0].z; }
+RPT_DEV float mat_dm(const Mat& m) { return (1.0f - m.metallic) * (1.0f - m.spec_trans); }
+RPT_DEV float mat_dm(const MatRow& m) { return m.more[1].x; }
+RPT_DEV float mat_gtr1(const Mat& m, float ndoth) { return gtr1(ndoth, m.clearcoat_roughness); }
+RPT_DEV float mat_gtr1(const MatRow& m, float ndoth)                // gtr1, tracer.rs:233
+{
+    if (m.clearcoat_roughness >= 1.0f) return kInvPi;
+    const float4 r = m.more[1];
+    float t = 1.0f + r.y * ndoth * ndoth;
+    return fdiv(r.y, r.z * t);
+}
+// cos(theta) of sample_gtr1 (tracer.rs:242-245) for the clearcoat's roughness
+RPT_DEV float mat_cc_cos_theta(const Mat& m, float r1)
+{
+    float a = rmax(0.001f, m.clearcoat_roughness);
+    float a2 = a * a;
+    return fsqrt(fdiv(1.0f - rpt_powf(a2, 1.0f - r1), 1.0f - a2));
+}
+RPT_DEV float mat_cc_cos_theta(const MatRow& m, float r1)
+{
+    const float cc_a2 = m.more[1].w;
+    const float4 r = m.more[2];
+    const double lx = rpt_u2d((uint64_t)rpt_f2u(r.z) | ((uint64_t)rpt_f2u(r.w) << 32));
+    return fsqrt(fdiv(1.0f - rpt_powf_log2x(cc_a2, lx, 1.0f - r1), r.x));
+}
+RPT_DEV void mat_row_derive(const Mat& m0, MatRowValues& m)
+{
+    m.lum = luminance(m0.rgb);
+    m.w_diffuse = m.lum * (1.0f - m0.metallic) * (1.0f - m0.spec_trans);
+    m.w_clearcoat = 0.25f * m0.clearcoat * (1.0f - m0.metallic);
+    m.one_m_metallic = 1.0f - m0.metallic;
+    m.dm = (1.0f - m0.metallic) * (1.0f - m0.spec_trans);
+    {
+        float a = m0.clearcoat_roughness;
+        float a2 = a * a;
+        m.gtr1_a2m1 = a2 - 1.0f;
+        m.gtr1_k = kPi * rpt_log2f(a2);
+    }
+    {
+        float a = rmax(0.001f, m0.clearcoat_roughness);
+        float a2 = a * a;
+        m.cc_a2 = a2;
+        m.cc_one_m_a2 = 1.0f - a2;
+        m.cc_log2_a2 = (rpt_f2u(a2) - 1u < 0x7f7fffffu) ? rpt_log2_core(a2) : 0.0;     // (rpt_powf_log2x reads it for such an a2 only)
+    }
+}
+
 RPT_DEV void get_spec_color(const Mat& m, float eta, v3& spec_col, v3& sheen_col)   // tracer.rs:335
 {
     float lum = luminance(m.rgb);
@@ -162,7 +234,8 @@ RPT_DEV float disney_fresnel(const Mat& m, float eta, float ldoth, float vdoth) 
     return mixf(dielectric, metallic_fresnel, m.metallic);
 }
 
-RPT_DEV v3 eval_diffuse(const Mat& m, v3 c_sheen, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:343
+template <class MT>
+RPT_DEV v3 eval_diffuse(const MT& m, v3 c_sheen, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:343
 {
     pdf = 0.0f;
     if (l.z <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
@@ -177,7 +250,7 @@ RPT_DEV v3 eval_diffuse(const Mat& m, v3 c_sheen, v3 v, v3 l, v3 h, float& pdf) 
     float ss = 1.25f * (fss * (fdiv(1.0f, l.z + v.z) - 0.5f) + 0.5f);
     v3 fsheen = (fh * m.sheen) * c_sheen;
     pdf = l.z * kInvPi;
-    return ((1.0f - m.metallic) * (1.0f - m.spec_trans)) * ((kInvPi * mixf(fd, ss, m.subsurface)) * m.rgb + fsheen);
+    return mat_dm(m) * ((kInvPi * mixf(fd, ss, m.subsurface)) * m.rgb + fsheen);
 }
 
 RPT_DEV v3 eval_spec_reflection(const Mat& m, float eta, v3 spec_col, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:368
@@ -212,14 +285,15 @@ RPT_DEV v3 eval_spec_refraction(const Mat& m, float eta, v3 v, v3 l, v3 h, float
     return s * mk3(rpt_powf(m.rgb.x, 0.5f), rpt_powf(m.rgb.y, 0.5f), rpt_powf(m.rgb.z, 0.5f));
 }
 
-RPT_DEV v3 eval_clearcoat(const Mat& m, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:404
+template <class MT>
+RPT_DEV v3 eval_clearcoat(const MT& m, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:404
 {
     pdf = 0.0f;
     if (l.z <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
     float vdh = dot3(v, h);
     float fh = dielectric_fresnel(vdh, 1.0f / 1.5f);
     float f = mixf(0.04f, 1.0f, fh);
-    float d = gtr1(h.z, m.clearcoat_roughness);
+    float d = mat_gtr1(m, h.z);
     float g = smithg(l.z, 0.25f) * smithg(v.z, 0.25f);
     float jacobian = fdiv(1.0f, 4.0f * vdh);
     pdf = d * h.z * jacobian;
@@ -230,14 +304,15 @@ struct LobeWeights {
     float diffuse, spec_reflect, spec_refract, clearcoat;
 };
 
-RPT_DEV LobeWeights get_lobe_probabilities(const Mat& m, v3 spec_col, float approx_fresnel)   // tracer.rs:421
+template <class MT>
+RPT_DEV LobeWeights get_lobe_probabilities(const MT& m, v3 spec_col, float approx_fresnel)   // tracer.rs:421
 {
     LobeWeights w;
-    float lum = luminance(m.rgb);
-    w.diffuse = lum * (1.0f - m.metallic) * (1.0f - m.spec_trans);
+    float lum = mat_lum(m);
+    w.diffuse = mat_w_diffuse(m, lum);
     w.spec_reflect = luminance(mix3(spec_col, mk3(1.0f, 1.0f, 1.0f), approx_fresnel));
-    w.spec_refract = (1.0f - approx_fresnel) * (1.0f - m.metallic) * m.spec_trans * lum;
-    w.clearcoat = 0.25f * m.clearcoat * (1.0f - m.metallic);
+    w.spec_refract = (1.0f - approx_fresnel) * mat_one_m_metallic(m) * m.spec_trans * lum;
+    w.clearcoat = mat_w_clearcoat(m);
     float total = w.diffuse + w.spec_reflect + w.spec_refract + w.clearcoat;
     const v3 w3 = divs3(mk3(w.diffuse, w.spec_reflect, w.spec_refract), total);      // (four quotients by one total)
     w.diffuse = w3.x;
@@ -283,6 +358,12 @@ RPT_DEV ShadeFrame make_frame(const Mat& m, float eta, v3 v_world, v3 n)
     return fr;
 }
 
+// The two colours of get_spec_color: in the frame for a Mat; for a MatRow they are part of the row and stay there until read.
+RPT_DEV v3 mat_spec_col(const Mat&, const ShadeFrame& fr) { return fr.spec_col; }
+RPT_DEV v3 mat_spec_col(const MatRow& m, const ShadeFrame&) { const float4 c = m.more[kMatRowSpecCol]; return mk3(c.x, c.y, c.z); }
+RPT_DEV v3 mat_sheen_col(const Mat&, const ShadeFrame& fr) { return fr.sheen_col; }
+RPT_DEV v3 mat_sheen_col(const MatRow& m, const ShadeFrame&) { const float4 c = m.more[kMatRowSheenCol]; return mk3(c.x, c.y, c.z); }
+
 // tracer.rs:441-553.  l_io: in = the previous bounce's world-space direction (zeros
 // on the first bounce) which the specular branch reads before overwriting it
 // (tracer.rs:531); out = the sampled world-space direction.
@@ -299,16 +380,17 @@ RPT_DEV ShadeFrame make_frame(const Mat& m, float eta, v3 v_world, v3 n)
 //     dielectric Fresnel term, the two Smith terms' common tail 2n / (n + sqrt(E)), the pdf's division and the
 //     first division of the value.
 // Every lane still executes exactly the reference's operations on its own values, in the reference's order.
-RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3& l_io, float& pdf, Rng& rng)
+template <class MT>
+RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3& l_io, float& pdf, Rng& rng)
 {
     pdf = 0.0f;
     v3 f = mk3(0.0f, 0.0f, 0.0f);
     float r1 = rng.gen();
     float r2 = rng.gen();
 
-    const v3 t = fr.t, b = fr.b, v = fr.v, spec_col = fr.spec_col, sheen_col = fr.sheen_col;
+    const v3 t = fr.t, b = fr.b, v = fr.v;
     float approx_fresnel = disney_fresnel(m, eta, v.z, v.z);
-    LobeWeights w = get_lobe_probabilities(m, spec_col, approx_fresnel);
+    LobeWeights w = get_lobe_probabilities(m, mat_spec_col(m, fr), approx_fresnel);
 
     float cdf0 = w.diffuse;
     float cdf1 = cdf0 + w.clearcoat;
@@ -339,9 +421,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
         other = l;
     } else if (is_c) {
         RPT_PROF(PB_LOBE_CLEARCOAT);
-        float a = rmax(0.001f, m.clearcoat_roughness);              // sample_gtr1, tracer.rs:242 (r2 is unused there)
-        float a2 = a * a;
-        float cos_theta = fsqrt(fdiv(1.0f - rpt_powf(a2, 1.0f - r1), 1.0f - a2));
+        float cos_theta = mat_cc_cos_theta(m, r1);                  // sample_gtr1, tracer.rs:242 (r2 is unused there)
         float sin_theta = clamp01(fsqrt(1.0f - (cos_theta * cos_theta)));
         v3 h = mk3(sin_theta * cs, sin_theta * sn, cos_theta);
         if (h.z < 0.0f) h = -h;
@@ -375,7 +455,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
 
     if (is_d) {
         RPT_PROF(PB_LOBE_DIFFUSE);
-        f = eval_diffuse(m, sheen_col, v, l, h, pdf);
+        f = eval_diffuse(m, mat_sheen_col(m, fr), v, l, h, pdf);
         pdf *= w.diffuse;
     } else if (!reflected) {
         f = eval_spec_refraction(m, eta, v, l, h, pdf);
@@ -391,7 +471,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
             float e_v, e_l;                                         // what each Smith term takes the root of
             v3 fcol;
             if (is_c) {
-                d = gtr1(h.z, m.clearcoat_roughness);
+                d = mat_gtr1(m, h.z);
                 const float a = 0.25f * 0.25f;                      // smithg, tracer.rs:276
                 const float bv = v.z * v.z, bl = l.z * l.z;
                 e_v = a + bv - a * bv;
@@ -405,7 +485,7 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
                 e_v = av * av + bv * bv + cv * cv;
                 e_l = al * al + bl * bl + cl * cl;
                 const float fm = mixf(dfr, schlick_fresnel(dot3(l, h)), m.metallic);       // disney_fresnel, tracer.rs:435
-                fcol = mix3(spec_col, mk3(1.0f, 1.0f, 1.0f), fm);
+                fcol = mix3(mat_spec_col(m, fr), mk3(1.0f, 1.0f, 1.0f), fm);
             }
             const float n_v = is_c ? v.z : __builtin_fabsf(v.z);
             const float n_l = is_c ? l.z : __builtin_fabsf(l.z);
@@ -439,11 +519,12 @@ RPT_DEV v3 disney_sample(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3
 }
 
 // tracer.rs:555-626
-RPT_DEV v3 disney_eval(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3 l_world, float& bsdf_pdf)
+template <class MT>
+RPT_DEV v3 disney_eval(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3 l_world, float& bsdf_pdf)
 {
     bsdf_pdf = 0.0f;
     v3 f = mk3(0.0f, 0.0f, 0.0f);
-    const v3 t = fr.t, b = fr.b, v = fr.v, spec_col = fr.spec_col, sheen_col = fr.sheen_col;
+    const v3 t = fr.t, b = fr.b, v = fr.v;
     v3 l = to_local(t, b, n, l_world);
 
     v3 h;
@@ -452,15 +533,15 @@ RPT_DEV v3 disney_eval(const Mat& m, float eta, const ShadeFrame& fr, v3 n, v3 l
     if (h.z < 0.0f) h = -h;
 
     float fresnel = disney_fresnel(m, eta, dot3(l, h), dot3(v, h));
-    LobeWeights w = get_lobe_probabilities(m, spec_col, fresnel);
+    LobeWeights w = get_lobe_probabilities(m, mat_spec_col(m, fr), fresnel);
 
     float pdf;
     if (w.diffuse > 0.0f && l.z > 0.0f) {
-        f = f + eval_diffuse(m, sheen_col, v, l, h, pdf);
+        f = f + eval_diffuse(m, mat_sheen_col(m, fr), v, l, h, pdf);
         bsdf_pdf += pdf * w.diffuse;
     }
     if (w.spec_reflect > 0.0f && l.z > 0.0f && v.z > 0.0f) {
-        f = f + eval_spec_reflection(m, eta, spec_col, v, l, h, pdf);
+        f = f + eval_spec_reflection(m, eta, mat_spec_col(m, fr), v, l, h, pdf);
         bsdf_pdf += pdf * w.spec_reflect;
     }
     if (w.spec_refract > 0.0f && l.z < 0.0f) {

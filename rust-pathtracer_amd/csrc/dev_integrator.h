@@ -677,20 +677,24 @@ struct DirectQuery {
 // looks at, and of the side the ray comes from (eta): a handful of cases when the scene has a handful of primitives.
 struct MaterialPerHit {
     static constexpr bool kTable = false;
+    typedef Mat MatType;
 };
 // A kernel for NS spheres and NP planes (kernels.hip, sized_scene) computes every case once per workgroup, with the same functions,
 // into 2^(NS + NP + 2) rows of LDS (material_table_build) and SHADE reads its row: 8 x ds_read_b128 for what was ~45 selects behind
 // uniform branches on the patches' masks, a square root and nine divides.  The checker itself stays per ray.
 // Row index: accepted spheres | accepted planes << NS | second colour << (NS + NP) | (normal . ray < 0) << (NS + NP + 1).
 // The host launches such a kernel only when at most ONE primitive's material is procedural (one bit for "second colour").
-constexpr uint32_t kMatRowFloat4s = 8u;
+constexpr uint32_t kMatRowFloat4s = 10u;
+constexpr uint32_t kMatRowMore = 7u;             // where MatRow::more starts
+static_assert((int)kMatRowMore + kMatRowSpecCol == 2 && (int)kMatRowMore + kMatRowSheenCol == 3, "dev_bsdf.h reads the colours relative to MatRow::more");
 template <uint32_t NS, uint32_t NP>
 struct MaterialTable {
     static constexpr bool kTable = true;
+    typedef MatRow MatType;                    // (dev_bsdf.h: + what the BSDF code derives from the material alone)
     static constexpr uint32_t kRows = 1u << (NS + NP + 2u);
     const float4* rows;
     template <class S>
-    RPT_DEV void fetch(const S& sc, const RayD& ray, uint32_t accepted, bool ndd_negative, Mat& m, float& eta, v3& spec_col, v3& sheen_col) const
+    RPT_DEV void fetch(const S& sc, const RayD& ray, uint32_t accepted, bool ndd_negative, MatRow& m, float& eta) const
     {
         bool second = false;
         for (uint32_t i = 0; i < NS; ++i) {
@@ -704,14 +708,15 @@ struct MaterialTable {
         const uint32_t row = (accepted & ((1u << NS) - 1u)) | (((accepted >> kMaxSpheres) & ((1u << NP) - 1u)) << NS) |
                              ((second ? 1u : 0u) << (NS + NP)) | ((ndd_negative ? 1u : 0u) << (NS + NP + 1u));
         const float4* r = rows + row * kMatRowFloat4s;
-        const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6];
+        const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6];         // (the colours in c and d: mat_spec_col)
         m.rgb = mk3(a.x, a.y, a.z);                 m.metallic = a.w;
         m.emission = mk3(b.x, b.y, b.z);            m.roughness = b.w;
-        spec_col = mk3(c.x, c.y, c.z);              m.subsurface = c.w;
-        sheen_col = mk3(d.x, d.y, d.z);             m.sheen = d.w;
+        m.subsurface = c.w;
+        m.sheen = d.w;
         m.clearcoat = e.x; m.clearcoat_roughness = e.y; m.spec_trans = e.z; m.ior = e.w;
         m.ax = f.x; m.ay = f.y; eta = f.z; m.specular_tint = f.w;
         m.sheen_tint = g.x; m.anisotropic = g.y; m.clearcoat_gloss = g.z;
+        m.more = r + kMatRowMore;
     }
 };
 // One row of that table (the lane that owns it calls this; any pass's functions: the row holds their results).
@@ -727,6 +732,9 @@ RPT_DEV void material_table_row(const S& sc, uint32_t row, float4* rows)
     const float eta = ndd_negative ? fdiv(1.0f, m.ior) : m.ior;
     v3 spec_col, sheen_col;
     get_spec_color(m, eta, spec_col, sheen_col);
+    MatRowValues x;
+    mat_row_derive(m, x);
+    const uint64_t l2 = rpt_d2u(x.cc_log2_a2);
     float4* r = rows + row * kMatRowFloat4s;
     r[0] = make_float4(m.rgb.x, m.rgb.y, m.rgb.z, m.metallic);
     r[1] = make_float4(m.emission.x, m.emission.y, m.emission.z, m.roughness);
@@ -735,7 +743,9 @@ RPT_DEV void material_table_row(const S& sc, uint32_t row, float4* rows)
     r[4] = make_float4(m.clearcoat, m.clearcoat_roughness, m.spec_trans, m.ior);
     r[5] = make_float4(m.ax, m.ay, eta, m.specular_tint);
     r[6] = make_float4(m.sheen_tint, m.anisotropic, m.clearcoat_gloss, 0.0f);
-    r[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    r[kMatRowMore + 0u] = make_float4(x.lum, x.w_diffuse, x.w_clearcoat, x.one_m_metallic);
+    r[kMatRowMore + 1u] = make_float4(x.dm, x.gtr1_a2m1, x.gtr1_k, x.cc_a2);
+    r[kMatRowMore + 2u] = make_float4(x.cc_one_m_a2, 0.0f, rpt_u2f((uint32_t)l2), rpt_u2f((uint32_t)(l2 >> 32)));
 }
 
 // Head of direct_light (tracer.rs:130-145): pick a light, sample it.  Returns the facing test of tracer.rs:147.
@@ -791,7 +801,8 @@ RPT_DEV NeeQuery nee_query(const S& sc, const Q& q, v3 fhp, v3 ffnormal, Rng& rn
     return n;
 }
 
-RPT_DEV v3 nee_eval(const NeeQuery& n, const Mat& mat, float eta, const ShadeFrame& fr, v3 ffnormal)
+template <class MT>
+RPT_DEV v3 nee_eval(const NeeQuery& n, const MT& mat, float eta, const ShadeFrame& fr, v3 ffnormal)
 {
     v3 ld = mk3(0.0f, 0.0f, 0.0f);
     if (n.lit) {
@@ -984,12 +995,13 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
     const float ndd = dot3(normal, p.ray.d);
     const bool front = (ndd <= 0.0f);
     const v3 ffnormal = mk3(front ? normal.x : -normal.x, front ? normal.y : -normal.y, front ? normal.z : -normal.z);
-    Mat mat;
+    typename M::MatType mat;
     float eta;
     ShadeFrame fr;
     if constexpr (M::kTable) {
         RPT_PROF(PB_FINALIZE);
-        materials.fetch(sc, p.ray, g.code, ndd < 0.0f, mat, eta, fr.spec_col, fr.sheen_col);
+        materials.fetch(sc, p.ray, g.code, ndd < 0.0f, mat, eta);
+        fr.spec_col = fr.sheen_col = mk3(0.0f, 0.0f, 0.0f);          // (not read: mat_spec_col)
         p.radiance = p.radiance + mat.emission * p.throughput;
     } else {
         RPT_PROF(PB_FINALIZE);
