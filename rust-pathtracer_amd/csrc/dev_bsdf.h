@@ -154,15 +154,33 @@ struct MatRowValues {
     float one_m_metallic;             // 1 - metallic
     float dm;                         // eval_diffuse: (1 - metallic) * (1 - spec_trans)
     float gtr1_a2m1, gtr1_k;          // gtr1 of a = clearcoat_roughness: a^2 - 1, pi * log2(a^2)
-    float cc_a2, cc_one_m_a2;         // sample_gtr1 of a = max(0.001, clearcoat_roughness): a^2, 1 - a^2
+    float cc_a2;                      // sample_gtr1 of a = max(0.001, clearcoat_roughness): a^2
     double cc_log2_a2;                // ... and rpt_log2_core(a^2), the first half of powf(a^2, 1 - r1)
 };
-// The finalized material in registers, the derived values left in the row (LDS) until the code that needs one reads it: kept in
-// registers from the row's fetch on they cost more in spills than they save (measured: +0.3 % instead of the values below).
-constexpr int kMatRowSpecCol = -5, kMatRowSheenCol = -4;      // (relative to MatRow::more: rows 2 and 3 of dev_integrator.h's layout)
-struct MatRow : Mat {
-    const float4* more;               // {lum, w_diffuse, w_clearcoat, one_m_metallic}, {dm, gtr1_a2m1, gtr1_k, cc_a2}, {cc_one_m_a2, -, cc_log2_a2}
+// A MatRow is the row's address: every value — the finalized material's fields too — stays in LDS until the code that needs it reads
+// it (one ds_read off the one address register).  Kept in registers from the row's fetch on, the derived values cost more in spills
+// than they saved (+0.3 %); read where they are used +2.4 %, the two colours likewise +1.1 %, the material's own fields +-0.
+constexpr int kMatRowMore = 6;                                       // row layout (dev_integrator.h, material_table_row), in float4s:
+constexpr int kMatRowSpecCol = 2 - kMatRowMore, kMatRowSheenCol = 3 - kMatRowMore;   // relative to MatRow::more
+struct MatRow {
+    const float4* more;               // {lum, w_diffuse, w_clearcoat, one_m_metallic}, {dm, gtr1_a2m1, gtr1_k, cc_a2}
 };
+// m.field for either kind of material
+#define RPT_MAT_FIELD(name, at)                                                                          \
+    RPT_DEV float mat_##name(const Mat& m) { return m.name; }                                            \
+    RPT_DEV float mat_##name(const MatRow& m) { return ((const float*)(m.more - kMatRowMore))[at]; }
+RPT_MAT_FIELD(metallic, 3)
+RPT_MAT_FIELD(roughness, 7)
+RPT_MAT_FIELD(subsurface, 11)
+RPT_MAT_FIELD(sheen, 15)
+RPT_MAT_FIELD(clearcoat, 16)
+RPT_MAT_FIELD(clearcoat_roughness, 17)
+RPT_MAT_FIELD(spec_trans, 18)
+RPT_MAT_FIELD(ax, 20)
+RPT_MAT_FIELD(ay, 21)
+#undef RPT_MAT_FIELD
+RPT_DEV v3 mat_rgb(const Mat& m) { return m.rgb; }
+RPT_DEV v3 mat_rgb(const MatRow& m) { const float4 c = m.more[-kMatRowMore]; return mk3(c.x, c.y, c.z); }
 RPT_DEV float mat_lum(const Mat& m) { return luminance(m.rgb); }
 RPT_DEV float mat_lum(const MatRow& m) { return m.more[0].x; }
 RPT_DEV float mat_one_m_metallic(const Mat& m) { return 1.0f - m.metallic; }
@@ -176,7 +194,7 @@ RPT_DEV float mat_dm(const MatRow& m) { return m.more[1].x; }
 RPT_DEV float mat_gtr1(const Mat& m, float ndoth) { return gtr1(ndoth, m.clearcoat_roughness); }
 RPT_DEV float mat_gtr1(const MatRow& m, float ndoth)                // gtr1, tracer.rs:233
 {
-    if (m.clearcoat_roughness >= 1.0f) return kInvPi;
+    if (mat_clearcoat_roughness(m) >= 1.0f) return kInvPi;
     const float4 r = m.more[1];
     float t = 1.0f + r.y * ndoth * ndoth;
     return fdiv(r.y, r.z * t);
@@ -190,10 +208,10 @@ RPT_DEV float mat_cc_cos_theta(const Mat& m, float r1)
 }
 RPT_DEV float mat_cc_cos_theta(const MatRow& m, float r1)
 {
-    const float cc_a2 = m.more[1].w;
-    const float4 r = m.more[2];
+    const float a2 = m.more[1].w;
+    const float4 r = m.more[-1];
     const double lx = rpt_u2d((uint64_t)rpt_f2u(r.z) | ((uint64_t)rpt_f2u(r.w) << 32));
-    return fsqrt(fdiv(1.0f - rpt_powf_log2x(cc_a2, lx, 1.0f - r1), r.x));
+    return fsqrt(fdiv(1.0f - rpt_powf_log2x(a2, lx, 1.0f - r1), 1.0f - a2));
 }
 RPT_DEV void mat_row_derive(const Mat& m0, MatRowValues& m)
 {
@@ -212,7 +230,6 @@ RPT_DEV void mat_row_derive(const Mat& m0, MatRowValues& m)
         float a = rmax(0.001f, m0.clearcoat_roughness);
         float a2 = a * a;
         m.cc_a2 = a2;
-        m.cc_one_m_a2 = 1.0f - a2;
         m.cc_log2_a2 = (rpt_f2u(a2) - 1u < 0x7f7fffffu) ? rpt_log2_core(a2) : 0.0;     // (rpt_powf_log2x reads it for such an a2 only)
     }
 }
@@ -227,11 +244,12 @@ RPT_DEV void get_spec_color(const Mat& m, float eta, v3& spec_col, v3& sheen_col
     sheen_col = mix3(mk3(1.0f, 1.0f, 1.0f), ctint, m.sheen_tint);
 }
 
-RPT_DEV float disney_fresnel(const Mat& m, float eta, float ldoth, float vdoth)   // tracer.rs:435
+template <class MT>
+RPT_DEV float disney_fresnel(const MT& m, float eta, float ldoth, float vdoth)   // tracer.rs:435
 {
     float metallic_fresnel = schlick_fresnel(ldoth);
     float dielectric = dielectric_fresnel(__builtin_fabsf(vdoth), eta);
-    return mixf(dielectric, metallic_fresnel, m.metallic);
+    return mixf(dielectric, metallic_fresnel, mat_metallic(m));
 }
 
 template <class MT>
@@ -243,46 +261,48 @@ RPT_DEV v3 eval_diffuse(const MT& m, v3 c_sheen, v3 v, v3 l, v3 h, float& pdf)  
     float fl = schlick_fresnel(l.z);
     float fv = schlick_fresnel(v.z);
     float fh = schlick_fresnel(ldh);
-    float fd90 = 0.5f + 2.0f * ldh * ldh * m.roughness;
+    float fd90 = 0.5f + 2.0f * ldh * ldh * mat_roughness(m);
     float fd = mixf(1.0f, fd90, fl) * mixf(1.0f, fd90, fv);
-    float fss90 = ldh * ldh * m.roughness;
+    float fss90 = ldh * ldh * mat_roughness(m);
     float fss = mixf(1.0f, fss90, fl) * mixf(1.0f, fss90, fv);
     float ss = 1.25f * (fss * (fdiv(1.0f, l.z + v.z) - 0.5f) + 0.5f);
-    v3 fsheen = (fh * m.sheen) * c_sheen;
+    v3 fsheen = (fh * mat_sheen(m)) * c_sheen;
     pdf = l.z * kInvPi;
-    return mat_dm(m) * ((kInvPi * mixf(fd, ss, m.subsurface)) * m.rgb + fsheen);
+    return mat_dm(m) * ((kInvPi * mixf(fd, ss, mat_subsurface(m))) * mat_rgb(m) + fsheen);
 }
 
-RPT_DEV v3 eval_spec_reflection(const Mat& m, float eta, v3 spec_col, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:368
+template <class MT>
+RPT_DEV v3 eval_spec_reflection(const MT& m, float eta, v3 spec_col, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:368
 {
     pdf = 0.0f;
     if (l.z <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
     float fm = disney_fresnel(m, eta, dot3(l, h), dot3(v, h));
     v3 f = mix3(spec_col, mk3(1.0f, 1.0f, 1.0f), fm);
-    float d = gtr2aniso(h.z, h.x, h.y, m.ax, m.ay);
-    float g1 = smithganiso(__builtin_fabsf(v.z), v.x, v.y, m.ax, m.ay);
-    float g2 = g1 * smithganiso(__builtin_fabsf(l.z), l.x, l.y, m.ax, m.ay);
+    float d = gtr2aniso(h.z, h.x, h.y, mat_ax(m), mat_ay(m));
+    float g1 = smithganiso(__builtin_fabsf(v.z), v.x, v.y, mat_ax(m), mat_ay(m));
+    float g2 = g1 * smithganiso(__builtin_fabsf(l.z), l.x, l.y, mat_ax(m), mat_ay(m));
     pdf = fdiv(g1 * d, 4.0f * v.z);
     return divs3((d * g2) * f, 4.0f * l.z * v.z);
 }
 
-RPT_DEV v3 eval_spec_refraction(const Mat& m, float eta, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:384
+template <class MT>
+RPT_DEV v3 eval_spec_refraction(const MT& m, float eta, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:384
 {
     pdf = 0.0f;
     if (l.z >= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
     float vdh = dot3(v, h), ldh = dot3(l, h);
     float f = dielectric_fresnel(__builtin_fabsf(vdh), eta);
-    float d = gtr2aniso(h.z, h.x, h.y, m.ax, m.ay);
-    float g1 = smithganiso(__builtin_fabsf(v.z), v.x, v.y, m.ax, m.ay);
-    float g2 = g1 * smithganiso(__builtin_fabsf(l.z), l.x, l.y, m.ax, m.ay);
+    float d = gtr2aniso(h.z, h.x, h.y, mat_ax(m), mat_ay(m));
+    float g1 = smithganiso(__builtin_fabsf(v.z), v.x, v.y, mat_ax(m), mat_ay(m));
+    float g2 = g1 * smithganiso(__builtin_fabsf(l.z), l.x, l.y, mat_ax(m), mat_ay(m));
     float denom = ldh + vdh * eta;
     denom *= denom;
     float eta2 = eta * eta;
     float jacobian = fdiv(__builtin_fabsf(ldh), denom);
     pdf = fdiv(g1 * rmax(0.0f, vdh) * d * jacobian, v.z);
-    float s = fdiv((1.0f - m.metallic) * m.spec_trans * (1.0f - f) * d * g2 * __builtin_fabsf(vdh) * jacobian * eta2,
+    float s = fdiv((1.0f - mat_metallic(m)) * mat_spec_trans(m) * (1.0f - f) * d * g2 * __builtin_fabsf(vdh) * jacobian * eta2,
                    __builtin_fabsf(l.z * v.z));
-    return s * mk3(rpt_powf(m.rgb.x, 0.5f), rpt_powf(m.rgb.y, 0.5f), rpt_powf(m.rgb.z, 0.5f));
+    return s * mk3(rpt_powf(mat_rgb(m).x, 0.5f), rpt_powf(mat_rgb(m).y, 0.5f), rpt_powf(mat_rgb(m).z, 0.5f));
 }
 
 template <class MT>
@@ -297,7 +317,7 @@ RPT_DEV v3 eval_clearcoat(const MT& m, v3 v, v3 l, v3 h, float& pdf)   // tracer
     float g = smithg(l.z, 0.25f) * smithg(v.z, 0.25f);
     float jacobian = fdiv(1.0f, 4.0f * vdh);
     pdf = d * h.z * jacobian;
-    return fdiv(m.clearcoat * f * d * g, 4.0f * l.z * v.z) * mk3(0.25f, 0.25f, 0.25f);
+    return fdiv(mat_clearcoat(m) * f * d * g, 4.0f * l.z * v.z) * mk3(0.25f, 0.25f, 0.25f);
 }
 
 struct LobeWeights {
@@ -311,7 +331,7 @@ RPT_DEV LobeWeights get_lobe_probabilities(const MT& m, v3 spec_col, float appro
     float lum = mat_lum(m);
     w.diffuse = mat_w_diffuse(m, lum);
     w.spec_reflect = luminance(mix3(spec_col, mk3(1.0f, 1.0f, 1.0f), approx_fresnel));
-    w.spec_refract = (1.0f - approx_fresnel) * mat_one_m_metallic(m) * m.spec_trans * lum;
+    w.spec_refract = (1.0f - approx_fresnel) * mat_one_m_metallic(m) * mat_spec_trans(m) * lum;
     w.clearcoat = mat_w_clearcoat(m);
     float total = w.diffuse + w.spec_reflect + w.spec_refract + w.clearcoat;
     const v3 w3 = divs3(mk3(w.diffuse, w.spec_reflect, w.spec_refract), total);      // (four quotients by one total)
@@ -429,7 +449,7 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
         other = h;
     } else {
         RPT_PROF(PB_LOBE_SPEC);
-        v3 vh = norm3(mk3(m.ax * v.x, m.ay * v.y, v.z));            // sample_ggxvndf, tracer.rs:256
+        v3 vh = norm3(mk3(mat_ax(m) * v.x, mat_ay(m) * v.y, v.z));            // sample_ggxvndf, tracer.rs:256
         float lensq = vh.x * vh.x + vh.y * vh.y;
         v3 t_1 = mk3(1.0f, 0.0f, 0.0f);
         if (lensq > 0.0f) t_1 = scale3(mk3(-vh.y, vh.x, 0.0f), fdiv(1.0f, fsqrt(lensq)));
@@ -439,10 +459,10 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
         float s = 0.5f * (1.0f + vh.z);
         t2 = (1.0f - s) * fsqrt(1.0f - t1 * t1) + s * t2;
         v3 nh = t1 * t_1 + t2 * t_2 + fsqrt(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
-        v3 h = norm3(mk3(m.ax * nh.x, m.ay * nh.y, rmax(0.0f, nh.z)));
+        v3 h = norm3(mk3(mat_ax(m) * nh.x, mat_ay(m) * nh.y, rmax(0.0f, nh.z)));
         if (h.z < 0.0f) h = -h;
         float fresnel = disney_fresnel(m, eta, dot3(l_io, h), dot3(v, h));
-        ff = 1.0f - ((1.0f - fresnel) * m.spec_trans * (1.0f - m.metallic));
+        ff = 1.0f - ((1.0f - fresnel) * mat_spec_trans(m) * (1.0f - mat_metallic(m)));
         float rnd = rng.gen();
         reflected = rnd < ff;
         if (reflected) pre = reflect3(-v, h);
@@ -479,12 +499,12 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
                 const float fc = mixf(0.04f, 1.0f, dfr);
                 fcol = mk3(fc, fc, fc);
             } else {
-                d = gtr2aniso(h.z, h.x, h.y, m.ax, m.ay);
-                const float av = v.x * m.ax, bv = v.y * m.ay, cv = __builtin_fabsf(v.z);   // smithganiso, tracer.rs:301
-                const float al = l.x * m.ax, bl = l.y * m.ay, cl = __builtin_fabsf(l.z);
+                d = gtr2aniso(h.z, h.x, h.y, mat_ax(m), mat_ay(m));
+                const float av = v.x * mat_ax(m), bv = v.y * mat_ay(m), cv = __builtin_fabsf(v.z);   // smithganiso, tracer.rs:301
+                const float al = l.x * mat_ax(m), bl = l.y * mat_ay(m), cl = __builtin_fabsf(l.z);
                 e_v = av * av + bv * bv + cv * cv;
                 e_l = al * al + bl * bl + cl * cl;
-                const float fm = mixf(dfr, schlick_fresnel(dot3(l, h)), m.metallic);       // disney_fresnel, tracer.rs:435
+                const float fm = mixf(dfr, schlick_fresnel(dot3(l, h)), mat_metallic(m));       // disney_fresnel, tracer.rs:435
                 fcol = mix3(mat_spec_col(m, fr), mk3(1.0f, 1.0f, 1.0f), fm);
             }
             const float n_v = is_c ? v.z : __builtin_fabsf(v.z);
@@ -498,7 +518,7 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
             const float den = 4.0f * l.z * v.z;
             // value: clearcoat (clearcoat * F * d * g / den) * 0.25; specular ((d * g) * F) / den per channel
             const float dg = d * g;
-            const float numx = is_c ? (m.clearcoat * fcol.x * d * g) : (dg * fcol.x);
+            const float numx = is_c ? (mat_clearcoat(m) * fcol.x * d * g) : (dg * fcol.x);
             const v3 q3 = divs3(mk3(numx, dg * fcol.y, dg * fcol.z), den);          // (the clearcoat arm uses the first quotient only)
             if (is_c) {
                 const float c = q3.x * 0.25f;

@@ -679,55 +679,62 @@ struct MaterialPerHit {
     static constexpr bool kTable = false;
     typedef Mat MatType;
 };
-// A kernel for NS spheres and NP planes (kernels.hip, sized_scene) computes every case once per workgroup, with the same functions,
-// into 2^(NS + NP + 2) rows of LDS (material_table_build) and SHADE reads its row: 8 x ds_read_b128 for what was ~45 selects behind
-// uniform branches on the patches' masks, a square root and nine divides.  The checker itself stays per ray.
-// Row index: accepted spheres | accepted planes << NS | second colour << (NS + NP) | (normal . ray < 0) << (NS + NP + 1).
-// The host launches such a kernel only when at most ONE primitive's material is procedural (one bit for "second colour").
-constexpr uint32_t kMatRowFloat4s = 10u;
-constexpr uint32_t kMatRowMore = 7u;             // where MatRow::more starts
-static_assert((int)kMatRowMore + kMatRowSpecCol == 2 && (int)kMatRowMore + kMatRowSheenCol == 3, "dev_bsdf.h reads the colours relative to MatRow::more");
-template <uint32_t NS, uint32_t NP>
+// A kernel for scenes of at most kMatTableBits primitives (kernels.hip) computes every case once per workgroup, with the same
+// functions, into rows of LDS (material_table_row) and SHADE keeps its row's address: what the BSDF code needs of the material it
+// reads there, where it needs it (dev_bsdf.h, MatRow) — for what was ~45 selects behind uniform branches on the patches' masks, a
+// square root and nine divides per hit, and more inside disney_eval / disney_sample.  The checker itself stays per ray.
+// Row index, nb = ns + np + SDF: accepted spheres | accepted planes << ns | SDF object accepted << (ns + np) | the checker's second
+// colour << nb | (normal . ray < 0) << (nb + 1).  The host launches such a kernel only when nb <= kMatTableBits and at most ONE
+// primitive's material is procedural (one bit for "second colour").
+constexpr uint32_t kMatRowFloat4s = 8u;          // 128 B
+constexpr uint32_t kMatTableBits = 3u;
+constexpr uint32_t kMatTableRows = 1u << (kMatTableBits + 2u);       // 4 KB
+template <bool SDF>
 struct MaterialTable {
     static constexpr bool kTable = true;
-    typedef MatRow MatType;                    // (dev_bsdf.h: + what the BSDF code derives from the material alone)
-    static constexpr uint32_t kRows = 1u << (NS + NP + 2u);
+    typedef MatRow MatType;
     const float4* rows;
+    uint32_t ns, np;                           // the scene's n_spheres and n_planes (literals in the kernels that know them)
     template <class S>
-    RPT_DEV void fetch(const S& sc, const RayD& ray, uint32_t accepted, bool ndd_negative, MatRow& m, float& eta) const
+    RPT_DEV void fetch(const S& sc, const RayD& ray, uint32_t accepted, bool ndd_negative, MatRow& m, float& eta, v3& emission) const
     {
         bool second = false;
-        for (uint32_t i = 0; i < NS; ++i) {
+        for (uint32_t i = 0; i < ns; ++i) {
             const DevMaterial& pm = sc.materials[sc.spheres[i].material];
             if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { if ((accepted >> i) & 1u) second = checker_second(pm, ray.d); }
         }
-        for (uint32_t k = 0; k < NP; ++k) {
+        for (uint32_t k = 0; k < np; ++k) {
             const DevMaterial& pm = sc.materials[sc.planes[k].material];
             if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { if ((accepted >> (kMaxSpheres + k)) & 1u) second = checker_second(pm, ray.d); }
         }
-        const uint32_t row = (accepted & ((1u << NS) - 1u)) | (((accepted >> kMaxSpheres) & ((1u << NP) - 1u)) << NS) |
-                             ((second ? 1u : 0u) << (NS + NP)) | ((ndd_negative ? 1u : 0u) << (NS + NP + 1u));
+        uint32_t row = (accepted & ((1u << ns) - 1u)) | (((accepted >> kMaxSpheres) & ((1u << np) - 1u)) << ns);
+        uint32_t nb = ns + np;
+        if constexpr (SDF) {
+            const DevMaterial& pm = sc.materials[sc.sdf.material];
+            const uint32_t on = (accepted >> (kMaxSpheres + kMaxPlanes)) & 1u;
+            if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { if (on) second = checker_second(pm, ray.d); }
+            row |= on << nb;
+            nb += 1u;
+        }
+        row |= ((second ? 1u : 0u) << nb) | ((ndd_negative ? 1u : 0u) << (nb + 1u));
         const float4* r = rows + row * kMatRowFloat4s;
-        const float4 a = r[0], b = r[1], c = r[2], d = r[3], e = r[4], f = r[5], g = r[6];         // (the colours in c and d: mat_spec_col)
-        m.rgb = mk3(a.x, a.y, a.z);                 m.metallic = a.w;
-        m.emission = mk3(b.x, b.y, b.z);            m.roughness = b.w;
-        m.subsurface = c.w;
-        m.sheen = d.w;
-        m.clearcoat = e.x; m.clearcoat_roughness = e.y; m.spec_trans = e.z; m.ior = e.w;
-        m.ax = f.x; m.ay = f.y; eta = f.z; m.specular_tint = f.w;
-        m.sheen_tint = g.x; m.anisotropic = g.y; m.clearcoat_gloss = g.z;
+        const float4 em = r[1];
+        emission = mk3(em.x, em.y, em.z);
+        eta = r[4].w;
         m.more = r + kMatRowMore;
     }
 };
 // One row of that table (the lane that owns it calls this; any pass's functions: the row holds their results).
-template <uint32_t NS, uint32_t NP, class S>
-RPT_DEV void material_table_row(const S& sc, uint32_t row, float4* rows)
+template <bool SDF, class S>
+RPT_DEV void material_table_row(const S& sc, uint32_t ns, uint32_t np, uint32_t row, float4* rows)
 {
-    const bool second = (row >> (NS + NP)) & 1u, ndd_negative = (row >> (NS + NP + 1u)) & 1u;
+    const uint32_t nb = ns + np + (SDF ? 1u : 0u);
+    const bool second = (row >> nb) & 1u, ndd_negative = (row >> (nb + 1u)) & 1u;
     Mat m;
     mat_defaults(m);
-    for (uint32_t i = 0; i < NS; ++i) apply_patch_row(m, sc.materials[sc.spheres[i].material], (row >> i) & 1u, second);
-    for (uint32_t k = 0; k < NP; ++k) apply_patch_row(m, sc.materials[sc.planes[k].material], (row >> (NS + k)) & 1u, second);
+    for (uint32_t i = 0; i < ns; ++i) apply_patch_row(m, sc.materials[sc.spheres[i].material], (row >> i) & 1u, second);
+    for (uint32_t k = 0; k < np; ++k) apply_patch_row(m, sc.materials[sc.planes[k].material], (row >> (ns + k)) & 1u, second);
+    if constexpr (SDF) apply_patch_row(m, sc.materials[sc.sdf.material], (row >> (ns + np)) & 1u, second);
     mat_finalize(m);
     const float eta = ndd_negative ? fdiv(1.0f, m.ior) : m.ior;
     v3 spec_col, sheen_col;
@@ -740,12 +747,11 @@ RPT_DEV void material_table_row(const S& sc, uint32_t row, float4* rows)
     r[1] = make_float4(m.emission.x, m.emission.y, m.emission.z, m.roughness);
     r[2] = make_float4(spec_col.x, spec_col.y, spec_col.z, m.subsurface);
     r[3] = make_float4(sheen_col.x, sheen_col.y, sheen_col.z, m.sheen);
-    r[4] = make_float4(m.clearcoat, m.clearcoat_roughness, m.spec_trans, m.ior);
-    r[5] = make_float4(m.ax, m.ay, eta, m.specular_tint);
-    r[6] = make_float4(m.sheen_tint, m.anisotropic, m.clearcoat_gloss, 0.0f);
-    r[kMatRowMore + 0u] = make_float4(x.lum, x.w_diffuse, x.w_clearcoat, x.one_m_metallic);
-    r[kMatRowMore + 1u] = make_float4(x.dm, x.gtr1_a2m1, x.gtr1_k, x.cc_a2);
-    r[kMatRowMore + 2u] = make_float4(x.cc_one_m_a2, 0.0f, rpt_u2f((uint32_t)l2), rpt_u2f((uint32_t)(l2 >> 32)));
+    r[4] = make_float4(m.clearcoat, m.clearcoat_roughness, m.spec_trans, eta);
+    r[5] = make_float4(m.ax, m.ay, rpt_u2f((uint32_t)l2), rpt_u2f((uint32_t)(l2 >> 32)));
+    r[kMatRowMore + 0] = make_float4(x.lum, x.w_diffuse, x.w_clearcoat, x.one_m_metallic);
+    r[kMatRowMore + 1] = make_float4(x.dm, x.gtr1_a2m1, x.gtr1_k, x.cc_a2);
+    static_assert(kMatRowMore + 2 == (int)kMatRowFloat4s, "row layout");
 }
 
 // Head of direct_light (tracer.rs:130-145): pick a light, sample it.  Returns the facing test of tracer.rs:147.
@@ -1000,9 +1006,10 @@ RPT_DEV bool path_shade_full(const S& sc, const Q& q, PathRegs& p, const GeomHit
     ShadeFrame fr;
     if constexpr (M::kTable) {
         RPT_PROF(PB_FINALIZE);
-        materials.fetch(sc, p.ray, g.code, ndd < 0.0f, mat, eta);
+        v3 emission;
+        materials.fetch(sc, p.ray, g.code, ndd < 0.0f, mat, eta, emission);
         fr.spec_col = fr.sheen_col = mk3(0.0f, 0.0f, 0.0f);          // (not read: mat_spec_col)
-        p.radiance = p.radiance + mat.emission * p.throughput;
+        p.radiance = p.radiance + emission * p.throughput;
     } else {
         RPT_PROF(PB_FINALIZE);
         hit_material(sc, p.ray, g, mat);

@@ -449,6 +449,28 @@ RPT_DEV void lane_finish(const RenderParams& rp, float4 acc)
     unit_end(rp, true);
 }
 
+// The workgroup's material table (dev_integrator.h, MaterialTable): one row per lane of its first wave, built with the functions SHADE
+// would have called at a hit — over hipcc's own divide and sqrtf in the object that tracks operand ranges instead of testing them
+// (a row is built outside any sample: there is nobody to compute it a second time).  Every lane of the workgroup must get here.
+template <bool SDF, class S>
+RPT_DEV MaterialTable<SDF> material_table_build(const S& sc, uint32_t ns, uint32_t np, float4* rows)
+{
+    if (threadIdx.x < (4u << (ns + np + (SDF ? 1u : 0u)))) RPT_ROW_NS::material_table_row<SDF>(sc, ns, np, threadIdx.x, rows);
+    __syncthreads();
+    return MaterialTable<SDF>{rows, ns, np};
+}
+// Which scenes: the host's side of the same rule (render(), below).
+template <class S>
+inline bool material_table_fits(const S& sc, uint32_t sdf_material, bool has_sdf)
+{
+    if (sc.n_spheres + sc.n_planes + (has_sdf ? 1u : 0u) > kMatTableBits) return false;
+    uint32_t n_procedural = 0;
+    for (uint32_t i = 0; i < sc.n_spheres; ++i) n_procedural += sc.materials[sc.spheres[i].material].proc_kind != 0u;
+    for (uint32_t k = 0; k < sc.n_planes; ++k) n_procedural += sc.materials[sc.planes[k].material].proc_kind != 0u;
+    if (has_sdf) n_procedural += sc.materials[sdf_material].proc_kind != 0u;
+    return n_procedural <= 1u;
+}
+
 enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u, ST_MISS = 4u };
 
 // Three blocks, two waiting rooms.  TRACE (closest_hit's geometry pass + the emitter exit) runs at once for every lane that has a
@@ -603,18 +625,14 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 #endif
 #ifndef RPT_NO_SMALL_KERNELS
 #ifdef RPT_HAS_SIZED_KERNELS
-// ... and that reads a hit's material from a table of the 2^(2 + 1 + 2) cases there are (dev_integrator.h, MaterialTable), built here by
-// the workgroup's first 32 lanes with the functions SHADE would have called (over hipcc's own divide and sqrtf where this object
-// tracks operand ranges instead of testing them: a row is built outside any sample).  RPT_NO_MATERIAL_TABLE=1: the kernel below it.
+// ... and that reads a hit's material from a table of the 2^(2 + 1 + 2) cases there are (dev_integrator.h, MaterialTable).
+// RPT_NO_MATERIAL_TABLE=1: the kernel below it.
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_sized_table_kernel)(const SceneSmall sc, const RenderParams rp)
 {
     constexpr uint32_t sizes[3] = {RPT_REFERENCE_SIZES};
-    typedef MaterialTable<sizes[0], sizes[1]> Table;
-    __shared__ float4 s_rows[Table::kRows * kMatRowFloat4s];
+    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
     const SceneSmall& s = sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc));
-    if (threadIdx.x < Table::kRows) RPT_ROW_NS::material_table_row<sizes[0], sizes[1]>(s, threadIdx.x, s_rows);
-    __syncthreads();
-    render_regen_body(s, rp, Table{s_rows});
+    render_regen_body(s, rp, material_table_build<false>(s, sizes[0], sizes[1], s_rows));
 }
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_sized_kernel)(const SceneSmall sc, const RenderParams rp)
 {
@@ -978,8 +996,8 @@ RPT_DEV bool compact_finish(const S& sc, const RenderParams& rp, uint32_t i, Pat
 // Per pass two barriers:  TRACE for the trace list (closest_hit only: surface -> S, miss / emitter -> F)  |  SHADE for the
 // entries of S from thread 0 up and, at the same time, FINISH (background for a miss, blend, the pixel's next camera path)
 // for the entries of F from thread 255 down — |S| + |F| <= 256, so at most one wave has both kinds.
-template <class S>
-RPT_DEV void render_compact_body(const S& sc, const RenderParams& launch)
+template <class MS = MaterialPerHit, class S>
+RPT_DEV void render_compact_body(const S& sc, const RenderParams& launch, const MS& materials = MS{})
 {
     constexpr bool M = S::kMedia;
     RenderParams rp = launch;
@@ -1044,7 +1062,7 @@ RPT_DEV void render_compact_body(const S& sc, const RenderParams& launch)
                 GeomHit g;
                 g.code = gcode;
                 uint32_t s = ctl >> 1;
-                if (path_shade_full(sc, DirectQuery{}, p, g)) to_trace = compact_finish(sc, rp, i, p, s);
+                if (path_shade_full(sc, DirectQuery{}, p, g, nullptr, nullptr, materials)) to_trace = compact_finish(sc, rp, i, p, s);
                 else to_trace = true;
                 if (to_trace) wf_rec_put<M>(rec, i, p, 0u, s << 1);
             } else if (255u - tid < n_f) {
@@ -1082,6 +1100,21 @@ __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_
 __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_sized_kernel)(const SceneSmall sc, const RenderParams rp)
 {
     render_compact_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
+}
+// ... with the material table (dev_integrator.h, MaterialTable)
+__global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_sized_table_kernel)(const SceneSmall sc, const RenderParams rp)
+{
+    constexpr uint32_t sizes[3] = {RPT_REFERENCE_SIZES};
+    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
+    const SceneSmall& s = sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc));
+    render_compact_body(s, rp, material_table_build<false>(s, sizes[0], sizes[1], s_rows));
+}
+__global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_sized_table_kernel)(const SceneSmall sc, const RenderParams rp)
+{
+    constexpr uint32_t sizes[3] = {RPT_REFERENCE_SIZES};
+    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
+    const SceneSmall& s = sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc));
+    render_compact_body(s, rp, material_table_build<false>(s, sizes[0], sizes[1], s_rows));
 }
 #endif
 #endif
@@ -1741,10 +1774,7 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
     const uint32_t sized_sdf = (!no_sized && !media && has_sdf && !nested && sc.n_planes == 1u && sc.n_lights == 1u && scs.sdf.n_prims <= 4u) ? scs.sdf.n_prims : 0u;
     // ... and that read materials from a table: at most one primitive with a procedural material (MaterialTable)
     static const bool no_table = getenv("RPT_NO_MATERIAL_TABLE") && atoi(getenv("RPT_NO_MATERIAL_TABLE")) != 0;
-    uint32_t n_procedural = 0;
-    for (uint32_t i = 0; i < sc.n_spheres && i < (uint32_t)kMaxSpheres; ++i) n_procedural += sc.materials[sc.spheres[i].material].proc_kind != 0u;
-    for (uint32_t k = 0; k < sc.n_planes && k < (uint32_t)kMaxPlanes; ++k) n_procedural += sc.materials[sc.planes[k].material].proc_kind != 0u;
-    const bool one_procedural = n_procedural <= 1u;
+    const bool one_procedural = !large && material_table_fits(sc, scs.sdf.material, has_sdf);
     (void)sized; (void)sized_sdf; (void)no_table; (void)one_procedural;
 #ifdef RPT_NO_LARGE_SDF_KERNELS
     if (large || has_sdf || (rp.compact && !nested)) return rptlaunch_perop::render(scs, scl, large, nested, rp, nblocks, st, scs_dev, media);   // (the RPT_PEROP_BUILD object)
@@ -1812,6 +1842,8 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #endif
 #ifndef RPT_NO_COMPACT_KERNELS
 #ifdef RPT_HAS_SIZED_KERNELS
+    else if (rp.compact && nblocks <= 3072u && sized && one_procedural && !no_table) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_sized_table_kernel), tiles, wg, 0, st, sc, rp);
+    else if (rp.compact && sized && one_procedural && !no_table) hipLaunchKernelGGL(RPT_K(render_small_compact_sized_table_kernel), tiles, wg, 0, st, sc, rp);
     else if (rp.compact && nblocks <= 3072u && sized) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_sized_kernel), tiles, wg, 0, st, sc, rp);
     else if (rp.compact && sized) hipLaunchKernelGGL(RPT_K(render_small_compact_sized_kernel), tiles, wg, 0, st, sc, rp);
 #endif
