@@ -374,7 +374,7 @@ int rpt_set_tile_rows(rpt_ctx* ctx, uint32_t tile_rows);
  *                  launch of the same shape, so that the cheap ones fill the launch's tail; 0: bottom rows first, always
  *   unit_rounds    a launch whose tiles are fewer than this many rounds of workgroups on the device (default 12) is cut into
  *                  chunks of samples until they are — a tile's chunks are handed from workgroup to workgroup through HBM, in
- *                  order —; 0: one unit per tile (and launches of more samples than the kernel's sample tables hold — 512, 480 for
+ *                  order —; 0: one unit per tile (and launches of more samples than the kernel's sample tables hold — 512, 192 for
  *                  scenes with the SDF object — are still one launch: chunks of that many)
  *   unit_min_spp   ... but no chunk shorter than this many samples (default 64)
  *   unit_slots     workgroups the device holds at once; 0 (default): 5 per compute unit

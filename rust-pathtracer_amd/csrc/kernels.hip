@@ -382,9 +382,9 @@ __global__ __launch_bounds__(256) void RPT_K(render_sdf_nested_media_kernel)(con
 #define RPT_MAX_SPP_PER_LAUNCH 512
 #endif
 constexpr uint32_t kMaxSppPerLaunch = RPT_MAX_SPP_PER_LAUNCH;
-// ... of the SDF march kernel: its workgroup also parks three float4 per lane, and with the range trackers' 2 KB (dev_math.h) 512
-// entries would put it 24 bytes over the 32 KB that let five workgroups share a CU's LDS
-constexpr uint32_t kMaxSppPerLaunchSdf = RPT_MAX_SPP_PER_LAUNCH < 480 ? RPT_MAX_SPP_PER_LAUNCH : 480;
+// ... of the SDF march kernel: its workgroup also parks four float4 per lane and keeps a material table (4 KB); 192 entries leave it
+// within the 32 KB that let five workgroups share a CU's LDS
+constexpr uint32_t kMaxSppPerLaunchSdf = RPT_MAX_SPP_PER_LAUNCH < 192 ? RPT_MAX_SPP_PER_LAUNCH : 192;
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd argument of
 // __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
@@ -1256,8 +1256,8 @@ __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_
 // for the lanes that wait.
 enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u };
 
-template <class S>
-RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch)
+template <class MS = MaterialPerHit, class S>
+RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, const MS& materials = MS{})
 {
     RPT_PROF_INIT();
     __shared__ FrameKey s_fkey[kMaxSppPerLaunchSdf];
@@ -1368,7 +1368,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch)
                 else {
                     // (pending comes back through the parked ray: the query marks it in the slot's direction.w)
                     s_shd[tid].w = 1.0f;
-                    over = path_shade_full(sc, q, p, g);
+                    over = path_shade_full(sc, q, p, g, nullptr, nullptr, materials);
                     pending = s_shd[tid].w == 0.0f;
                 }
             }
@@ -1419,6 +1419,15 @@ void RPT_K(render_sdf_march2_kernel)(const SceneSmallSdf sc, const RenderParams 
 template <uint32_t NPRIMS>
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD)
 void RPT_K(render_sdf_march2_sized_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body(sized_sdf_scene<NPRIMS>(kernarg_scene(sc)), rp); }
+// ... with the material table (dev_integrator.h, MaterialTable): at most one analytical sphere beside the plane and the object
+template <uint32_t NPRIMS>
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD)
+void RPT_K(render_sdf_march2_sized_table_kernel)(const SceneSmallSdf sc, const RenderParams rp)
+{
+    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
+    const SceneSmallSdf& s = sized_sdf_scene<NPRIMS>(kernarg_scene(sc));
+    render_sdf_march2_body(s, rp, material_table_build<true>(s, s.n_spheres, 1u, s_rows));
+}
 #endif
 #endif
 #ifndef RPT_NO_MEDIA_KERNELS
@@ -1830,6 +1839,10 @@ hipError_t render(const SceneSmallSdf& scs, const SceneLarge& scl, bool large, b
 #ifndef RPT_NO_LARGE_SDF_KERNELS
     else if (large) hipLaunchKernelGGL(RPT_K(render_large_regen_kernel), tiles, wg, 0, st, scl, rp);
 #ifdef RPT_HAS_SIZED_KERNELS
+    else if (sized_sdf == 1u && one_procedural && !no_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<1u>, tiles, wg, 0, st, scs, rp);
+    else if (sized_sdf == 2u && one_procedural && !no_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<2u>, tiles, wg, 0, st, scs, rp);
+    else if (sized_sdf == 3u && one_procedural && !no_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<3u>, tiles, wg, 0, st, scs, rp);
+    else if (sized_sdf == 4u && one_procedural && !no_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<4u>, tiles, wg, 0, st, scs, rp);
     else if (sized_sdf == 1u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<1u>, tiles, wg, 0, st, scs, rp);
     else if (sized_sdf == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<2u>, tiles, wg, 0, st, scs, rp);
     else if (sized_sdf == 3u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<3u>, tiles, wg, 0, st, scs, rp);

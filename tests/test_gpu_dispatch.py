@@ -241,12 +241,26 @@ for name, scene in cases:
 
 
 def _table_scene(rpt, which):
-    """Scenes of the reference's table sizes for the material table (dev_integrator.h, MaterialTable): what a row depends on."""
+    """Scenes for the material table (dev_integrator.h, MaterialTable): what a row depends on, and what rules a table out."""
     from rust_pathtracer_amd import scenes
     from scene_fuzz import random_small_scene
     if isinstance(which, int):                                        # random materials, random scale (2^-33 ... 2^33), roulette or not
         s, _, flags, _ = random_small_scene(rpt, which, n_spheres=2, n_lights=1)
         return s, flags
+    if isinstance(which, str) and which.startswith("sdf"):
+        # the SDF march kernel's table: the plane, the object and at most one analytical sphere (3 bits + colour + side = 32 rows)
+        s = scenes.sdf_scene()
+        if which == "sdf no sphere":
+            s.spheres = []
+        elif which == "sdf two spheres":                              # 4 primitives: no table
+            s.spheres = list(s.spheres) + [((-1.8, -0.5, 0.9), 0.5, 0)]
+        elif which == "sdf checker object":                           # the one procedural material on the object, glass beside it
+            s.materials = [rpt.Material(roughness=0.4, checker_dir=(3.0, 11.0, 0.8, 0.1)),
+                           scenes.full_material(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5),
+                           rpt.Material(rgb=(0.5, 0.5, 0.5), roughness=0.7, metallic=1.0)]
+        else:
+            assert which == "sdf"
+        return s, 0
     s = rpt.AnalyticalScene()
     if which == "overlapping patches":
         # two spheres through each other whose patches write DIFFERENT fields: a hit on the second after the first was accepted
@@ -282,15 +296,18 @@ def _table_scene(rpt, which):
     return s, 0
 
 
-_TABLE_CASES = ["reference", "overlapping patches", "camera inside glass", "checker on a sphere", "two checkers", 2, 5, 9, 13, 17, 21, 26, 33]
+_TABLE_CASES = ["reference", "overlapping patches", "camera inside glass", "checker on a sphere", "two checkers", "sdf", "sdf no sphere", "sdf two spheres",
+                "sdf checker object", 2, 5, 9, 13, 17, 21, 26, 33]
 
 
 def test_the_material_table_holds_what_every_hit_would_compute(rpt, oracle, torch_cuda):
-    """The megakernel for scenes of the reference's table sizes reads a hit's finalized material, eta and the specular / sheen colours
-    from a table of the 32 cases (accepted primitives x checker colour x side), built once per workgroup
-    (kernels.hip, render_small_regen_sized_table_kernel); RPT_NO_MATERIAL_TABLE=1 takes the kernel that computes them at every hit.
-    Same frames, and the oracle's: patches that write different fields on overlapping spheres, a camera inside a glass sphere, the
-    procedural material on a sphere, two of them (no table), random materials at random scales with and without roulette."""
+    """The kernels for scenes of the reference's table sizes (megakernel, compacting kernel of one-sample launches) and for an SDF
+    object over one plane read what the BSDF code needs of a hit's material — the finalized fields, eta, the specular / sheen
+    colours, the lobe weights' numerators, gtr1's constants — from a table of the cases there are (accepted primitives x checker
+    colour x side), built once per workgroup (dev_integrator.h, MaterialTable); RPT_NO_MATERIAL_TABLE=1 takes the kernels that
+    compute them at every hit.  Same frames, and the oracle's: patches that write different fields on overlapping spheres, a camera
+    inside a glass sphere, the procedural material on a sphere or on the SDF object, two of them or four primitives (no table),
+    random materials at random scales with and without roulette."""
     import os
     import subprocess
     import sys
@@ -306,7 +323,7 @@ for which in T._TABLE_CASES:
     t = rpt.Tracer(scene, device=0, seed=5)
     t.flags = flags
     buf = rpt.DeviceColorBuffer(176, 96)
-    for n in (2, 7):
+    for n in (1, 2, 7):                                               # (1: the compacting kernel)
         t.render_n(buf, n)
     torch.cuda.synchronize()
     print("HASH", which, hashlib.sha1(buf.pixels.cpu().numpy().tobytes()).hexdigest())
@@ -326,8 +343,8 @@ for which in T._TABLE_CASES:
         t = rpt.Tracer(s, device=0, seed=2)
         t.flags = flags
         buf = rpt.DeviceColorBuffer(w, h)
-        t.render_n(buf, 2)
-        t.render_n(buf, 3)
+        for n in (1, 1, 3):
+            t.render_n(buf, n)
         torch_cuda.cuda.synchronize()
         got = buf.pixels.cpu().numpy()
         t.close()
