@@ -194,7 +194,7 @@ def other_configs(rpt, torch, device, small):
     sdf = scenes.sdf_scene()
     w, h, spp = 1920 // div, 1080 // div, 64 // (4 if small else 1)
     t = run(sdf, w, h, spp, 3)
-    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march2_sized_kernel_perop<3u>", 1, w * h)
+    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march2_sized_table_kernel_perop<3u>", 1, w * h)
     blk.update({"workload": "SDF sphere-march scene %dx%d x %d spp per step (BASELINE.json configs[3])" % (w, h, spp),
                 "value": round(w * h * spp / t / 1e6, 2), "value_unit": "Msamples/s"})
     if not small:
@@ -315,7 +315,7 @@ def config1_line(rpt, torch, device, threads):
     return {"workload": "AnalyticalScene 800x600 x 1 spp per call (BASELINE.json configs[0]: one reference render())",
             "cpu_ms_per_call": round(cpu_s * 1e3, 3), "cpu_value": round(w * h / cpu_s / 1e6, 2), "cpu_cores": threads, "cpu_kind": "port",
             "gpu_ms_per_call": round(gpu_s * 1e3, 4), "gpu_value": round(w * h / gpu_s / 1e6, 1), "unit": "Msamples/s",
-            "gpu_kernel": "render_small_compact_dense_sized_kernel_perop", "gpu_over_cpu": round(cpu_s / gpu_s, 1)}
+            "gpu_kernel": "render_small_compact_dense_sized_table_kernel_perop", "gpu_over_cpu": round(cpu_s / gpu_s, 1)}
 
 
 class TorchGatherRender:
@@ -438,7 +438,7 @@ def main():
         algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
         hbm = algo_bytes / avg_kernel_s / 1e9
         launches = 1                              # one launch whatever spp is (kernels.hip: a launch is tiles x chunks of samples)
-        kernel = "render_small_regen_sized_table_kernel" if spp > 1 else "render_small_compact_sized_kernel_perop"     # (capi.hip: RPT_COMPACT_MAX_SPP; kernels.hip: sized_scene)
+        kernel = "render_small_regen_sized_table_kernel" if spp > 1 else "render_small_compact_sized_table_kernel_perop"     # (capi.hip: RPT_COMPACT_MAX_SPP; kernels.hip: sized_scene)
         roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels, tracked=spp > 1)
         roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
                             "rounded f32 divide or sqrt costs 8-13 VALU instructions in this library (ieee_expanded_*); kernel_ms = HIP events on the launch stream")
