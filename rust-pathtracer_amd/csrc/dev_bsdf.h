@@ -272,11 +272,11 @@ RPT_DEV v3 eval_diffuse(const MT& m, v3 c_sheen, v3 v, v3 l, v3 h, float& pdf)  
 }
 
 template <class MT>
-RPT_DEV v3 eval_spec_reflection(const MT& m, float eta, v3 spec_col, v3 v, v3 l, v3 h, float& pdf)   // tracer.rs:368
+RPT_DEV v3 eval_spec_reflection(const MT& m, float eta, v3 spec_col, v3 v, v3 l, v3 h, float& pdf, float fm)   // tracer.rs:368
 {
+    // fm = disney_fresnel(m, eta, dot3(l, h), dot3(v, h)) (tracer.rs:372): disney_eval, the only caller, has just computed it (tracer.rs:572)
     pdf = 0.0f;
     if (l.z <= 0.0f) return mk3(0.0f, 0.0f, 0.0f);
-    float fm = disney_fresnel(m, eta, dot3(l, h), dot3(v, h));
     v3 f = mix3(spec_col, mk3(1.0f, 1.0f, 1.0f), fm);
     float d = gtr2aniso(h.z, h.x, h.y, mat_ax(m), mat_ay(m));
     float g1 = smithganiso(__builtin_fabsf(v.z), v.x, v.y, mat_ax(m), mat_ay(m));
@@ -431,6 +431,10 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
     v3 other;                  // the arm's other vector: l (diffuse), h (the others)
     bool reflected = true;
     float ff = 1.0f;
+    // the dielectric Fresnel term of the arm's half vector: the specular arm needs it to choose between reflection and refraction
+    // (tracer.rs:527), eval_spec_reflection needs the same value again (tracer.rs:372), eval_clearcoat its own (tracer.rs:409): computed
+    // once, in the arm
+    float dfr = 0.0f;
     if (is_d) {
         RPT_PROF(PB_LOBE_DIFFUSE);
         v3 l;                                                       // cosine_sample_hemisphere, tracer.rs:324
@@ -445,6 +449,7 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
         float sin_theta = clamp01(fsqrt(1.0f - (cos_theta * cos_theta)));
         v3 h = mk3(sin_theta * cs, sin_theta * sn, cos_theta);
         if (h.z < 0.0f) h = -h;
+        dfr = dielectric_fresnel(dot3(v, h), 1.0f / 1.5f);
         pre = reflect3(-v, h);
         other = h;
     } else {
@@ -461,7 +466,8 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
         v3 nh = t1 * t_1 + t2 * t_2 + fsqrt(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
         v3 h = norm3(mk3(mat_ax(m) * nh.x, mat_ay(m) * nh.y, rmax(0.0f, nh.z)));
         if (h.z < 0.0f) h = -h;
-        float fresnel = disney_fresnel(m, eta, dot3(l_io, h), dot3(v, h));
+        dfr = dielectric_fresnel(__builtin_fabsf(dot3(v, h)), eta);
+        float fresnel = mixf(dfr, schlick_fresnel(dot3(l_io, h)), mat_metallic(m));            // disney_fresnel, tracer.rs:435
         ff = 1.0f - ((1.0f - fresnel) * mat_spec_trans(m) * (1.0f - mat_metallic(m)));
         float rnd = rng.gen();
         reflected = rnd < ff;
@@ -485,8 +491,7 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
         // eval_clearcoat (tracer.rs:404-419) and eval_spec_reflection (tracer.rs:368-382) side by side
         RPT_PROF(PB_LOBE_SPEC);
         if (!(l.z <= 0.0f)) {                                       // tracer.rs:370, 406
-            const float vdh = dot3(v, h);
-            const float dfr = dielectric_fresnel(is_c ? vdh : __builtin_fabsf(vdh), is_c ? (1.0f / 1.5f) : eta);
+            const float vdh = dot3(v, h);                           // (dfr: dielectric_fresnel(is_c ? vdh : |vdh|, is_c ? 1 / 1.5 : eta), from the arm)
             float d;                                                // the normal-distribution term
             float e_v, e_l;                                         // what each Smith term takes the root of
             v3 fcol;
@@ -561,7 +566,7 @@ RPT_DEV v3 disney_eval(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3 l_
         bsdf_pdf += pdf * w.diffuse;
     }
     if (w.spec_reflect > 0.0f && l.z > 0.0f && v.z > 0.0f) {
-        f = f + eval_spec_reflection(m, eta, mat_spec_col(m, fr), v, l, h, pdf);
+        f = f + eval_spec_reflection(m, eta, mat_spec_col(m, fr), v, l, h, pdf, fresnel);
         bsdf_pdf += pdf * w.spec_reflect;
     }
     if (w.spec_refract > 0.0f && l.z < 0.0f) {
