@@ -552,9 +552,9 @@ RPT_DEV v3 disney_eval(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3 l_
     const v3 t = fr.t, b = fr.b, v = fr.v;
     v3 l = to_local(t, b, n, l_world);
 
-    v3 h;
-    if (l.z > 0.0f) h = norm3(l + v);
-    else h = norm3(l + eta * v);
+    // tracer.rs:566-570: h = normalize(l + v) above the surface, normalize(l + eta * v) below.  One normalize for both (1 * v is v):
+    // as an if / else a wave with lanes on either side runs two.
+    v3 h = norm3(l + ((l.z > 0.0f) ? 1.0f : eta) * v);
     if (h.z < 0.0f) h = -h;
 
     float fresnel = disney_fresnel(m, eta, dot3(l, h), dot3(v, h));
