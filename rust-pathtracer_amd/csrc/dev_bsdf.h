@@ -433,8 +433,9 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
     float ff = 1.0f;
     // the dielectric Fresnel term of the arm's half vector: the specular arm needs it to choose between reflection and refraction
     // (tracer.rs:527), eval_spec_reflection needs the same value again (tracer.rs:372), eval_clearcoat its own (tracer.rs:409): computed
-    // once, in the arm
+    // once, for both arms at once, together with what else they have in common: h's flip into the upper hemisphere and the reflection
     float dfr = 0.0f;
+    v3 hs = mk3(0.0f, 0.0f, 1.0f);                                  // the sampled half vector of the clearcoat / specular arm
     if (is_d) {
         RPT_PROF(PB_LOBE_DIFFUSE);
         v3 l;                                                       // cosine_sample_hemisphere, tracer.rs:324
@@ -447,11 +448,7 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
         RPT_PROF(PB_LOBE_CLEARCOAT);
         float cos_theta = mat_cc_cos_theta(m, r1);                  // sample_gtr1, tracer.rs:242 (r2 is unused there)
         float sin_theta = clamp01(fsqrt(1.0f - (cos_theta * cos_theta)));
-        v3 h = mk3(sin_theta * cs, sin_theta * sn, cos_theta);
-        if (h.z < 0.0f) h = -h;
-        dfr = dielectric_fresnel(dot3(v, h), 1.0f / 1.5f);
-        pre = reflect3(-v, h);
-        other = h;
+        hs = mk3(sin_theta * cs, sin_theta * sn, cos_theta);
     } else {
         RPT_PROF(PB_LOBE_SPEC);
         v3 vh = norm3(mk3(mat_ax(m) * v.x, mat_ay(m) * v.y, v.z));            // sample_ggxvndf, tracer.rs:256
@@ -464,13 +461,19 @@ RPT_DEV v3 disney_sample(const MT& m, float eta, const ShadeFrame& fr, v3 n, v3&
         float s = 0.5f * (1.0f + vh.z);
         t2 = (1.0f - s) * fsqrt(1.0f - t1 * t1) + s * t2;
         v3 nh = t1 * t_1 + t2 * t_2 + fsqrt(rmax(0.0f, 1.0f - t1 * t1 - t2 * t2)) * vh;
-        v3 h = norm3(mk3(mat_ax(m) * nh.x, mat_ay(m) * nh.y, rmax(0.0f, nh.z)));
-        if (h.z < 0.0f) h = -h;
-        dfr = dielectric_fresnel(__builtin_fabsf(dot3(v, h)), eta);
-        float fresnel = mixf(dfr, schlick_fresnel(dot3(l_io, h)), mat_metallic(m));            // disney_fresnel, tracer.rs:435
-        ff = 1.0f - ((1.0f - fresnel) * mat_spec_trans(m) * (1.0f - mat_metallic(m)));
-        float rnd = rng.gen();
-        reflected = rnd < ff;
+        hs = norm3(mk3(mat_ax(m) * nh.x, mat_ay(m) * nh.y, rmax(0.0f, nh.z)));
+    }
+    if (!is_d) {
+        v3 h = hs;
+        if (h.z < 0.0f) h = -h;                                     // tracer.rs:513, 524
+        const float vdh = dot3(v, h);
+        dfr = dielectric_fresnel(is_c ? vdh : __builtin_fabsf(vdh), is_c ? (1.0f / 1.5f) : eta);
+        if (is_s) {
+            float fresnel = mixf(dfr, schlick_fresnel(dot3(l_io, h)), mat_metallic(m));        // disney_fresnel, tracer.rs:435
+            ff = 1.0f - ((1.0f - fresnel) * mat_spec_trans(m) * (1.0f - mat_metallic(m)));
+            float rnd = rng.gen();
+            reflected = rnd < ff;
+        }
         if (reflected) pre = reflect3(-v, h);
         else pre = refract3(-v, h, eta);
         other = h;
