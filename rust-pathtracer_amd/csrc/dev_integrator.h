@@ -96,14 +96,15 @@ RPT_DEV void apply_patch_fields(Mat& m, const DevMaterial& p, bool on)
     if (p.mask & RPT_MAT_IOR) m.ior = on ? p.ior : m.ior;
 }
 // The checker of analytical.rs:107-115 along a ray's direction: true on the squares of the SECOND colour (proc_params[3]).
-RPT_DEV bool checker_second(const DevMaterial& p, v3 dir)
+RPT_DEV bool checker_second(float scale, float offset, v3 dir)
 {
-    float x = fdiv(dir.x, dir.y) * p.proc_params[0] + p.proc_params[1];
-    float y = fdiv(dir.z, dir.y) * p.proc_params[0] + p.proc_params[1];
+    float x = fdiv(dir.x, dir.y) * scale + offset;
+    float y = fdiv(dir.z, dir.y) * scale + offset;
     float x1 = rem2(__builtin_floorf(x));
     float y1 = rem2(__builtin_floorf(y));
     return !(rem2(x1 + y1) < 1.0f);
 }
+RPT_DEV bool checker_second(const DevMaterial& p, v3 dir) { return checker_second(p.proc_params[0], p.proc_params[1], dir); }
 RPT_DEV void apply_patch(Mat& m, const DevMaterial& p, bool on, v3 dir)
 {
     apply_patch_fields(m, p, on);
@@ -695,25 +696,20 @@ struct MaterialTable {
     typedef MatRow MatType;
     const float4* rows;
     uint32_t ns, np;                           // the scene's n_spheres and n_planes (literals in the kernels that know them)
+    // the one procedural material there may be: its primitive's bit in the accepted mask (0: none) and the checker's scale and offset —
+    // found once per workgroup (material_table_procedural), not behind two dependent scalar loads per primitive at every hit
+    uint32_t proc_bit;
+    float proc_scale, proc_offset;
     template <class S>
     RPT_DEV void fetch(const S& sc, const RayD& ray, uint32_t accepted, bool ndd_negative, MatRow& m, float& eta, v3& emission) const
     {
+        (void)sc;
         bool second = false;
-        for (uint32_t i = 0; i < ns; ++i) {
-            const DevMaterial& pm = sc.materials[sc.spheres[i].material];
-            if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { if ((accepted >> i) & 1u) second = checker_second(pm, ray.d); }
-        }
-        for (uint32_t k = 0; k < np; ++k) {
-            const DevMaterial& pm = sc.materials[sc.planes[k].material];
-            if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { if ((accepted >> (kMaxSpheres + k)) & 1u) second = checker_second(pm, ray.d); }
-        }
+        if (proc_bit != 0u) { if (accepted & proc_bit) second = checker_second(proc_scale, proc_offset, ray.d); }
         uint32_t row = (accepted & ((1u << ns) - 1u)) | (((accepted >> kMaxSpheres) & ((1u << np) - 1u)) << ns);
         uint32_t nb = ns + np;
         if constexpr (SDF) {
-            const DevMaterial& pm = sc.materials[sc.sdf.material];
-            const uint32_t on = (accepted >> (kMaxSpheres + kMaxPlanes)) & 1u;
-            if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { if (on) second = checker_second(pm, ray.d); }
-            row |= on << nb;
+            row |= ((accepted >> (kMaxSpheres + kMaxPlanes)) & 1u) << nb;
             nb += 1u;
         }
         row |= ((second ? 1u : 0u) << nb) | ((ndd_negative ? 1u : 0u) << (nb + 1u));
@@ -724,6 +720,24 @@ struct MaterialTable {
         m.more = r + kMatRowMore;
     }
 };
+// The table's procedural primitive: wave-uniform, looked up once per workgroup.
+template <bool SDF, class S>
+RPT_DEV void material_table_procedural(const S& sc, uint32_t ns, uint32_t np, MaterialTable<SDF>& t)
+{
+    t.proc_bit = 0u; t.proc_scale = 0.0f; t.proc_offset = 0.0f;
+    for (uint32_t i = 0; i < ns; ++i) {
+        const DevMaterial& pm = sc.materials[sc.spheres[i].material];
+        if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { t.proc_bit = 1u << i; t.proc_scale = pm.proc_params[0]; t.proc_offset = pm.proc_params[1]; }
+    }
+    for (uint32_t k = 0; k < np; ++k) {
+        const DevMaterial& pm = sc.materials[sc.planes[k].material];
+        if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { t.proc_bit = 1u << (kMaxSpheres + k); t.proc_scale = pm.proc_params[0]; t.proc_offset = pm.proc_params[1]; }
+    }
+    if constexpr (SDF) {
+        const DevMaterial& pm = sc.materials[sc.sdf.material];
+        if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { t.proc_bit = 1u << (kMaxSpheres + kMaxPlanes); t.proc_scale = pm.proc_params[0]; t.proc_offset = pm.proc_params[1]; }
+    }
+}
 // One row of that table (the lane that owns it calls this; any pass's functions: the row holds their results).
 template <bool SDF, class S>
 RPT_DEV void material_table_row(const S& sc, uint32_t ns, uint32_t np, uint32_t row, float4* rows)

@@ -457,7 +457,10 @@ RPT_DEV MaterialTable<SDF> material_table_build(const S& sc, uint32_t ns, uint32
 {
     if (threadIdx.x < (4u << (ns + np + (SDF ? 1u : 0u)))) RPT_ROW_NS::material_table_row<SDF>(sc, ns, np, threadIdx.x, rows);
     __syncthreads();
-    return MaterialTable<SDF>{rows, ns, np};
+    MaterialTable<SDF> t;
+    t.rows = rows; t.ns = ns; t.np = np;
+    material_table_procedural(sc, ns, np, t);
+    return t;
 }
 // Which scenes: the host's side of the same rule (render(), below).
 template <class S>
