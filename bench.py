@@ -215,8 +215,9 @@ def other_configs(rpt, torch, device, small):
                                "kernel_ms": round(t8 * 1e3, 3), "value": round(w * h * 8 / t8 / 1e6, 2),
                                "frac": round(ops["flops_per_sample"] * w * h * 8 / t8 / 1e12 / FP32_PEAK_TFLOPS, 5)}
     if not small:
-        # (the committed counters are of the same kernel on the 2048 x 2048 x 32-spp frame: 2 x 16 B per pixel + the spills)
-        blk["progressive_8spp"]["traffic_2048x2048x32"], blk["traffic_source"] = committed_traffic("c5")
+        # (the committed counters: of this very launch, and of the same kernel on the 2048 x 2048 x 32-spp frame: 2 x 16 B per pixel + the spills)
+        blk["traffic"], blk["traffic_source"] = committed_traffic("c5_full")
+        blk["progressive_8spp"]["traffic_2048x2048x32"] = committed_traffic("c5")[0]
     out["roofline_c5"] = blk
     # the denoiser (include/rpt.h, project-defined): an HBM pass, 32 B per pixel per iteration
     for name, (dw, dh) in (("roofline_denoise_1080p", (1920 // div, 1080 // div)), ("roofline_denoise_4k", (3840 // div, 2160 // div))):
