@@ -387,7 +387,7 @@ void oracle_rng_f32(uint64_t seed, uint64_t frame, uint32_t pixel, uint32_t n, f
 }
 
 // element-wise math through the oracle's f_* layer (strict or glibc per build)
-// fn: 0 sin, 1 cos, 2 log2, 3 pow(a,b), 4 a/b, 5 sqrt, 7 tan
+// fn: 0 sin, 1 cos, 2 log2, 3 pow(a,b), 4 a/b, 5 sqrt, 7 exp, 8 ln, 9 three quotients, 10 rpt_powf_log2x (strict header, any build), 100 tan
 void oracle_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n)
 {
     for (uint64_t i = 0; i < n; ++i) {
@@ -404,6 +404,12 @@ void oracle_math(uint32_t fn, const float* a, const float* b, float* out, uint64
             const float x = a[i], d = b[i];
             const float qx = (i & 4u) ? x / d : x / d, qy = (i & 4u) ? (0.5f * d) / d : (-d) / d, qz = (i & 4u) ? 0.0f / d : (0.75f * x) / d;
             out[i] = (i % 3u == 0u) ? qx : ((i % 3u == 1u) ? qy : qz);
+            break;
+        }
+        case 10: {                                          // pow with the base's logarithm handed in (the library's material tables)
+            const uint32_t ia = rpt_f2u(a[i]);
+            const double la = (ia - 1u < 0x7f7fffffu) ? rpt_log2_core(a[i]) : 0.0;
+            out[i] = rpt_powf_log2x(a[i], la, b[i]);
             break;
         }
         case 100: out[i] = raw(f_tan(a[i])); break;         // host only (the camera's fov)

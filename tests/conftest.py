@@ -33,10 +33,8 @@ def pytest_configure(config):
 
 
 def _build_oracle():
-    libdir = os.path.join(ROOT, "oracle", "build")
-    need = ["liboracle.so", "liboracle_libm.so", "liboracle_opcount.so"]
-    if not all(os.path.exists(os.path.join(libdir, n)) for n in need):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
+    # always: make is a no-op when the libraries are newer than the oracle's sources, and a stale one would test yesterday's oracle
+    subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True, capture_output=True)
 
 
 @pytest.fixture(scope="session")

@@ -144,3 +144,21 @@ def test_exp_and_log_accuracy_and_special_cases(oracle, oracle_libm):
     assert l[0] == -np.inf and l[1] == -np.inf and l[2] == np.inf and np.isnan(l[3]) and np.isnan(l[4]) and l[5] == 0.0 and np.isnan(l[6])
     assert (oracle.math(7, x) == oracle_libm.math(7, x)).mean() > 0.99
     assert (oracle.math(8, y) == oracle_libm.math(8, y)).mean() > 0.99
+
+
+def test_pow_with_the_logarithm_handed_in_is_pow(oracle):
+    """rpt_powf_log2x(x, rpt_log2_core(x), y) — what the library's material tables call for a roughness whose logarithm a row keeps
+    (csrc/dev_bsdf.h, mat_cc_cos_theta) — is rpt_powf(x, y) bit for bit: random operands, and every special case of the C99 table."""
+    rng = np.random.default_rng(9)
+    n = 400_000
+    x = np.concatenate([rng.uniform(0.0, 2.0, n), rng.uniform(1e-6, 1e-2, n), np.exp(rng.uniform(-80, 80, n)), -rng.uniform(0.0, 4.0, n // 8)]).astype(np.float32)
+    y = np.concatenate([rng.uniform(0, 1, n), rng.uniform(-1.5, 1.5, n), rng.choice([2.2, 0.5, 0.4545, 3.0, -2.0], n), rng.choice([2.0, 3.0, 0.5], n // 8)]).astype(np.float32)
+    inf, nan = np.inf, np.nan
+    sx = np.array([0.0, -0.0, 1.0, inf, -inf, nan, 1e-45, 3.4e38, -1.0, 2.0, 0.5], dtype=np.float32)
+    sy = np.array([0.0, -0.0, 1.0, inf, -inf, nan, 0.5, -1.0, 3.0, 200.0, -200.0, 16777217.0], dtype=np.float32)
+    gx, gy = np.meshgrid(sx, sy)
+    x = np.concatenate([x, gx.ravel()])
+    y = np.concatenate([y, gy.ravel()])
+    a = oracle.math(3, x, y)
+    b = oracle.math(10, x, y)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
