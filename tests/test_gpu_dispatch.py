@@ -285,6 +285,14 @@ def _table_scene(rpt, which):
                        rpt.Material(rgb=(0.6, 0.6, 0.6), roughness=0.9)]
         s.spheres = [((-0.8, 0.0, 0.0), 1.0, 0), ((0.9, 0.0, 0.3), 0.8, 1)]
         s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2)]
+    elif which == "extreme materials":
+        # values that push State::finalize and get_spec_color out of the short divide's range (1 / ior = 1e20, aspect = sqrt(1e-7),
+        # roughness 1e-30): a row is built with hipcc's own divide, a hit's material with the tracked one + the second computation
+        s.materials = [scenes.full_material(rgb=(0.9, 0.9, 1.0), roughness=1e-30, spec_trans=1.0, ior=1e-20),
+                       scenes.full_material(rgb=(1e-30, 0.7, 1e20), roughness=0.3, anisotropic=0.9999999 / 0.9, metallic=1.0, clearcoat=1.0, clearcoat_gloss=1.0),
+                       rpt.Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1))]
+        s.spheres = [((-0.9, 0.0, 0.2), 0.9, 0), ((0.9, -0.1, -0.3), 0.8, 1)]
+        s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2)]
     elif which == "two checkers":
         # two procedural materials: the table has one bit for "the checker's second colour": the kernel without a table renders this one
         s.materials = [rpt.Material(roughness=0.5, checker_dir=(2.0, 7.0, 0.9, 0.05)), rpt.Material(rgb=(0.2, 0.5, 0.8), metallic=1.0, roughness=0.2),
@@ -296,7 +304,7 @@ def _table_scene(rpt, which):
     return s, 0
 
 
-_TABLE_CASES = ["reference", "overlapping patches", "camera inside glass", "checker on a sphere", "two checkers", "sdf", "sdf no sphere", "sdf two spheres",
+_TABLE_CASES = ["reference", "overlapping patches", "camera inside glass", "checker on a sphere", "extreme materials", "two checkers", "sdf", "sdf no sphere", "sdf two spheres",
                 "sdf checker object", 2, 5, 9, 13, 17, 21, 26, 33]
 
 
