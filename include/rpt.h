@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define RPT_ABI_VERSION 3u
+#define RPT_ABI_VERSION 4u            /* 4: the A/B-only render flags and the test hooks left this header (include/rpt_test.h) */
 
 typedef enum rpt_status {
     RPT_OK              =  0,
@@ -242,9 +242,9 @@ enum {                                /* rpt_scene_desc.flags */
  * Draw order of an iteration inside a SCATTER medium: the distance draw; then, on a scatter event, light index, light r1,
  * r2 (if the scene has lights), r1, r2 of sample_hg, [roulette]; otherwise the surface bounce's draws as always.
  * Materials of small scenes are patches: RPT_MAT_MEDIUM writes all four medium fields.  rpt_upload_scene rejects a
- * negative or non-finite density.  Kernel forms: every default form renders media (megakernel, nested loops, the
- * compacting kernel, the SDF march kernel, large scenes' megakernel and wavefront forms); RPT_RENDER_FAST_MATH and the
- * A/B kernels do not (RPT_ERR_UNSUPPORTED). */
+ * negative or non-finite density.  Kernel forms: every scene class's kernel renders media (megakernel, the compacting
+ * kernel, the SDF march kernel, large scenes' megakernel); RPT_RENDER_FAST_MATH and RPT_RENDER_NESTED_LOOPS do not
+ * (RPT_ERR_UNSUPPORTED). */
 
 typedef struct rpt_scene_desc {
     uint32_t abi_version;             /* RPT_ABI_VERSION */
@@ -264,25 +264,20 @@ typedef struct rpt_scene_desc {
  * 1 spherical light, Pinhole defaults).  The arrays it points to are static.  */
 int rpt_scene_analytical(rpt_scene_desc* out);
 
-/* ---- render flags ---------------------------------------------------------- */
+/* ---- render flags ----------------------------------------------------------
+ * Bits 2-4, 6-7 and 9-10 named measured-slower kernel forms kept for A/B runs until ABI 3 (inline / three-room / pool / compacting SDF
+ * marches, the resumable grid walk, the wavefront form of large scenes and its counterpart flag).  Those forms are gone from the
+ * library (profiles/NOTES.md has their numbers, the history their code); the bits are reserved and rpt_render* answer them with
+ * RPT_ERR_INVALID_ARG. */
 enum {
     RPT_RENDER_DEFAULT      = 0u,
-    /* Use the nested-loop kernel (sample loop outside, bounce loop inside) instead of
-     * the path-regenerating one.  Same image bit for bit; kept for A/B measurement. */
+    /* Small scenes without an SDF object or media: the nested-loop kernel (sample loop outside, bounce loop inside) instead of
+     * the path-regenerating one.  Same image bit for bit; the differential baseline of the reference's own scene class. */
     RPT_RENDER_NESTED_LOOPS = 1u << 0,
     /* Relaxed arithmetic: the same kernels built with hipcc's fast f32 divide/sqrt (~2.5 ulp) and FMA contraction.
-     * Not bit-identical to the reference arithmetic (statistically equivalent); off by default, never benchmarked. */
+     * Not bit-identical to the reference arithmetic (statistically equivalent: SURVEY.md 8c tier T1); off by default; bench.py
+     * reports it beside the headline, never as the headline. */
     RPT_RENDER_FAST_MATH    = 1u << 1,
-    /* Scenes with an SDF object: run the sphere march inside closest_hit / any_hit (one bounce per scheduling
-     * step) instead of as a resumable scheduling state of the lane (the default).  Same image bit for bit; kept for A/B. */
-    RPT_RENDER_SDF_INLINE_MARCH = 1u << 2,
-    /* REMOVED (accepted for source compatibility, rpt_render* return RPT_ERR_UNSUPPORTED): the grid walk of large scenes as a
-     * resumable scheduling state.  Measured slower in round 1. */
-    RPT_RENDER_GRID_RESUMABLE_WALK = 1u << 3,
-    /* Scenes with an SDF object: lanes submit their marches to a workgroup-wide queue in LDS that all four waves serve
-     * (dev_sdf_pool.h) instead of marching their own ray.  Same image bit for bit; measured SLOWER (1.5 vs 2.2
-     * Gsamples/s: DESIGN.md 4b); only in builds with -DRPT_AB_KERNELS, otherwise RPT_ERR_UNSUPPORTED. */
-    RPT_RENDER_SDF_POOL_MARCH = 1u << 4,
     /* Russian roulette (project-defined; the reference's bounce loop is a fixed `for _ in 0..depth` with three
      * early exits, tracer.rs:61-103).  After the throughput update and the next-ray set-up of bounce b (0-based),
      * when b + 1 >= 2 and b + 1 < depth:  q = clamp(max(throughput.x, throughput.y, throughput.z), 0.05, 1)
@@ -290,30 +285,13 @@ enum {
      * the path, otherwise throughput = throughput / q.  Same expectation, different samples: OFF (the default) is
      * the reference.  Worth it for deep paths (max_depth > 4). */
     RPT_RENDER_RUSSIAN_ROULETTE = 1u << 5,
-    /* Large scenes with a grid (64 spheres or more) have two forms, same image bit for bit:
-     *   megakernel — the grid walks inside the path-regenerating kernel, like everything else;
-     *   wavefront  — the grid walks in a kernel of their own over ray lists in HBM, the rest of a bounce in a shading
-     *                kernel; needs 168 B of device memory per pixel of the tile while it runs (kept by the context) and
-     *                1 + 2 * (spp * max_depth + 1) launches.
-     * Default: the megakernel (since round 3 it is the faster form at every tile size and sample count; the wavefront form runs its
-     * grid walks with three times the lane fill and remains for A/B measurement).
-     * These two flags force one form (both set: RPT_ERR_INVALID_ARG); scenes without a grid ignore them. */
-    RPT_RENDER_LARGE_WAVEFRONT = 1u << 6,
-    RPT_RENDER_LARGE_MEGAKERNEL = 1u << 7,
     /* Small scenes without an SDF object: use the kernel that keeps the workgroup's 256 paths in LDS and re-deals them to its
      * threads before every stage.  It is what a launch of ONE sample per pixel takes by default — the reference's
      * own usage, one render() per redraw, where the megakernel has nothing to regenerate over and its waves drain (+4 % at 1080p,
      * more on small frames) — and slower than the megakernel from two samples per launch up; the flag forces it at any sample
-     * count (A/B, tests).  Same image bit for bit. */
+     * count (tests).  Same image bit for bit. */
     RPT_RENDER_SMALL_COMPACT = 1u << 8,
-    /* Scenes with an SDF object: the same idea with the sphere march as one of the stages (paths in LDS, marching paths
-     * re-dealt every few iterations).  Same image bit for bit; measured SLOWER than the default march kernel (1.7 vs 2.4
-     * Gsamples/s: DESIGN.md 4b); only in builds with -DRPT_AB_KERNELS, otherwise RPT_ERR_UNSUPPORTED. */
-    RPT_RENDER_SDF_COMPACT = 1u << 9,
-    /* Scenes with an SDF object: round 2's march kernel (three waiting rooms per wave: RESOLVE, the shadow march, SHADE) instead of
-     * the default two-room one, which marches the shadow ray of a bounce right before the next path ray and does the rest of the
-     * bounce in one block.  Same image bit for bit; kept for A/B (2.35 vs 2.41 Gsamples/s on configs[3]). */
-    RPT_RENDER_SDF_THREE_ROOM_MARCH = 1u << 10
+    RPT_RENDER_ALL_FLAGS = RPT_RENDER_NESTED_LOOPS | RPT_RENDER_FAST_MATH | RPT_RENDER_RUSSIAN_ROULETTE | RPT_RENDER_SMALL_COMPACT
 };
 
 /* ---- context --------------------------------------------------------------- */
@@ -328,12 +306,10 @@ uint32_t rpt_abi_version(void);
 /* sizeof(rpt_scene_desc) as this library was built: a binding in another language asserts it against its own
  * mirror of the struct before the first rpt_upload_scene (rust/gpu_tracer.rs does). */
 uint32_t rpt_sizeof_scene_desc(void);
-/* 1 when the library was built with -DRPT_AB_KERNELS (python rust-pathtracer_amd/build.py --ab): it then holds every kernel form that was
- * ever measured — the wavefront form of large scenes, the three-room and inline-march SDF kernels, the nested-loop kernels of every
- * scene class, the forms under csrc/ab/ — for A/B timing and for the parity tests that run each form against the oracle.  The shipped
- * library (0) holds the default form of every scene class, the compacting kernel of one-sample launches and one nested-loop baseline
- * (small scenes without media); it answers the other forms' flags with RPT_ERR_UNSUPPORTED. */
-uint32_t rpt_build_has_ab_kernels(void);
+/* 0 for the shipped library (librpt_hip.so: exactly this header).  1 for the test build (librpt_hip_test.so): the same objects
+ * linked with the hooks of include/rpt_test.h — per-function probes, grid-query probes, dispatch read-outs — which the parity
+ * tests use to localise a mismatch. */
+uint32_t rpt_build_has_test_hooks(void);
 
 /* ---- the GPUs of one node (what replaces rayon's fan-out, tracer.rs:29-32) -----------------------------
  * The reference's only parallel construct is INSIDE render(): one rayon task per scanline.  Here the image is
@@ -503,56 +479,6 @@ int rpt_denoise(rpt_ctx* ctx, const float* pixels, float* out, uint32_t width, u
 int rpt_convert_to_u8(rpt_ctx* ctx, const float* pixels, uint8_t* frame, uint32_t width, uint32_t height);
 
 int rpt_synchronize(rpt_ctx* ctx, void* stream);
-
-/* ---- test probes ------------------------------------------------------------
- * Evaluate one device function over arrays (device pointers), so tests can compare
- * leaf functions with the oracle bit for bit.  Not part of the drop-in surface.  */
-enum {
-    RPT_PROBE_SIN = 0, RPT_PROBE_COS = 1, RPT_PROBE_LOG2 = 2, RPT_PROBE_POW = 3,
-    RPT_PROBE_DIV = 4, RPT_PROBE_SQRT = 5, RPT_PROBE_RNG = 6, RPT_PROBE_EXP = 7, RPT_PROBE_LOG = 8,
-    RPT_PROBE_DIV3 = 9                /* three quotients by one denominator, the library's shared-reciprocal form: see kernels.hip */
-};
-int rpt_probe_math(rpt_ctx* ctx, uint32_t fn, const float* a_dev, const float* b_dev,
-                   float* out_dev, uint64_t n, void* stream);
-
-/* One integrator function per record, for tests that localise a frame mismatch: records are RPT_PROBE_IN_STRIDE floats
- * in, RPT_PROBE_OUT_STRIDE floats out (u32 values as their bit patterns), device pointers.  Layouts (in -> out):
- *   GEN_RAY        {px, py, offx, offy}; camera = the uploaded scene's, params = {width, height} (host)
- *                  -> {origin[3], direction[3]}                                      camera/pinhole.rs:38-60
- *   HIT_SPHERE     {o[3], d[3], centre[3], radius} -> {hit, t}                       analytical.rs:166-190
- *   HIT_PLANE      {o[3], d[3], normal[3], point[3], min_denom, max_t} -> {hit, t}   analytical.rs:193-204
- *   SAMPLE_LIGHT   {type, position[3], emission[3], radius, area, u[3], v[3], scatter_pos[3], n_lights, scene flags,
- *                   rng state, rng increment, -} -> {normal[3], emission[3], direction[3], dist, pdf, draws}   tracer.rs:173-220
- *   DISNEY_EVAL    {material: rgb[3], emission[3], anisotropic, metallic, roughness, subsurface, specular_tint, sheen,
- *                   sheen_tint, clearcoat, clearcoat_gloss, spec_trans, ior (before finalize), eta, v[3], n[3], l[3]}
- *                  -> {f[3], pdf}                                                    tracer.rs:555-626
- *   DISNEY_SAMPLE  {material (17), eta, v[3], n[3], l_stale[3], rng state, rng increment, -}
- *                  -> {f[3], l[3], pdf, draws}                                       tracer.rs:441-553            */
-enum {
-    RPT_PROBE_FN_GEN_RAY = 0, RPT_PROBE_FN_HIT_SPHERE = 1, RPT_PROBE_FN_HIT_PLANE = 2, RPT_PROBE_FN_SAMPLE_LIGHT = 3,
-    RPT_PROBE_FN_DISNEY_EVAL = 4, RPT_PROBE_FN_DISNEY_SAMPLE = 5, RPT_PROBE_FN_COUNT = 6
-};
-#define RPT_PROBE_IN_STRIDE 32
-#define RPT_PROBE_OUT_STRIDE 16
-int rpt_probe_fn(rpt_ctx* ctx, uint32_t fn, const float* in_dev, float* out_dev, uint64_t n, const float* params, void* stream);
-
-/* Ray queries against the uploaded LARGE scene's spheres, for testing the acceleration structure:
- * rays_dev = n x {origin[3], direction[3], max_dist}; out_dev = n x {t (f32 bits), nearest sphere index
- * or 0xFFFFFFFF, any_hit (0/1) with max_dist honoured}.  use_grid = 0 forces the brute-force loops. */
-int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint64_t n, uint32_t use_grid, void* stream);
-
-/* Multi-device contexts, after rpt_render / rpt_resident_render: the time in ms from the moment device index `b` (position in
- * rpt_create_multi's list) BEGAN its part of the last render to the moment device index `a` ENDED its part (HIP events on their
- * streams).  Positive for a != b means the two overlapped: what the fan-out inside render() promises (tracer.rs:29-32).  Events
- * of two different physical devices cannot be compared (RPT_ERR_UNSUPPORTED): the probe is for virtual ranks, i.e. repeated
- * device ids.  Waits for both events. */
-int rpt_debug_render_overlap_ms(rpt_ctx* ctx, int a, int b, float* ms);
-
-/* What the last launch on the context's first device left for the next one's dispatch (rpt_set_dispatch): per tile of that launch
- * (16x16 pixels, row-major over the device's rows) out[tile * 4 + wave] = the time, in 10 ns, wave `wave` of the tile's last unit
- * held its slot, then from out[4 * n] the dispatch order (position -> tile: a permutation of 0 .. n - 1) and 5 * n more words of
- * development data (tools/dispatch_timeline.py).  `out` holds 10 * capacity_tiles dwords; *n_tiles = n.  Waits for the device. */
-int rpt_debug_sched_read(rpt_ctx* ctx, uint32_t* out, uint32_t capacity_tiles, uint32_t* n_tiles);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 // oracle_capi.cpp — C entry points of the CPU oracle (ctypes-friendly).
 // TEST INFRASTRUCTURE: see the header of rpt_oracle.hpp.  PARITY UNPINNED (ibid.).
 #include "rpt_oracle.hpp"
+#include "../include/rpt_test.h"          // the probe record layouts the oracle answers for (tests/test_gpu_probes.py)
 
 #include <cstdio>
 #ifdef _OPENMP

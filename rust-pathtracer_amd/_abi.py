@@ -1,7 +1,7 @@
 """ctypes mirror of include/rpt.h (the C ABI).  Plain data only."""
 import ctypes as C
 
-RPT_ABI_VERSION = 3
+RPT_ABI_VERSION = 4
 
 RPT_OK = 0
 RPT_ERR_INVALID_ARG = -1
@@ -46,15 +46,9 @@ RPT_SCENE_MEDIA = 1 << 2
 RPT_RENDER_DEFAULT = 0
 RPT_RENDER_NESTED_LOOPS = 1 << 0
 RPT_RENDER_FAST_MATH = 1 << 1
-RPT_RENDER_SDF_INLINE_MARCH = 1 << 2
-RPT_RENDER_GRID_RESUMABLE_WALK = 1 << 3
-RPT_RENDER_SDF_POOL_MARCH = 1 << 4
 RPT_RENDER_RUSSIAN_ROULETTE = 1 << 5
-RPT_RENDER_LARGE_WAVEFRONT = 1 << 6
-RPT_RENDER_LARGE_MEGAKERNEL = 1 << 7
 RPT_RENDER_SMALL_COMPACT = 1 << 8
-RPT_RENDER_SDF_COMPACT = 1 << 9
-RPT_RENDER_SDF_THREE_ROOM_MARCH = 1 << 10
+RPT_RENDER_ALL_FLAGS = RPT_RENDER_NESTED_LOOPS | RPT_RENDER_FAST_MATH | RPT_RENDER_RUSSIAN_ROULETTE | RPT_RENDER_SMALL_COMPACT   # (the other bits: reserved)
 
 (RPT_PROBE_SIN, RPT_PROBE_COS, RPT_PROBE_LOG2, RPT_PROBE_POW, RPT_PROBE_DIV, RPT_PROBE_SQRT, RPT_PROBE_RNG, RPT_PROBE_EXP,
  RPT_PROBE_LOG, RPT_PROBE_DIV3) = range(10)
@@ -140,7 +134,7 @@ class rpt_unique_id(C.Structure):
 # every symbol include/rpt.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rpt_sizeof_scene_desc": (C.c_uint32, []),
-    "rpt_build_has_ab_kernels": (C.c_uint32, []),
+    "rpt_build_has_test_hooks": (C.c_uint32, []),
     "rpt_create_multi": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
     "rpt_comm_unique_id": (C.c_int, [C.POINTER(rpt_unique_id)]),
     "rpt_create_rank": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(rpt_unique_id)]),
@@ -153,7 +147,6 @@ SYMBOLS = {
     "rpt_resident_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "rpt_tile_rows_padded": (C.c_uint32, [C.c_uint32, C.c_uint32, C.c_uint32]),
     "rpt_tile_copy_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(rpt_tile_plan)]),
-    "rpt_probe_fn": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rpt_scene_analytical": (C.c_int, [C.POINTER(rpt_scene_desc)]),
     "rpt_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     "rpt_destroy": (None, [C.c_void_p]),
@@ -181,6 +174,12 @@ SYMBOLS = {
     "rpt_denoise_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p]),
     "rpt_denoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float]),
     "rpt_synchronize": (C.c_int, [C.c_void_p, C.c_void_p]),
+}
+
+# include/rpt_test.h: the test hooks, exported by librpt_hip_test.so only
+TEST_SYMBOLS = {
+    "rpt_debug_reload_knobs": (C.c_int, []),
+    "rpt_probe_fn": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]),
     "rpt_probe_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "rpt_debug_render_overlap_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rpt_debug_sched_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),

@@ -6,7 +6,10 @@ import os
 from . import _abi
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RPT_LIB", os.path.join(HERE, "librpt_hip.so"))   # RPT_LIB: experiment builds
+# librpt_hip.so is the product (exactly include/rpt.h).  RPT_LIB selects another build of it: librpt_hip_test.so (the same objects
+# linked with the hooks of include/rpt_test.h — what tests/conftest.py loads), or an experiment build (tools/build_variants.py).
+LIB_PATH = os.environ.get("RPT_LIB", os.path.join(HERE, "librpt_hip.so"))
+TEST_LIB_PATH = os.path.join(HERE, "librpt_hip_test.so")
 
 _lib = None
 
@@ -37,6 +40,11 @@ def lib():
             fn = getattr(l, name)      # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
+        if l.rpt_build_has_test_hooks():
+            for name, (res, args) in _abi.TEST_SYMBOLS.items():
+                fn = getattr(l, name)
+                fn.restype = res
+                fn.argtypes = args
         _lib = l
     return _lib
 

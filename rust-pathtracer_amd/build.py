@@ -1,7 +1,7 @@
-"""Build the HIP extension (librpt_hip.so) for gfx950, in-tree.
+"""Build the HIP extension for gfx950, in-tree: librpt_hip.so (the product: exactly include/rpt.h) and librpt_hip_test.so (the SAME
+objects linked with the test hooks of include/rpt_test.h and the probe kernels: what the GPU parity tests load).
 
-    python rust-pathtracer_amd/build.py            # the shipped library
-    python rust-pathtracer_amd/build.py --ab       # librpt_hip_ab.so: + every kernel form kept for A/B runs (-DRPT_AB_KERNELS); RPT_LIB selects it
+    python rust-pathtracer_amd/build.py
 """
 import glob
 import os
@@ -13,16 +13,31 @@ import tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librpt_hip.so")
-# (object, source): kernels.hip is built three times (its first lines say why); everything but kernels_relaxed is strict
-OBJECTS = [("kernels", "kernels.hip"), ("kernels_perop", "kernels.hip"), ("kernels_relaxed", "kernels.hip"), ("denoise", "denoise.hip"),
-           ("capi", "capi.hip")]
-AB_SKIP = {"kernels_perop"}                               # (an A/B build holds every kernel in its one strict object)
-EXTRA_FLAGS = {"kernels_relaxed": ["-DRPT_RELAXED_BUILD", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"],
-               # large and SDF scenes' kernels: the range tests of the short divide / sqrt next to every operation (kernels.hip, top)
-               "kernels_perop": ["-DRPT_PEROP_BUILD"],
-               # the denoiser's taps are independent multiply / add sequences: packed f32 instructions halve their issue slots there
-               # (the path kernels lose from SLP: it pins register pairs)
-               "denoise": ["-fslp-vectorize"]}
+TEST_LIB = os.path.join(HERE, "librpt_hip_test.so")
+
+# One translation unit per kernel class (csrc/kernel_common.h says what each build of them is):
+#   strict    k_small tracks the range tests of the short divide / sqrt; k_compact, k_sdf, k_large test next to every operation
+#   relaxed   the four render TUs once more with hipcc's fast divide / sqrt and FMA contraction: what RPT_RENDER_FAST_MATH selects
+PEROP = ["-DRPT_GUARD_PER_OP"]
+RELAXED = ["-DRPT_RELAXED_BUILD", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-ffp-contract=fast"]
+# (object, source, extra flags, which library: "both" | "product" | "test")
+OBJECTS = [
+    ("k_small", "k_small.hip", [], "both"),
+    ("k_compact", "k_compact.hip", PEROP, "both"),
+    ("k_sdf", "k_sdf.hip", PEROP, "both"),
+    ("k_large", "k_large.hip", PEROP, "both"),
+    ("k_small_fast", "k_small.hip", RELAXED, "both"),
+    ("k_compact_fast", "k_compact.hip", RELAXED, "both"),
+    ("k_sdf_fast", "k_sdf.hip", RELAXED, "both"),
+    ("k_large_fast", "k_large.hip", RELAXED, "both"),
+    ("k_util", "k_util.hip", [], "both"),
+    # the denoiser's taps are independent multiply / add sequences: packed f32 instructions halve their issue slots there
+    # (the path kernels lose from SLP: it pins register pairs)
+    ("denoise", "denoise.hip", ["-fslp-vectorize"], "both"),
+    ("capi", "capi.hip", [], "product"),
+    ("capi_test", "capi.hip", ["-DRPT_TEST_HOOKS"], "test"),
+    ("k_probes", "k_probes.hip", [], "test"),
+]
 # -ffp-contract=off: results are compared bit for bit with a CPU restatement, the only
 # fused operations are the explicit fma calls of rpt_strict_math.h.
 # -mllvm -disable-machine-licm: MachineLICM hoists the materialisation of ~70 literal constants (the
@@ -33,7 +48,8 @@ EXTRA_FLAGS = {"kernels_relaxed": ["-DRPT_RELAXED_BUILD", "-fno-hip-fp32-correct
 # -mllvm -amdgpu-sched-strategy=max-ilp: the machine scheduler interleaves independent chains (the three divides of a
 #   normalize, the three pow of the background) instead of minimising register pressure first: +2 % on configs[1]
 #   and [3] at the same 96 VGPRs (iterative-ilp / iterative-minreg: no gain).
-BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC"]
+# -fvisibility=hidden: the library exports what include/rpt.h declares (capi.hip pushes default visibility around it) and nothing else.
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-fvisibility=hidden"]
 # The two -mllvm options are tuning only (they change instruction order / register use, never a result); a toolchain that
 # does not know them still builds the library without them (probed once, on an empty translation unit).
 TUNING_FLAGS = ["-mllvm", "-disable-machine-licm", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
@@ -63,10 +79,10 @@ def _tuning_flags():
 
 
 def _deps():
-    """Every file a change of which means a rebuild: all sources and headers under csrc/ (csrc/ab/ too) and include/."""
+    """Every file a change of which means a rebuild: all sources and headers under csrc/ and include/."""
     inc = os.path.join(HERE, "..", "include")
-    return (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "ab", "*.h")) +
-            glob.glob(os.path.join(inc, "*.h")) + [os.path.abspath(__file__)])
+    return (glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(inc, "*.h")) +
+            [os.path.abspath(__file__)])
 
 
 def needs_build(lib=LIB):
@@ -76,39 +92,49 @@ def needs_build(lib=LIB):
     return any(os.path.getmtime(d) > t for d in _deps())
 
 
-def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="build", ab=False):
-    """Compile csrc/*.hip -> librpt_hip.so.  hipcc cross-compiles gfx950 without a GPU.
-    `extra_flags` / `lib` / `objdir_name`: experiment builds next to the product library (tools/); `ab`: include the A/B kernels."""
-    if not force and not needs_build(lib):
+def build(force=False, verbose=False, extra_flags=(), lib=LIB, objdir_name="build", test_lib=None, only=None, jobs=None):
+    """Compile csrc/*.hip -> `lib` (and, when `test_lib` is given, the test build beside it).  hipcc cross-compiles gfx950 without a GPU.
+    `extra_flags` / `lib` / `objdir_name`: experiment builds next to the product library (tools/); `only`: recompile just these
+    objects (the others are taken from `objdir_name`/ as they are — or, if missing there, from the product's build/)."""
+    if not force and not needs_build(lib) and (test_lib is None or not needs_build(test_lib)):
         return lib
     objdir = os.path.join(HERE, objdir_name)
     os.makedirs(objdir, exist_ok=True)
-    flags = BASE_FLAGS + _tuning_flags() + (["-DRPT_AB_KERNELS"] if ab else [])
-    procs, objs = [], []
-    for name, src in OBJECTS:                             # one object each, with its own flags, in parallel
-        if (ab or "-DRPT_GUARD_PER_OP" in extra_flags) and name in AB_SKIP:
+    flags = BASE_FLAGS + _tuning_flags()
+    jobs = jobs or max(1, min(8, os.cpu_count() or 1))
+    pending, objs = [], {}
+    for name, src, extra, where in OBJECTS:
+        if where == "test" and test_lib is None:
             continue
         obj = os.path.join(objdir, name + ".o")
-        cmd = [_hipcc()] + flags + EXTRA_FLAGS.get(name, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
-        objs.append(obj)
-    failed = [" ".join(cmd) for cmd, p in procs if p.wait() != 0]
+        objs[name] = (obj, where)
+        if only is not None and name not in only:
+            if not os.path.exists(obj):
+                shutil.copy(os.path.join(HERE, "build", name + ".o"), obj)
+            continue
+        pending.append([_hipcc()] + flags + extra + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj])
+    running, failed = [], []
+    while pending or running:
+        while pending and len(running) < jobs:
+            cmd = pending.pop(0)
+            if verbose:
+                print(" ".join(cmd))
+            running.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+        cmd, p = running.pop(0)
+        if p.wait() != 0:
+            failed.append(" ".join(cmd))
     if failed:
         raise RuntimeError("build.py: compilation failed:\n" + "\n".join(failed))
-    os.makedirs(os.path.dirname(os.path.abspath(lib)), exist_ok=True)
-    link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + objs + ["-ldl", "-o", lib]
-    if verbose:
-        print(" ".join(link))
-    subprocess.run(link, check=True, cwd=CSRC)
+    for out, kinds in ((lib, ("both", "product")), (test_lib, ("both", "test"))):
+        if out is None:
+            continue
+        os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+        link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [o for o, w in objs.values() if w in kinds] + ["-ldl", "-o", out]
+        if verbose:
+            print(" ".join(link))
+        subprocess.run(link, check=True, cwd=CSRC)
     return lib
 
 
-AB_LIB = os.path.join(HERE, "librpt_hip_ab.so")           # every kernel form ever measured (-DRPT_AB_KERNELS), next to the shipped library
-
 if __name__ == "__main__":
-    if "--ab" in sys.argv[1:]:                            # RPT_LIB=rust-pathtracer_amd/librpt_hip_ab.so python -m pytest tests -m gpu
-        print(build(force=True, verbose=True, ab=True, lib=AB_LIB, objdir_name="build_ab"))
-    else:
-        print(build(force=True, verbose=True))
+    print(build(force=True, verbose=True, test_lib=TEST_LIB))

@@ -1,6 +1,6 @@
 // capi.hip — the C ABI of include/rpt.h: contexts (one device, the devices of a node in one process, or one rank of a
-// multi-process job), scene upload, launches, the RCCL gather.  Host code only; the kernels and their launch wrappers
-// are in kernels.hip (launch.h).
+// multi-process job), scene upload, launches, the RCCL gather.  Host code only; the kernels and their launch functions
+// are in the k_*.hip translation units (launch.h); every environment variable the library reads is in knobs.h.
 //
 // There is NO CPU fallback: without a gfx950 device every entry point that computes returns
 // RPT_ERR_NO_DEVICE / RPT_ERR_HIP.
@@ -20,12 +20,17 @@
 
 #include "../../include/rpt.h"
 #include "host_scene.h"
+#include "knobs.h"
 #include "launch.h"
+#ifdef RPT_TEST_HOOKS
+#include "../../include/rpt_test.h"
+#endif
 
 using namespace rptdev;
 using rpthost::HostAccel;
 using rpthost::build_accel;
 using rpthost::make_camera;
+using rpthost::knobs;
 
 // What one device of a context owns.
 struct DevState {
@@ -44,21 +49,24 @@ struct DevState {
     hipEvent_t snap_ready = nullptr;  // on `stream`: the snapshot is taken
     hipEvent_t snap_free = nullptr;   // on `comm_stream`: the snapshot has been sent (the next one may overwrite it)
     bool snap_used = false;
-    SceneSmallSdf* scene_small_dev = nullptr;   // the small scene in device memory, for the one kernel that reads it from there (SDF compact, A/B)
-    void* wf = nullptr;               // wavefront state of large scenes (dev_wavefront.h), grown on demand
-    size_t wf_bytes = 0;
     float* dn = nullptr;              // the denoiser's intermediate buffer, grown on demand
     size_t dn_bytes = 0;
-    // `wf` and `dn` are scratch of the CONTEXT, while rpt_render_device / rpt_denoise_device run on whatever stream the caller
-    // passes: a use on another stream than the previous one waits for that one's event (same stream: ordered anyway)
-    hipEvent_t wf_done = nullptr, dn_done = nullptr, sc_done = nullptr;
-    hipStream_t wf_stream = nullptr, dn_stream = nullptr, sc_stream = nullptr;
-    bool wf_used = false, dn_used = false, sc_used = false;
-    // dispatch (kernels.hip, "Dispatch: units, their order, their hand-off"), for launches of `sched_tiles` tiles: per tile 4 dwords of
+    // `dn` is scratch of the CONTEXT, while rpt_denoise_device runs on whatever stream the caller passes: a use on another stream
+    // than the previous one waits for that one's event (same stream: ordered anyway)
+    hipEvent_t dn_done = nullptr;
+    hipStream_t dn_stream = nullptr;
+    bool dn_used = false;
+    // dispatch (kernel_common.h, "Dispatch: units, their order, their hand-off"), for launches of `sched_tiles` tiles: per tile 4 dwords of
     // cost, 1 of order, 1 of sorting scratch, 4 of start stamps (development), then the hand-off words (SchedLayout)
-    uint32_t* sched = nullptr;
+    uint32_t* sched = nullptr;        // the tables of the CURRENT launch shape (an entry of sched_cache)
     uint32_t sched_tiles = 0;
     uint64_t sched_launches = 0;      // launches since the order was last started from scratch (the costs are re-sorted after the 1st, 2nd, 4th, ...)
+    // A context that alternates between launch shapes (a viewer's preview and full frames, bench.py's legs, one rank's tile and the
+    // whole frame) keeps each shape's learned order: up to kSchedCache tables, keyed by what decides a tile's cost (sched_for).
+    struct SchedEntry { uint64_t key[2]; uint32_t* buf; uint32_t tiles; uint64_t launches; uint64_t stamp; };
+    std::vector<SchedEntry> sched_cache;
+    uint64_t sched_key[2] = {0, 0};
+    uint64_t sched_clock = 0;
     hipEvent_t sched_done = nullptr;
     hipStream_t sched_stream = nullptr;
     bool sched_used = false;
@@ -119,6 +127,8 @@ static void set_err(rpt_ctx* ctx, const char* fmt, ...)
         }                                                                                         \
     } while (0)
 
+#define RPT_CHECK_RC(call) do { const int rc_ = (call); if (rc_ != RPT_OK) return rc_; } while (0)
+
 // Every entry point runs on its context's device(s) and puts the caller's current device back afterwards
 // (the caller may be a torch process with its own idea of the current device).
 struct DeviceGuard {
@@ -156,7 +166,7 @@ struct RcclApi {
 // Loads librccl once per process (thread-safe: a function-local static's initialiser); false when it cannot be loaded.
 static bool rccl_load(RcclApi& api)
 {
-    const char* forced = getenv("RPT_RCCL_LIB");                     // tests: a name that cannot be loaded exercises the error path
+    const char* forced = knobs().rccl_lib.empty() ? nullptr : knobs().rccl_lib.c_str();   // tests: a name that cannot be loaded exercises the error path
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     if (forced) api.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
     else
@@ -201,40 +211,6 @@ static const char* rccl_why() { return g_rccl.error.empty() ? "unknown reason" :
         }                                                                                         \
     } while (0)
 
-// Lanes that must be parked on a surface hit before a wave runs its shading block (1..64).
-// RPT_SHADE_THRESHOLD overrides the default for tuning runs.
-static uint32_t env_lanes(const char* name, long dflt)
-{
-    const char* e = getenv(name);
-    long t = e ? strtol(e, nullptr, 10) : dflt;
-    return (uint32_t)(t < 1 ? 1 : (t > 64 ? 64 : t));
-}
-// Scheduling knobs (they change when work runs, never its result): lanes that must be waiting before a wave
-// runs a block.
-static uint32_t shade_threshold() { static const uint32_t v = env_lanes("RPT_SHADE_THRESHOLD", 56); return v; }
-static uint32_t finish_threshold() { static const uint32_t v = env_lanes("RPT_FINISH_THRESHOLD", 24); return v; }
-static uint32_t sdf_march_min_lanes(bool two_rooms)
-{
-    static const uint32_t two = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8), three = env_lanes("RPT_SDF_MARCH_MIN_LANES", 8);
-    return two_rooms ? two : three;
-}
-static uint32_t sdf_pool_shade_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_SHADE_LANES", 48); return v; }
-static uint32_t sdf_pool_resolve_lanes() { static const uint32_t v = env_lanes("RPT_SDF_POOL_RESOLVE_LANES", 16); return v; }
-static uint32_t sdf_pool_min_batch() { static const uint32_t v = env_lanes("RPT_SDF_POOL_MIN_BATCH", 32); return v; }
-static uint32_t sdf_pool_patience() { static const uint32_t v = getenv("RPT_SDF_POOL_PATIENCE") ? (uint32_t)atoi(getenv("RPT_SDF_POOL_PATIENCE")) : 8u; return v; }
-// Which form a large scene with a grid takes (include/rpt.h): the megakernel unless the caller asks for the wavefront form.
-// (Rounds 2 and early 3 chose the wavefront form for launches of up to 8 samples on tiles from 1.5 M pixels; since the two tiers of
-// cell lists and the 5-wave megakernel the megakernel is ahead at every size and sample count: 2048^2 x 1 / 2 / 4 / 8 / 16 spp 2.51 /
-// 5.16 / 10.2 / 19.4 / 36.8 ms against 2.75 / 5.49 / 10.9 / 21.3 / 41.6, 4096^2 x 8: 71.9 against 78.7.)  RPT_LARGE_FORM=wavefront|megakernel
-// overrides flags and default (A/B runs of unmodified callers).
-constexpr uint64_t kWavefrontMaxBlindIterations = 256;              // iterations render_wavefront enqueues without looking at the device
-static bool wavefront_wanted(uint32_t flags)
-{
-    static const char* form = getenv("RPT_LARGE_FORM");
-    if (form && form[0] == 'w') return true;
-    if (form && form[0] == 'm') return false;
-    return (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
-}
 // Where things are in DevState::sched (dwords), for n tiles.
 struct SchedLayout {
     size_t n;
@@ -251,17 +227,7 @@ constexpr size_t kSyncTimeoutWord = 0, kSyncZeroFrom = 16, kSyncDoneFrom = 32;  
 struct DispatchPolicy {
     uint32_t cost_order, unit_rounds, unit_min_spp, unit_slots;
 };
-static DispatchPolicy default_dispatch()
-{
-    // RPT_DISPATCH_ORDER: 0 bottom rows first, always; 1 most expensive tile first; 2 (development) the costs are recorded, the
-    // order stays bottom rows first (tools/dispatch_timeline.py)
-    static const DispatchPolicy p = {
-        getenv("RPT_DISPATCH_ORDER") ? (uint32_t)atoi(getenv("RPT_DISPATCH_ORDER")) : 1u,
-        getenv("RPT_UNIT_ROUNDS") ? (uint32_t)atoi(getenv("RPT_UNIT_ROUNDS")) : 12u,
-        getenv("RPT_UNIT_MIN_SPP") ? (uint32_t)atoi(getenv("RPT_UNIT_MIN_SPP")) : 64u,
-        0u};
-    return p;
-}
+static DispatchPolicy default_dispatch() { return DispatchPolicy{knobs().dispatch_order, knobs().unit_rounds, knobs().unit_min_spp, 0u}; }
 
 static DispatchPolicy policy_of(const rpt_ctx* ctx)
 {
@@ -290,22 +256,8 @@ static uint32_t unit_chunks(const DispatchPolicy& pol, uint64_t nblocks, uint32_
 // Launches of at least this many samples per pixel re-sort the order from their own costs every time (one small kernel behind
 // the launch); shorter ones only after the 1st, 2nd, 4th, 8th ... launch since the order was started.
 constexpr uint32_t kOrderAlwaysFromSpp = 16;
-// Small scenes: launches of at most this many samples per pixel take the compacting kernel (kernels.hip, render_small_compact_kernel).
+// Small scenes: launches of at most knobs().compact_max_spp samples per pixel take the compacting kernel (k_compact.hip).
 // (1 since round 3: 1080p, 1 spp 7.12 vs 6.83 Gsamples/s for the megakernel, 2 spp 7.01 vs 7.39: profiles/r3/spp_curve.txt)
-static uint32_t compact_max_spp() { static const uint32_t v = getenv("RPT_COMPACT_MAX_SPP") ? (uint32_t)atoi(getenv("RPT_COMPACT_MAX_SPP")) : 1u; return v; }
-// SDF scenes: RPT_SDF_FORM=compact|march overrides the flag (A/B runs of unmodified callers)
-static bool sdf_compact_wanted(uint32_t flags)
-{
-#ifndef RPT_AB_KERNELS
-    (void)flags;
-    return false;                                                   // (the flag itself is refused in launch_render)
-#endif
-    static const char* form = getenv("RPT_SDF_FORM");
-    if (form && form[0] == 'c') return true;
-    if (form && form[0] == 'm') return false;
-    return (flags & RPT_RENDER_SDF_COMPACT) != 0;
-}
-static uint32_t sdf_compact_steps() { static const uint32_t v = getenv("RPT_SDF_COMPACT_STEPS") ? (uint32_t)atoi(getenv("RPT_SDF_COMPACT_STEPS")) : 8u; return v; }
 // ---- descriptor -> device tables ---------------------------------------------------------------------------
 static DevPlane dev_plane(const rpt_plane& a) { return DevPlane{a.normal[0], a.normal[1], a.normal[2], a.point[0], a.point[1], a.point[2], a.min_denom, a.material, a.max_t}; }
 static DevLight dev_light(const rpt_light& a)
@@ -337,10 +289,8 @@ static void free_dev(DevState& d)
     if (d.fb) (void)hipFree(d.fb);
     if (d.tile) (void)hipFree(d.tile);
     if (d.tables) (void)hipFree(d.tables);
-    if (d.wf) (void)hipFree(d.wf);
     if (d.dn) (void)hipFree(d.dn);
-    if (d.scene_small_dev) (void)hipFree(d.scene_small_dev);
-    if (d.sched) (void)hipFree(d.sched);
+    for (DevState::SchedEntry& e : d.sched_cache) if (e.buf) (void)hipFree(e.buf);
     if (d.sched_done) (void)hipEventDestroy(d.sched_done);
     if (d.ev_begin) (void)hipEventDestroy(d.ev_begin);
     if (d.ev_end) (void)hipEventDestroy(d.ev_end);
@@ -349,8 +299,6 @@ static void free_dev(DevState& d)
     if (d.snap_ready) (void)hipEventDestroy(d.snap_ready);
     if (d.snap_free) (void)hipEventDestroy(d.snap_free);
     if (d.comm_stream) (void)hipStreamDestroy(d.comm_stream);
-    if (d.wf_done) (void)hipEventDestroy(d.wf_done);
-    if (d.sc_done) (void)hipEventDestroy(d.sc_done);
     if (d.dn_done) (void)hipEventDestroy(d.dn_done);
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d = DevState();
@@ -381,8 +329,6 @@ static int open_dev(DevState& d, int device_id, int rank, const char* who)
         hipStreamCreateWithFlags(&d.comm_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&d.snap_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.snap_free, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d.wf_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d.sc_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.dn_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&d.sched_done, hipEventDisableTiming) != hipSuccess) {
         set_err(nullptr, "%s: cannot create a stream on device %d", who, device_id);
@@ -443,47 +389,59 @@ static hipError_t copy_rank_rows(bool to_device, float* host_image, float* tile,
     return hipSuccess;
 }
 
-// One render launch sequence on one device.
-// The wavefront's per-slot state and lists: one allocation, carved up here.
-static int wavefront_buffers(rpt_ctx* ctx, DevState& d, size_t n_slots, WfBuffers& wb)
+// The dispatch tables for a launch of `nblocks` tiles of this shape: the context's current ones if the shape is the same, else the
+// cached ones of that shape (their learned order intact), else new ones (bottom rows first, no costs).  Nothing is freed — and so
+// nothing waits for the device — unless kSchedCache shapes are already held; then the least recently used goes.
+constexpr size_t kSchedCache = 6;
+static int sched_for(rpt_ctx* ctx, DevState& d, uint32_t nblocks, uint32_t width, uint32_t rows_local, uint32_t tile_rows, uint32_t rank, uint32_t world, hipStream_t stream)
 {
-    const size_t n_seg = (n_slots + 63) / 64, padded = n_seg * 64;
-    const size_t head = (kWalkGroups * kWalkCounterStride + 64) * sizeof(uint32_t);
-    const size_t bytes = head + padded * (8 * sizeof(float4) + sizeof(uint4) + 2 * sizeof(uint32_t)) + n_seg * 2 * sizeof(uint32_t);
-    if (bytes > d.wf_bytes) {
-        if (d.wf) { RPT_HIP_CHECK(ctx, hipFree(d.wf)); d.wf = nullptr; d.wf_bytes = 0; }
-        RPT_HIP_CHECK(ctx, hipMalloc(&d.wf, bytes));
-        d.wf_bytes = bytes;
+    const uint64_t key[2] = {((uint64_t)width << 32) | rows_local, ((uint64_t)tile_rows << 40) ^ ((uint64_t)rank << 20) ^ (uint64_t)world};
+    d.sched_clock += 1;
+    if (d.sched && d.sched_key[0] == key[0] && d.sched_key[1] == key[1] && d.sched_tiles == nblocks) {
+        for (DevState::SchedEntry& e : d.sched_cache) if (e.buf == d.sched) e.stamp = d.sched_clock;
+        return RPT_OK;
     }
-    char* p = (char*)d.wf;
-    auto take = [&](size_t n) { char* q = p; p += n; return q; };
-    wb.group_next = (uint32_t*)take(kWalkGroups * kWalkCounterStride * sizeof(uint32_t));
-    wb.any_active = (uint32_t*)take(64 * sizeof(uint32_t));
-    wb.ray_o = (float4*)take(padded * sizeof(float4));
-    wb.ray_d = (float4*)take(padded * sizeof(float4));
-    wb.thr = (float4*)take(padded * sizeof(float4));
-    wb.rad = (float4*)take(padded * sizeof(float4));
-    wb.sh_o = (float4*)take(padded * sizeof(float4));
-    wb.sh_d = (float4*)take(padded * sizeof(float4));
-    wb.c_lit = (float4*)take(padded * sizeof(float4));
-    wb.prev = (float4*)take(padded * sizeof(float4));
-    wb.ctl = (uint4*)take(padded * sizeof(uint4));
-    wb.closest = (uint32_t*)take(padded * sizeof(uint32_t));
-    wb.shadow = (uint32_t*)take(padded * sizeof(uint32_t));
-    wb.cnt_closest = (uint32_t*)take(n_seg * sizeof(uint32_t));
-    wb.cnt_shadow = (uint32_t*)take(n_seg * sizeof(uint32_t));
-    wb.n_slots = (uint32_t)n_slots;
-    wb.n_seg = (uint32_t)n_seg;
+    for (DevState::SchedEntry& e : d.sched_cache) if (e.buf == d.sched) e.launches = d.sched_launches;     // park the current shape
+    DevState::SchedEntry* hit = nullptr;
+    for (DevState::SchedEntry& e : d.sched_cache) if (e.key[0] == key[0] && e.key[1] == key[1] && e.tiles == nblocks) hit = &e;
+    if (!hit) {
+        if (d.sched_cache.size() >= kSchedCache) {
+            size_t lru = 0;
+            for (size_t i = 1; i < d.sched_cache.size(); ++i) if (d.sched_cache[i].stamp < d.sched_cache[lru].stamp) lru = i;
+            RPT_HIP_CHECK(ctx, hipFree(d.sched_cache[lru].buf));     // (hipFree waits for the device: rare by construction)
+            d.sched_cache.erase(d.sched_cache.begin() + (long)lru);
+        }
+        const SchedLayout lay{(size_t)nblocks};
+        uint32_t* buf = nullptr;
+        RPT_HIP_CHECK(ctx, hipMalloc((void**)&buf, lay.total() * sizeof(uint32_t)));
+        d.sched_cache.push_back(DevState::SchedEntry{{key[0], key[1]}, buf, nblocks, 0, d.sched_clock});
+        hit = &d.sched_cache.back();
+        RPT_HIP_CHECK(ctx, hipMemsetAsync(buf + lay.sync(), 0, (32 + lay.n) * sizeof(uint32_t), stream));
+        RPT_HIP_CHECK(ctx, rptlaunch::sched_init(buf + lay.cost(), buf + lay.order(), nblocks, stream));
+    }
+    hit->stamp = d.sched_clock;
+    d.sched = hit->buf;
+    d.sched_tiles = hit->tiles;
+    d.sched_launches = hit->launches;
+    d.sched_key[0] = key[0]; d.sched_key[1] = key[1];
     return RPT_OK;
 }
 
+// One render launch sequence on one device.
 static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp,
                          uint64_t seed, uint32_t flags, uint32_t tile_rows, uint32_t rank, uint32_t world, hipStream_t stream)
 {
     if (world == 1) tile_rows = height;                              // one block: local row == global row
+    if (flags & ~(uint32_t)RPT_RENDER_ALL_FLAGS) {
+        set_err(ctx, "render: unknown flag bits 0x%x (bits 2-4, 6-7, 9-10 named A/B kernel forms until ABI 3; they are gone, include/rpt.h)", flags & ~(uint32_t)RPT_RENDER_ALL_FLAGS);
+        return RPT_ERR_INVALID_ARG;
+    }
     SceneSmallSdf scs = ctx->scene;
     SceneLarge scl = d.scene_large;
     scs.cam = scl.cam = make_camera(ctx->camera, (float)width, (float)height);
+    const bool has_sdf = !ctx->large && scs.sdf.n_prims > 0;
+    const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
+    const bool fast = (flags & RPT_RENDER_FAST_MATH) != 0;
 
     RenderParams rp;
     memset(&rp, 0, sizeof(rp));
@@ -493,116 +451,48 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
     rp.seed = seed;
     rp.tiles_x = (width + 15u) / 16u;
-    // SDF scenes: 0 inline march, 1 round 2's three-room march kernel, 2 / 3 the A/B kernels, 4 the two-room march kernel (default)
-    rp.sdf_resumable_march = (flags & RPT_RENDER_SDF_INLINE_MARCH) ? 0u : ((flags & RPT_RENDER_SDF_POOL_MARCH) ? 2u : (sdf_compact_wanted(flags) ? 3u :
-                             ((flags & RPT_RENDER_SDF_THREE_ROOM_MARCH) ? 1u : 4u)));
-    rp.sdf_compact_steps = sdf_compact_steps();
-    rp.pool_shade_lanes = sdf_pool_shade_lanes();
-    rp.pool_resolve_lanes = sdf_pool_resolve_lanes();
-    rp.pool_min_batch = sdf_pool_min_batch();
-    rp.pool_patience = sdf_pool_patience();
-    rp.shade_threshold = shade_threshold();
+    rp.shade_threshold = knobs().shade_threshold;
     // (small scenes' megakernel only; 8 ... 48 are within 2 % of each other, +5.9 % over finishing un-voted)
-    rp.finish_threshold = finish_threshold();
-    rp.compact = ((flags & RPT_RENDER_SMALL_COMPACT) || spp <= compact_max_spp()) ? 1u : 0u;
-    rp.march_min_lanes = sdf_march_min_lanes(rp.sdf_resumable_march == 4u);
-    {
-        static const char* mega = getenv("RPT_LARGE_MEGA");          // pair | plain: which megakernel large scenes with a grid take (A/B)
-        static const uint32_t refill = getenv("RPT_PAIR_REFILL_AT") ? ((uint32_t)atoi(getenv("RPT_PAIR_REFILL_AT")) & 63u) : (mega && mega[0] == 'c' ? 12u : 32u);
-        static const uint32_t wait_at = getenv("RPT_CARRY_WAIT_AT") ? (uint32_t)atoi(getenv("RPT_CARRY_WAIT_AT")) : 48u;
-        static const uint32_t walk_min = getenv("RPT_CARRY_WALK_MIN") ? (uint32_t)atoi(getenv("RPT_CARRY_WALK_MIN")) : 8u;
-        rp.large_pair_walk = (mega && mega[0] == 'p' && mega[1] == 'a') ? 1u : 0u;
-        rp.large_carry_walk = (mega && mega[0] == 'c') ? 1u : 0u;
-        rp.walk_refill_at = refill;
-        rp.carry_wait_at = wait_at < 1u ? 1u : wait_at;
-        rp.carry_walk_min = walk_min;
-        static const uint32_t walk_cap = getenv("RPT_LARGE_WALK_CAP") ? (uint32_t)atoi(getenv("RPT_LARGE_WALK_CAP")) : 0u;
-        rp.large_walk_cap = walk_cap;
-    }
+    rp.finish_threshold = knobs().finish_threshold;
+    rp.march_min_lanes = knobs().sdf_march_min_lanes;
+    rp.compact = (!ctx->large && !has_sdf && ((flags & RPT_RENDER_SMALL_COMPACT) || spp <= knobs().compact_max_spp)) ? 1u : 0u;
     if (flags & RPT_RENDER_RUSSIAN_ROULETTE) { scs.flags |= kSceneFlagRussianRoulette; scl.flags |= kSceneFlagRussianRoulette; }
     if (rp.rows_local == 0) return RPT_OK;
     const uint32_t tiles_y = (rp.rows_local + 15u) / 16u;
     const uint64_t nblocks = (uint64_t)rp.tiles_x * tiles_y;
     if (nblocks > 0x7FFFFFFFull) { set_err(ctx, "render: grid too large"); return RPT_ERR_INVALID_ARG; }
-    if (flags & RPT_RENDER_GRID_RESUMABLE_WALK) { set_err(ctx, "render: RPT_RENDER_GRID_RESUMABLE_WALK was removed (measured slower, DESIGN.md 4b)"); return RPT_ERR_UNSUPPORTED; }
-#ifndef RPT_AB_KERNELS
-    // Forms that only A/B builds hold (kernels.hip, rptlaunch::render): refused loudly, never replaced by another form in silence.
+    // The nested-loop kernel is the differential baseline of the reference's own scene class; the other classes have one form.
+    if (nested && (ctx->large || has_sdf || ctx->media)) {
+        set_err(ctx, "render: RPT_RENDER_NESTED_LOOPS exists for small scenes without an SDF object or media only");
+        return RPT_ERR_UNSUPPORTED;
+    }
+    if (ctx->media && fast) {
+        set_err(ctx, "render: scenes with participating media (RPT_SCENE_MEDIA) have no relaxed-arithmetic kernel form");
+        return RPT_ERR_UNSUPPORTED;
+    }
+
+    // Which instantiation (launch.h, KernelChoice): the kernels that know the reference scene's table sizes, and those that read a
+    // hit's material from a table (at most three primitives, at most one of them with a procedural material).
+    KernelChoice kc;
     {
-        const bool has_sdf = !ctx->large && scs.sdf.n_prims > 0;
-        const char* what = nullptr;
-        if ((flags & RPT_RENDER_NESTED_LOOPS) && (ctx->large || has_sdf || ctx->media)) what = "RPT_RENDER_NESTED_LOOPS for a large scene, an SDF object or media";
-        else if (has_sdf && (flags & RPT_RENDER_SDF_INLINE_MARCH)) what = "RPT_RENDER_SDF_INLINE_MARCH";
-        else if (has_sdf && (flags & RPT_RENDER_SDF_THREE_ROOM_MARCH)) what = "RPT_RENDER_SDF_THREE_ROOM_MARCH";
-        else if (ctx->large && scl.use_accel && scl.max_depth != 0u && wavefront_wanted(flags)) what = "RPT_RENDER_LARGE_WAVEFRONT";
-        else if (ctx->large && (rp.large_pair_walk || rp.large_carry_walk || rp.large_walk_cap)) what = "selected by RPT_LARGE_MEGA / RPT_LARGE_WALK_CAP";
-        if (what) {
-            set_err(ctx, "render: the A/B kernel form %s is not in this build (-DRPT_AB_KERNELS: python rust-pathtracer_amd/build.py --ab)", what);
-            return RPT_ERR_UNSUPPORTED;
-        }
+        const SceneSmall& sc = scs;
+        const bool can_size = !knobs().no_sized_kernels && !ctx->media && !ctx->large && !nested && !fast;
+        kc.sized = can_size && !has_sdf && sc.n_spheres == 2u && sc.n_planes == 1u && sc.n_lights == 1u;      // (kernel_common.h, RPT_REFERENCE_SIZES)
+        kc.sized_sdf = (can_size && has_sdf && sc.n_planes == 1u && sc.n_lights == 1u && scs.sdf.n_prims <= 4u) ? scs.sdf.n_prims : 0u;
+        kc.material_table = (kc.sized || kc.sized_sdf != 0u) && !knobs().no_material_table && rptlaunch::material_table_fits_small(scs, has_sdf);
+        kc.extra_lds = knobs().debug_extra_lds;
     }
-    if (flags & RPT_RENDER_SDF_COMPACT) {
-        set_err(ctx, "render: the A/B kernel RPT_RENDER_SDF_COMPACT is not in this build (-DRPT_AB_KERNELS)");
-        return RPT_ERR_UNSUPPORTED;
-    }
-    if (flags & RPT_RENDER_SDF_POOL_MARCH) {
-        set_err(ctx, "render: the A/B kernel RPT_RENDER_SDF_POOL_MARCH is not in this build (-DRPT_AB_KERNELS)");
-        return RPT_ERR_UNSUPPORTED;
-    }
-#endif
-    if (ctx->media && (flags & (RPT_RENDER_FAST_MATH | RPT_RENDER_SDF_POOL_MARCH | RPT_RENDER_SDF_COMPACT))) {
-        set_err(ctx, "render: scenes with participating media (RPT_SCENE_MEDIA) have no relaxed-arithmetic or A/B kernel form");
-        return RPT_ERR_UNSUPPORTED;
-    }
-    const bool nested = (flags & RPT_RENDER_NESTED_LOOPS) != 0;
-    // wavefront form of large scenes with a grid (max_depth == 0 has no bounce loop: the megakernel's prologue does that)
-    if ((flags & RPT_RENDER_LARGE_WAVEFRONT) && (flags & RPT_RENDER_LARGE_MEGAKERNEL)) {
-        set_err(ctx, "render: RPT_RENDER_LARGE_WAVEFRONT and RPT_RENDER_LARGE_MEGAKERNEL exclude each other");
-        return RPT_ERR_INVALID_ARG;
-    }
-    bool wavefront = ctx->large && scl.use_accel && !nested && scl.max_depth != 0u && wavefront_wanted(flags);
-    WfBuffers wb;
-    if (wavefront) {
-        const uint64_t n_slots = (uint64_t)rp.rows_local * width;
-        const bool forced = (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
-        // The wavefront form enqueues up to 2 * (spp * max_depth + 1) launches per chunk and, past 256 iterations, has the host
-        // look at the device's "anything left?" flag every 256 (kernels.hip, render_wavefront) — a wait that would keep the one
-        // host thread of a multi-device context from feeding its other devices.  Such contexts take the megakernel for deep
-        // bounds unless the caller insists.
-        const uint32_t chunk_spp = spp < rptlaunch::max_spp_per_launch(false) ? spp : rptlaunch::max_spp_per_launch(false);
-        if (!forced && ctx->devs.size() > 1 && (uint64_t)chunk_spp * scl.max_depth + 1u > kWavefrontMaxBlindIterations) wavefront = false;
-    }
-    if (wavefront) {
-        const uint64_t n_slots = (uint64_t)rp.rows_local * width;
-        const bool forced = (flags & RPT_RENDER_LARGE_WAVEFRONT) != 0;
-        if (n_slots >= (1ull << 31)) {
-            if (forced) { set_err(ctx, "render: tile too large for the wavefront form"); return RPT_ERR_INVALID_ARG; }
-            wavefront = false;
-        } else {
-            int rc = wavefront_buffers(ctx, d, (size_t)n_slots, wb);
-            if (rc != RPT_OK) {
-                if (forced) return rc;
-                (void)hipGetLastError();                            // no room for 168 B per pixel: the megakernel needs none
-                wavefront = false;
-            }
-        }
-    }
+    const auto launch = [&](uint32_t grid) -> hipError_t {
+        if (ctx->large) return fast ? rptlaunch_fast::render_large(scl, false, rp, grid, stream) : rptlaunch::render_large(scl, ctx->media, rp, grid, stream);
+        if (has_sdf) return fast ? rptlaunch_fast::render_sdf(scs, false, rp, grid, stream, kc) : rptlaunch::render_sdf(scs, ctx->media, rp, grid, stream, kc);
+        if (rp.compact && !nested) return fast ? rptlaunch_fast::render_compact(scs, false, rp, grid, stream, kc) : rptlaunch::render_compact(scs, ctx->media, rp, grid, stream, kc);
+        return fast ? rptlaunch_fast::render_small(scs, false, nested, rp, grid, stream, kc) : rptlaunch::render_small(scs, ctx->media, nested, rp, grid, stream, kc);
+    };
 
-    const SceneSmallSdf* scs_dev = nullptr;
-    if (!ctx->large && scs.sdf.n_prims > 0 && rp.sdf_resumable_march == 3u && !nested) {
-        // (a copy per launch: the camera in it depends on the frame size; pageable source, so the copy has left `scs` on return)
-        if (!d.scene_small_dev) RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.scene_small_dev, sizeof(SceneSmallSdf)));
-        // (the context's one copy: a launch on another stream may still be reading the previous frame size's camera)
-        if (d.sc_used && d.sc_stream != stream) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, d.sc_done, 0));
-        RPT_HIP_CHECK(ctx, hipMemcpyAsync(d.scene_small_dev, &scs, sizeof(SceneSmallSdf), hipMemcpyHostToDevice, stream));
-        scs_dev = d.scene_small_dev;
-    }
-
-    if (wavefront && d.wf_used && d.wf_stream != stream) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, d.wf_done, 0));   // the path buffers are the context's
-
-    // Dispatch (kernels.hip): this device's launches of `nblocks` tiles run most expensive tile first, as measured by the previous
+    // Dispatch (kernel_common.h): this device's launches of `nblocks` tiles run most expensive tile first, as measured by the previous
     // one, and in units of one tile x one chunk of the samples.
-    // Kernels without units: nested loops, the compacting kernel of small scenes, the A/B compacting SDF kernel.
-    const bool unit_kernel = !wavefront && !nested && !(rp.compact && !ctx->large && scs.sdf.n_prims == 0) && !scs_dev;
+    // Kernels without units: nested loops, the compacting kernel of small scenes.
+    const bool unit_kernel = !nested && !rp.compact;
     const SchedLayout lay{(size_t)nblocks};
     bool reorder = false;
     DispatchPolicy pol = policy_of(ctx);
@@ -612,28 +502,20 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     // The compacting kernel of one-sample launches below three rounds of workgroups stays bottom rows first: most expensive first
     // costs 8 % at the reference's 800x600 window (1.5 rounds; 0.081 -> 0.088 ms) and gains 2 % at 1920x1080 (6.4 rounds).
     if (!unit_kernel && nblocks < 3ull * slots) pol.cost_order = 0u;
-    if (!wavefront && !nested && (pol.cost_order != 0u || unit_kernel)) {
-        if (d.sched_tiles != (uint32_t)nblocks) {
-            if (d.sched) { RPT_HIP_CHECK(ctx, hipFree(d.sched)); d.sched = nullptr; d.sched_tiles = 0; }   // (hipFree waits for the device)
-            RPT_HIP_CHECK(ctx, hipMalloc((void**)&d.sched, lay.total() * sizeof(uint32_t)));
-            d.sched_tiles = (uint32_t)nblocks;
-            d.sched_launches = 0;
-            d.sched_used = false;
-            RPT_HIP_CHECK(ctx, hipMemsetAsync(d.sched + lay.sync(), 0, (32 + lay.n) * sizeof(uint32_t), stream));
-            RPT_HIP_CHECK(ctx, rptlaunch::sched_init(d.sched + lay.cost(), d.sched + lay.order(), d.sched_tiles, stream));
-        }
+    if (!nested && (pol.cost_order != 0u || unit_kernel)) {
+        RPT_CHECK_RC(sched_for(ctx, d, (uint32_t)nblocks, width, rp.rows_local, tile_rows, rank, world, stream));
         if (d.sched_used && d.sched_stream != stream) RPT_HIP_CHECK(ctx, hipStreamWaitEvent(stream, d.sched_done, 0));
         if (pol.cost_order != 0u) {
             d.sched_launches += 1;
             reorder = spp >= kOrderAlwaysFromSpp || (d.sched_launches & (d.sched_launches - 1u)) == 0u;
             rp.tile_order = d.sched + lay.order();
             rp.tile_cost = reorder ? d.sched + lay.cost() : nullptr;
-            rp.tile_start = (reorder && getenv("RPT_DISPATCH_TIMELINE")) ? d.sched + lay.start() : nullptr;
+            rp.tile_start = (reorder && knobs().dispatch_timeline) ? d.sched + lay.start() : nullptr;
         }
         rp.sched_sync = d.sched + lay.sync();
     }
 
-    const uint32_t max_chunk = rptlaunch::max_spp_per_launch(!ctx->large && scs.sdf.n_prims > 0);
+    const uint32_t max_chunk = rptlaunch::max_spp_per_launch(has_sdf);
     if (unit_kernel) {
         // ONE launch whatever spp is: the LDS tables of the state-machine kernels hold a chunk's samples, and a launch is as many
         // chunks as it takes.
@@ -647,9 +529,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         rp.spp = spp;
         rp.frames_done = frames_done;
         if (n_chunks > 1u) RPT_HIP_CHECK(ctx, hipMemsetAsync(d.sched + lay.sync() + kSyncZeroFrom, 0, (32 - kSyncZeroFrom + lay.n) * sizeof(uint32_t), stream));
-        const uint32_t grid = (uint32_t)(nblocks * n_chunks);
-        if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, grid, stream, scs_dev));
-        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, grid, stream, scs_dev, ctx->media));
+        RPT_HIP_CHECK(ctx, launch((uint32_t)(nblocks * n_chunks)));
         d.sync_used = d.sync_used || n_chunks > 1u;
     } else
     // Kernels without units: batches beyond what one launch holds are split into consecutive launches (the running mean carries
@@ -659,16 +539,8 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         rp.spp = chunk;
         rp.frames_done = frames_done + done;
         rp.n_chunks = 0u;
-        if (wavefront && (flags & RPT_RENDER_FAST_MATH)) RPT_HIP_CHECK(ctx, rptlaunch_fast::render_wavefront(scl, rp, wb, stream));
-        else if (wavefront) RPT_HIP_CHECK(ctx, rptlaunch::render_wavefront(scl, rp, wb, stream, ctx->media));
-        else if (flags & RPT_RENDER_FAST_MATH) RPT_HIP_CHECK(ctx, rptlaunch_fast::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev));
-        else RPT_HIP_CHECK(ctx, rptlaunch::render(scs, scl, ctx->large, nested, rp, (uint32_t)nblocks, stream, scs_dev, ctx->media));
+        RPT_HIP_CHECK(ctx, launch((uint32_t)nblocks));
         done += chunk;
-    }
-    if (wavefront) {
-        RPT_HIP_CHECK(ctx, hipEventRecord(d.wf_done, stream));
-        d.wf_stream = stream;
-        d.wf_used = true;
     }
     if (rp.tile_order || rp.sched_sync) {
         if (reorder && pol.cost_order != 2u)
@@ -677,26 +549,36 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         d.sched_stream = stream;
         d.sched_used = true;
     }
-    if (scs_dev) {
-        RPT_HIP_CHECK(ctx, hipEventRecord(d.sc_done, stream));
-        d.sc_stream = stream;
-        d.sc_used = true;
-    }
     return RPT_OK;
 }
 
-// Behind a wait for the device: did a unit of a chunked launch give up waiting for its tile's previous chunk (kernels.hip,
-// unit_begin)?  It cannot happen by construction (the predecessor holds an earlier ticket); if it ever does the image is wrong
-// and the caller must know.
+// Behind a wait for the device: did a unit of a chunked launch give up waiting for its tile's previous chunk (kernel_common.h,
+// unit_begin)?  It cannot happen by construction (the predecessor holds an earlier ticket); if it ever does the image is wrong —
+// the unit has poisoned its pixels with NaN — and the caller must know.  The word is cleared once it has been reported.
 static int check_handoffs(rpt_ctx* ctx, DevState& d)
 {
-    if (!d.sync_used || !d.sched) return RPT_OK;
-    uint32_t timed_out = 0;
-    RPT_HIP_CHECK(ctx, hipMemcpy(&timed_out, d.sched + SchedLayout{(size_t)d.sched_tiles}.sync() + kSyncTimeoutWord, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (!d.sync_used) return RPT_OK;
     d.sync_used = false;
-    if (timed_out) {
-        set_err(ctx, "render: a workgroup timed out waiting for its tile's previous chunk of samples on device %d; the image is incomplete", d.device);
+    bool any = false;
+    for (DevState::SchedEntry& e : d.sched_cache) {
+        uint32_t* word = e.buf + SchedLayout{(size_t)e.tiles}.sync() + kSyncTimeoutWord;
+        uint32_t timed_out = 0;
+        RPT_HIP_CHECK(ctx, hipMemcpy(&timed_out, word, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        if (timed_out) { any = true; RPT_HIP_CHECK(ctx, hipMemset(word, 0, sizeof(uint32_t))); }
+    }
+    if (any) {
+        set_err(ctx, "render: a workgroup timed out waiting for its tile's previous chunk of samples on device %d; the tile's pixels are NaN", d.device);
         return RPT_ERR_HIP;
+    }
+    return RPT_OK;
+}
+static int check_handoffs_all(rpt_ctx* ctx)
+{
+    DeviceGuard guard(ctx->devs[0].device);
+    for (DevState& d : ctx->devs) {
+        if (!d.sync_used) continue;
+        RPT_HIP_CHECK(ctx, guard.to(d.device));
+        RPT_CHECK_RC(check_handoffs(ctx, d));
     }
     return RPT_OK;
 }
@@ -725,13 +607,15 @@ struct HostPin {
     ~HostPin() { if (p) (void)hipHostUnregister(p); }
 };
 
+// The library is built with -fvisibility=hidden: what include/rpt.h (and, in the test build, include/rpt_test.h) declares is ALL it exports.
+#pragma GCC visibility push(default)
 extern "C" {
 
 uint32_t rpt_abi_version(void) { return RPT_ABI_VERSION; }
 uint32_t rpt_sizeof_scene_desc(void) { return (uint32_t)sizeof(rpt_scene_desc); }
-uint32_t rpt_build_has_ab_kernels(void)
+uint32_t rpt_build_has_test_hooks(void)
 {
-#ifdef RPT_AB_KERNELS
+#ifdef RPT_TEST_HOOKS
     return 1u;
 #else
     return 0u;
@@ -820,11 +704,10 @@ int rpt_create_multi(rpt_ctx** out, const int* device_ids, int n_devices)
     // resident 1920x1080 frame: 11.4 -> 12.0 Gsamples/s with the device listed twice; 3840x270: 7.6 -> 9.3).  RCCL needs one device
     // per rank, so such contexts gather with peer copies (on one device: device-to-device copies); RPT_GATHER=p2p asks for that
     // with distinct devices too.
-    const char* g = getenv("RPT_GATHER");
     bool distinct = true;
     for (int i = 0; i < n_devices; ++i)
         for (int j = 0; j < i; ++j) distinct = distinct && device_ids[i] != device_ids[j];
-    const bool peer = !distinct || (g && strcmp(g, "p2p") == 0);
+    const bool peer = !distinct || knobs().gather == "p2p";
     rpt_ctx* ctx = new (std::nothrow) rpt_ctx();
     if (!ctx) return RPT_ERR_HIP;
     ctx->devs.resize((size_t)n_devices);
@@ -1005,7 +888,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         const size_t sz_smat = (sizeof(uint32_t) * s->n_spheres + 15) & ~(size_t)15;
         const size_t sz_lights = (sizeof(DevLight) * (s->n_lights ? s->n_lights : 1) + 15) & ~(size_t)15;
         const size_t sz_mats = (sizeof(DevMaterial) * (s->n_materials ? s->n_materials : 1) + 15) & ~(size_t)15;
-        const bool use_accel = s->n_spheres >= 64 && !getenv("RPT_NO_GRID");
+        const bool use_accel = s->n_spheres >= 64 && !knobs().no_grid;
         HostAccel accel;
         if (use_accel) {
             std::string why;
@@ -1072,17 +955,16 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         ctx->large = true;
         ctx->media = media;
         ctx->has_scene = true;
-        for (DevState& dv : ctx->devs) dv.sched_launches = 0;           // a new scene: the dispatch order is learned again
+        for (DevState& dv : ctx->devs) { dv.sched_launches = 0; for (DevState::SchedEntry& e : dv.sched_cache) e.launches = 0; }   // a new scene: the dispatch order is learned again
         return RPT_OK;
     }
 
-    for (DevState& d : ctx->devs) {                                 // a small scene needs no tables: drop a previous large scene's,
-        if (!d.tables && !d.wf) continue;                           // and the path buffers of its wavefront form
+    for (DevState& d : ctx->devs) {                                 // a small scene needs no tables: drop a previous large scene's
+        if (!d.tables) continue;
         DeviceGuard guard(d.device);
         RPT_HIP_CHECK(ctx, guard.status);
         RPT_HIP_CHECK(ctx, hipStreamSynchronize(d.stream));
-        if (d.tables) { RPT_HIP_CHECK(ctx, hipFree(d.tables)); d.tables = nullptr; }
-        if (d.wf) { RPT_HIP_CHECK(ctx, hipFree(d.wf)); d.wf = nullptr; d.wf_bytes = 0; }
+        RPT_HIP_CHECK(ctx, hipFree(d.tables)); d.tables = nullptr;
     }
     SceneSmallSdf& d = ctx->scene;
     memset(&d, 0, sizeof(d));
@@ -1177,8 +1059,7 @@ int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height, uin
     const uint32_t tile_rows = world == 1 ? height : ctx->tile_rows;
     const uint32_t rows_padded = rows_padded_for(height, tile_rows, world);
     HostPin pin;
-    static const bool pin_wanted = !(getenv("RPT_PIN_HOST") && atoi(getenv("RPT_PIN_HOST")) == 0);
-    if (ctx->devs.size() > 1 && pin_wanted) pin.lock(pixels, (size_t)width * height * 16u);
+    if (ctx->devs.size() > 1 && knobs().pin_host) pin.lock(pixels, (size_t)width * height * 16u);
     const auto enqueue = [&]() -> int {
         for (DevState& d : ctx->devs) {
             RPT_HIP_CHECK(ctx, guard.to(d.device));
@@ -1215,7 +1096,8 @@ int rpt_render(rpt_ctx* ctx, float* pixels, uint32_t width, uint32_t height, uin
     return rc != RPT_OK ? rc : rc_sync;
 }
 
-// Test / development probe (include/rpt.h): device 0's tile costs (4 per tile), dispatch order, development data.
+#ifdef RPT_TEST_HOOKS    // include/rpt_test.h: the test build only (librpt_hip_test.so)
+// Test / development probe (include/rpt_test.h): device 0's tile costs (4 per tile), dispatch order, development data.
 int rpt_debug_sched_read(rpt_ctx* ctx, uint32_t* out, uint32_t capacity_tiles, uint32_t* n_tiles)
 {
     if (!ctx || !out || !n_tiles) return RPT_ERR_INVALID_ARG;
@@ -1228,7 +1110,10 @@ int rpt_debug_sched_read(rpt_ctx* ctx, uint32_t* out, uint32_t capacity_tiles, u
     return RPT_OK;
 }
 
-// Test probe (include/rpt.h): how long before device `a`'s last render ENDED device `b`'s began.
+// (include/rpt_test.h) read the environment's knobs again
+int rpt_debug_reload_knobs(void) { rpthost::reload_knobs(); return RPT_OK; }
+
+// Test probe (include/rpt_test.h): how long before device `a`'s last render ENDED device `b`'s began.
 int rpt_debug_render_overlap_ms(rpt_ctx* ctx, int a, int b, float* ms)
 {
     if (!ctx || !ms || a < 0 || b < 0 || (size_t)a >= ctx->devs.size() || (size_t)b >= ctx->devs.size()) {
@@ -1245,6 +1130,8 @@ int rpt_debug_render_overlap_ms(rpt_ctx* ctx, int a, int b, float* ms)
     RPT_HIP_CHECK(ctx, hipEventElapsedTime(ms, db.ev_begin, da.ev_end));
     return RPT_OK;
 }
+
+#endif  // RPT_TEST_HOOKS
 
 // ---- resident ColorBuffer ------------------------------------------------------------------------------------
 
@@ -1396,15 +1283,24 @@ static int gather_to_root(rpt_ctx* ctx, float* image_dst, float** image_out)
         RcclApi* api = rccl_api();
         if (!api) { set_err(ctx, "gather: cannot load RCCL: %s", rccl_why()); return RPT_ERR_RCCL; }
         RPT_RCCL_CHECK(ctx, api, api->GroupStart());
+        // From here to GroupEnd nothing returns: a group left open would swallow every later RCCL call of the process.
+        ncclResult_t posted = ncclSuccess;
+        const char* what = "";
         for (DevState& d : ctx->devs) {
+            if (posted != ncclSuccess) break;
             if (d.rank == 0) {
-                for (uint32_t r = 1; r < world; ++r)
-                    RPT_RCCL_CHECK(ctx, api, api->Recv(ctx->gathered + (size_t)r * count, count, ncclFloat, (int)r, d.comm, d.comm_stream));
+                for (uint32_t r = 1; r < world && posted == ncclSuccess; ++r) {
+                    posted = api->Recv(ctx->gathered + (size_t)r * count, count, ncclFloat, (int)r, d.comm, d.comm_stream);
+                    what = "ncclRecv";
+                }
             } else {
-                RPT_RCCL_CHECK(ctx, api, api->Send(d.snap, count, ncclFloat, 0, d.comm, d.comm_stream));
+                posted = api->Send(d.snap, count, ncclFloat, 0, d.comm, d.comm_stream);
+                what = "ncclSend";
             }
         }
-        RPT_RCCL_CHECK(ctx, api, api->GroupEnd());
+        const ncclResult_t closed = api->GroupEnd();
+        if (posted != ncclSuccess) { set_err(ctx, "gather: %s failed: %s", what, api->GetErrorString(posted)); return RPT_ERR_RCCL; }
+        if (closed != ncclSuccess) { set_err(ctx, "gather: ncclGroupEnd failed: %s", api->GetErrorString(closed)); return RPT_ERR_RCCL; }
         if (ctx->is_root()) {
             RPT_HIP_CHECK(ctx, guard.to(root.device));
             RPT_HIP_CHECK(ctx, hipMemcpyAsync(ctx->gathered, root.snap, count * 4u, hipMemcpyDeviceToDevice, root.comm_stream));
@@ -1632,9 +1528,10 @@ int rpt_synchronize(rpt_ctx* ctx, void* stream)
     if (!ctx) { set_err(nullptr, "rpt_synchronize: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
     RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, hipStreamSynchronize((hipStream_t)stream));
-    return check_handoffs(ctx, ctx->devs[0]);
+    return check_handoffs_all(ctx);
 }
 
+#ifdef RPT_TEST_HOOKS    // include/rpt_test.h: the test build only
 int rpt_probe_rays(rpt_ctx* ctx, const float* rays_dev, uint32_t* out_dev, uint64_t n, uint32_t use_grid, void* stream)
 {
     if (!ctx) { set_err(nullptr, "rpt_probe_rays: ctx is NULL"); return RPT_ERR_INVALID_ARG; }
@@ -1675,13 +1572,23 @@ int rpt_probe_fn(rpt_ctx* ctx, uint32_t fn, const float* in_dev, float* out_dev,
     return RPT_OK;
 }
 
+#endif  // RPT_TEST_HOOKS
+
 }  // extern "C"
+#pragma GCC visibility pop
 
 #ifdef RPT_PROFILE_BLOCKS
-// Development build only (dev_prof.h, tools/block_profile.py): not part of include/rpt.h.
-namespace rptlaunch { hipError_t prof_read(unsigned long long* out); }
-extern "C" int rpt_prof_read(unsigned long long* out)
+// Development build only (dev_prof.h, tools/block_profile.py): not part of include/rpt.h.  Every kernel class's object keeps its own
+// counters; a profiled run uses one class, so their sum is that class's table.
+extern "C" __attribute__((visibility("default"))) int rpt_prof_read(unsigned long long* out)
 {
-    return rptlaunch::prof_read(out) == hipSuccess ? RPT_OK : RPT_ERR_HIP;
+    unsigned long long part[rptdev::PB_COUNT * 3];
+    for (uint32_t i = 0; i < rptdev::PB_COUNT * 3; ++i) out[i] = 0;
+    hipError_t (*const readers[3])(unsigned long long*) = {rptlaunch::prof_read_small, rptlaunch::prof_read_sdf, rptlaunch::prof_read_large};
+    for (auto rd : readers) {
+        if (rd(part) != hipSuccess) return RPT_ERR_HIP;
+        for (uint32_t i = 0; i < rptdev::PB_COUNT * 3; ++i) out[i] += part[i];
+    }
+    return RPT_OK;
 }
 #endif

@@ -65,7 +65,17 @@ __global__ __launch_bounds__(kDnThreads) void denoise_tile_kernel(const float4* 
 {
     constexpr int T = kDnTile + 2 * STEP;
     __shared__ float s_c[3][T * T];
+#ifdef RPT_DENOISE_XCD
+    // Workgroups go to the 8 XCDs round-robin in dispatch order, and a tile's halo is its neighbours' pixels: with every XCD
+    // on its own band of consecutive tiles the halos are hits in that XCD's L2 instead of a second fetch from memory.
+    const uint32_t tiles_x = (w + (uint32_t)kDnTile - 1u) / (uint32_t)kDnTile, tiles_y = (h + (uint32_t)kDnTile - 1u) / (uint32_t)kDnTile;
+    const uint32_t per = (tiles_x * tiles_y + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (tile >= tiles_x * tiles_y) return;
+    const int x0 = (int)(tile % tiles_x) * kDnTile, y0 = (int)(tile / tiles_x) * kDnTile;
+#else
     const int x0 = (int)blockIdx.x * kDnTile, y0 = (int)blockIdx.y * kDnTile;
+#endif
     for (uint32_t e = threadIdx.x; e < (uint32_t)(T * T); e += kDnThreads) {
         const int lx = (int)(e % (uint32_t)T), ly = (int)(e / (uint32_t)T);
         const int gx = x0 + lx - STEP, gy = y0 + ly - STEP;
@@ -132,7 +142,12 @@ hipError_t denoise(const float* in, float* out, float* scratch, uint32_t width, 
 {
     (void)hipGetLastError();
     const dim3 grid((width + 15u) / 16u, (height + 15u) / 16u), wg(256);
+#ifdef RPT_DENOISE_XCD
+    const uint32_t n_tiles = ((width + (uint32_t)kDnTile - 1u) / (uint32_t)kDnTile) * ((height + (uint32_t)kDnTile - 1u) / (uint32_t)kDnTile);
+    const dim3 tgrid(8u * ((n_tiles + 7u) / 8u)), twg(kDnThreads);
+#else
     const dim3 tgrid((width + (uint32_t)kDnTile - 1u) / (uint32_t)kDnTile, (height + (uint32_t)kDnTile - 1u) / (uint32_t)kDnTile), twg(kDnThreads);
+#endif
     float k = edge_k;
     const float4* cur = nullptr;
     for (uint32_t i = 0; i < iterations; ++i) {

@@ -31,11 +31,12 @@ enum ProfBlock : uint32_t {
     PB_SAMPLE_TAIL,    //   to_world, throughput, next ray
     PB_PASS,           // one pass of the scheduling loop (votes included)
     PB_GRID_BEGIN,     // large scenes: DDA set-up of one grid walk
-    PB_GRID_CELL,      // large scenes: one cell of a grid walk (record tests + step + prefetch)
-    PB_WF_WAVE,        // wavefront walk kernel: a wave's whole life
-    PB_WF_FETCH,       //   taking segments / entries for the idle lanes
-    PB_WF_SETUP,       //   ray load, slab test, DDA set-up, first cell's bounds
-    PB_WF_CELL,        //   one cell iteration of the wave
+    PB_GRID_CELL,      // large scenes: one cell of a closest-hit walk (record tests + step + prefetch)
+    PB_GRID_CELL_ANY,  // large scenes: one cell of a SHADOW walk (PB_GRID_CELL: of a closest-hit walk)
+    PB_GRID_EXTRA,     //   a trip of a cell's list beyond its first batch (either walk)
+    PB_GRID_RESOLVE,   //   the square-root half of a candidate (either walk)
+    PB_WALK_HEAD,      // large scenes: sphere 0, oversize spheres, the grid-or-brute decision before a closest-hit walk
+    PB_LIGHTS,         // large scenes: sample_lights' loop over the light spheres
     PB_COUNT
 };
 
@@ -82,6 +83,14 @@ struct ProfScope {
         }
     }
 };
+// host: copy out and clear this translation unit's counters
+inline hipError_t prof_read(unsigned long long* out)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * PB_COUNT * 3);
+    if (e != hipSuccess) return e;
+    static const unsigned long long zeros[PB_COUNT * 3] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zeros, sizeof(zeros));
+}
 #define RPT_PROF(id) ::rptdev::ProfScope rpt_prof_scope_##id(::rptdev::id)
 #define RPT_PROF_INIT() ::rptdev::prof_init()
 #define RPT_PROF_FLUSH() ::rptdev::prof_flush()

@@ -209,21 +209,8 @@ struct RenderParams {
     uint32_t shade_threshold;  // lanes that must be waiting before a wave runs the shading block
     uint32_t finish_threshold; // ... and before it runs the finishing block (background, blend, next camera path) instead of the fuller room
     uint32_t march_min_lanes;      // SDF scenes: a wave keeps marching while at least this many lanes are marching
-    uint32_t sdf_resumable_march;  // SDF scenes: 0 march inside closest_hit / any_hit, 1 as a scheduling state of the lane (dev_sdf_path.h),
-                                   // 2 through the workgroup's march pool (dev_sdf_pool.h), 3 the compacting kernel (paths in LDS)
-    uint32_t pool_shade_lanes;     // march pool: a wave runs SHADE / RESOLVE when this many of its lanes wait at it ...
-    uint32_t pool_resolve_lanes;
-    uint32_t pool_min_batch;       // ... serves the queue when it can fill this many lanes with jobs ...
-    uint32_t pool_patience;        // ... and after this many idle passes does whatever there is to do
-    uint32_t sdf_compact_steps;    // SDF scenes, compacting kernel: march iterations per pass
-    uint32_t large_pair_walk;      // large scenes with a grid: the megakernel that walks a bounce's two rays in one loop (kernels.hip, render_large_pair_kernel)
-    uint32_t walk_refill_at;       // ... its idle lanes set up their next ray when at most this many lanes still walk
-    uint32_t large_carry_walk;     // large scenes with a grid: the megakernel whose walks are a scheduling state of the lane (kernel_large_carry.h)
-    uint32_t carry_wait_at;        // ... it leaves the walk loop for the block when this many lanes are through their walks ...
-    uint32_t carry_walk_min;       // ... or when fewer than this many still walk (and somebody waits)
-    uint32_t large_walk_cap;       // large scenes with a grid: cells a closest-hit walk takes per TRACE pass before it parks (0: the walk runs inside closest_hit)
     uint32_t compact;              // small scenes: the kernel that re-deals its workgroup's paths before every stage (few samples per launch)
-    // Dispatch (kernels.hip, "Dispatch: units, their order, their hand-off").  A launch of the state-machine kernels is
+    // Dispatch (kernel_common.h, "Dispatch: units, their order, their hand-off").  A launch of the state-machine kernels is
     // n_chunks * (tiles) workgroups; each renders chunk_spp samples (the last chunk: the rest of spp) of one tile.  n_chunks == 0:
     // a kernel without units (nested loops, the compacting kernel): workgroup b renders tile tile_order[b], all samples.
     uint32_t n_chunks, chunk_spp;

@@ -331,6 +331,7 @@ RPT_DEV bool closest_walk_cell(const SceneLarge& sc, const RayD& ray, ClosestWal
     // square root, so t0 = tca - thc <= tca + thc = t1 unless both are NaN, and then nothing below accepts them either.  The
     // sphere's index is loaded only for a root that can still win (t <= dist).
     auto resolve = [&](float tca, float rd, uint32_t kk) {
+        RPT_PROF(PB_GRID_RESOLVE);
         const float thc = fsqrt(rd);
         const float t0 = tca - thc;
         const float t1 = tca + thc;
@@ -355,6 +356,7 @@ RPT_DEV bool closest_walk_cell(const SceneLarge& sc, const RayD& ray, ClosestWal
     };
     test_batch(w.pf, k0);                                           // the list's first entries were requested a cell ago (+1.5 %, round 4)
     for (uint32_t k = k0 + RPT_GRID_BATCH; k < k1; k += RPT_GRID_BATCH) {
+        RPT_PROF(PB_GRID_EXTRA);
         float4 sp[RPT_GRID_BATCH];
 #pragma unroll
         for (uint32_t j = 0; j < RPT_GRID_BATCH; ++j) sp[j] = gather32(sc.cell_spheres, k + j);
@@ -376,6 +378,7 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
 {
     if (!grid_usable(sc, ray)) { brute_closest_sphere(sc, ray, dist, best, hit); return; }
     uint32_t hit_w = hit ? 1u : 0u;
+    {   RPT_PROF(PB_WALK_HEAD);
     {   // sphere 0: accepted whenever it is hit (analytical.rs:43)
         const float4 s = sphere_uniform(sc, 0);
         float t;
@@ -386,6 +389,7 @@ RPT_DEV void grid_closest_sphere(const SceneLarge& sc, const RayD& ray, float& d
         const float4 s = sphere_uniform(sc, i);
         float t;
         if (i != 0u && hit_sphere(ray, mk3(s.x, s.y, s.z), s.w, t) && (t < dist || (t == dist && i < best))) { dist = t; best = i; hit_w = 1u; }
+    }
     }
     ClosestWalk w;
     { RPT_PROF(PB_GRID_BEGIN); w.g = grid_begin(sc, ray); }
@@ -414,7 +418,7 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
     if (g.alive) cell_bounds(sc, grid_cell_index(sc, g), k0, k1);
     if (g.alive)
     for (uint32_t guard = sc.gn[0] + sc.gn[1] + sc.gn[2] + 3u; guard != 0u; --guard) {
-        RPT_PROF(PB_GRID_CELL);
+        RPT_PROF(PB_GRID_CELL_ANY);
         const float t_exit = grid_cell_exit(g);
         const bool last = t_exit > g.t_end;
         grid_advance(g);                                            // as in grid_closest_sphere
@@ -499,6 +503,7 @@ RPT_DEV bool closest_geom_finish(const SceneLarge& sc, const RayD& ray, PathStat
     // itself.  Per light the operations and their order are light_intersect's.  (Until round 4 every closest_hit loaded 16 light
     // records of 15 dwords one after the other and waited for each: a fifth of the 10 k-sphere frame's time.)
     uint32_t hit_w = hit ? 1u : 0u;
+    RPT_PROF(PB_LIGHTS);
     for (uint32_t i = 0; i < sc.n_light_spheres; i += 4u) {
         cfloat_p rec = (cfloat_p)sc.light_spheres + 4u * i;
         float c_tca[4], c_rd[4];

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/rpt.h"
+#include "knobs.h"
 
 namespace rpthost {
 
@@ -107,8 +108,7 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
     half_diag = std::sqrt(half_diag);
     const double safe_r = 6.0 * half_diag;
     g.safe_r2 = (float)(safe_r * safe_r);
-    const char* nr = getenv("RPT_GRID_NEAR_REACH");                // near tier's reach in half-diagonals (0: none)
-    const double near_r = (nr ? atof(nr) : 1.5) * half_diag;
+    const double near_r = (double)knobs().grid_near_reach * half_diag;      // near tier's reach in half-diagonals (0: none)
     const int n_tiers = near_r > 0.0 && near_r < safe_r ? 2 : 1;
     g.cell_start.clear();
     g.items.clear();
@@ -127,8 +127,7 @@ inline bool build_grid(const rpt_sphere* sph, uint32_t count, double spheres_per
         // reported hit point lies within sqrt(r^2 + d2_err) of the centre, so its cell is one of these.  (Border cells stand for
         // everything outside the grid on their side — the box above is clamped — so they are kept as the box has them.)
         auto touches = [&](const rpt_sphere& s, int x, int y, int z) {
-            static const bool ball = !(getenv("RPT_GRID_BOX_LISTS") && atoi(getenv("RPT_GRID_BOX_LISTS")) != 0);
-            if (!ball) return true;
+            if (knobs().grid_box_lists) return true;
             const int c[3] = {x, y, z};
             double d2 = 0.0;
             for (int a = 0; a < 3; ++a) {
@@ -199,8 +198,7 @@ struct HostAccelData {
 
 inline bool build_accel(const rpt_sphere* sph, uint32_t count, HostAccelData& a, std::string& why)
 {
-    const char* e = getenv("RPT_GRID_SPHERES_PER_CELL");
-    if (!build_grid(sph, count, e ? atof(e) : 1.0, a.grid, why)) return false;
+    if (!build_grid(sph, count, (double)knobs().grid_spheres_per_cell, a.grid, why)) return false;
     // (kSpare more entries than the lists hold: the walks read a list RPT_GRID_BATCH entries per trip without asking whether the
     // last trip's entries are all there — the answer is in the candidate test anyway — so the array must be readable a little past its end)
     a.cell_spheres.assign((a.grid.items.size() + kSpareListEntries) * 4, 0.0f);

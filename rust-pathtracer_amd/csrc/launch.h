@@ -1,4 +1,6 @@
-// launch.h — the seam between the host-side C ABI (capi.hip) and the kernels (kernels.hip).
+// launch.h — the seam between the host-side C ABI (capi.hip) and the kernels: one translation unit per kernel class
+// (k_small.hip, k_compact.hip, k_sdf.hip, k_large.hip: each holds its kernels and the function that launches them), the utility
+// kernels (k_util.hip), the denoiser (denoise.hip) and, in the test build only, the probes (k_probes.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -6,28 +8,30 @@
 
 #include "dev_scene.h"
 #include "dev_scene_large.h"
-#include "dev_wavefront.h"
 
 #include "tile_plan.h"
+
+// Which instantiation of a class's kernel a launch takes (capi.hip decides from the scene and the knobs, knobs.h).
+struct KernelChoice {
+    bool sized = false;             // small scenes: the reference scene's table sizes are known at compile time (kernel_common.h, sized_scene)
+    uint32_t sized_sdf = 0;         // SDF scenes: 1-4 primitives over one plane under one light: that many, known at compile time; 0: data
+    bool material_table = false;    // a hit's material from the workgroup's table (dev_integrator.h, MaterialTable)
+    uint32_t extra_lds = 0;         // development: pad the headline kernel's LDS (occupancy experiments)
+};
 
 namespace rptlaunch {
 
 uint32_t max_spp_per_launch(bool sdf_object);      // samples a chunk of the state-machine kernels can hold in its LDS tables (scenes with an SDF object: fewer)
+bool material_table_fits_small(const rptdev::SceneSmallSdf& scs, bool has_sdf);   // (kernel_common.h, material_table_fits)
 
-// One launch of the megakernel on `nblocks` 16x16 tiles: picks the instantiation (small / SDF / large,
-// regenerating or nested) from the scene.  `small_scene_dev`: the same small scene in device memory (only the compacting SDF
-// kernel, rp.sdf_resumable_march == 3, reads it; without it that mode falls back to the march kernel).
-// `media`: the scene has participating media — the same forms instantiated for WithMedia<Scene> (dev_scene.h).
-hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr,
-                  bool media = false);
-// Large scenes with a grid, wavefront form (dev_wavefront.h): `spp` samples of every pixel of the tile; the buffers hold
-// rp.rows_local * rp.width slots.  Needs at most 1 + 2 * (spp * max_depth + 1) launches; launches after the last useful
-// iteration return at once, and the host never has more than 256 iterations enqueued without having looked at the device's
-// "anything left?" flag (it waits for the stream there: a bound of up to 256 iterations is enqueued blind).
-hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st,
-                            bool media = false);
-// Cost-ordered dispatch (kernels.hip, block_tile): `cost` holds 4 dwords per tile, `order` one; init = bottom rows first and no
+// One launch on `nblocks` workgroups (16x16 tiles x chunks of samples).  `media`: the scene has participating media — the same forms
+// instantiated for WithMedia<Scene> (dev_scene.h).  `nested`: the nested-loop baseline (small scenes without media only).
+hipError_t render_small(const rptdev::SceneSmall& sc, bool media, bool nested, const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const KernelChoice& kc);
+hipError_t render_compact(const rptdev::SceneSmall& sc, bool media, const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const KernelChoice& kc);
+hipError_t render_sdf(const rptdev::SceneSmallSdf& scs, bool media, const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const KernelChoice& kc);
+hipError_t render_large(const rptdev::SceneLarge& scl, bool media, const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st);
+
+// Cost-ordered dispatch (kernel_common.h, block_tile): `cost` holds 4 dwords per tile, `order` one; init = bottom rows first and no
 // costs; order = the tiles sorted by the costs the last launch left, most expensive first.
 hipError_t sched_init(uint32_t* cost, uint32_t* order, uint32_t n_tiles, hipStream_t st);
 hipError_t sched_order(const uint32_t* cost, uint32_t* order, uint32_t n_tiles, hipStream_t st);
@@ -39,24 +43,21 @@ hipError_t convert_to_u8_at(const float* pixels, uint32_t bw, uint32_t bh, uint8
 // the denoiser (denoise.hip): `iterations` a-trous passes in -> out through `scratch` (each width * height * 4 f32)
 hipError_t denoise(const float* in, float* out, float* scratch, uint32_t width, uint32_t height, uint32_t iterations, float edge_k,
                    hipStream_t st);
+// test build only (k_probes.hip, include/rpt_test.h)
 hipError_t probe_math(uint32_t fn, const float* a, const float* b, float* out, uint64_t n, hipStream_t st);
 hipError_t probe_fn(uint32_t fn, const rptdev::DevCamera& cam, const float* in, float* out, uint64_t n, hipStream_t st);
 hipError_t probe_rays(const rptdev::SceneLarge& sc, const float* rays, uint32_t* out, uint64_t n, hipStream_t st);
+// development only (-DRPT_PROFILE_BLOCKS, dev_prof.h): copy out and clear the block counters of one class's object
+hipError_t prof_read_small(unsigned long long* out);
+hipError_t prof_read_sdf(unsigned long long* out);
+hipError_t prof_read_large(unsigned long long* out);
 
 }  // namespace rptlaunch
 
-// the relaxed-arithmetic build of the same kernels (kernels.hip under -DRPT_RELAXED_BUILD)
+// the relaxed-arithmetic build of the same four translation units (-DRPT_RELAXED_BUILD): what RPT_RENDER_FAST_MATH selects
 namespace rptlaunch_fast {
-hipError_t render_wavefront(const rptdev::SceneLarge& sc, const rptdev::RenderParams& rp, const rptdev::WfBuffers& wb, hipStream_t st,
-                            bool media = false);
-hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr,
-                  bool media = false);
+hipError_t render_small(const rptdev::SceneSmall& sc, bool media, bool nested, const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const KernelChoice& kc);
+hipError_t render_compact(const rptdev::SceneSmall& sc, bool media, const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const KernelChoice& kc);
+hipError_t render_sdf(const rptdev::SceneSmallSdf& scs, bool media, const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const KernelChoice& kc);
+hipError_t render_large(const rptdev::SceneLarge& scl, bool media, const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st);
 }  // namespace rptlaunch_fast
-
-// large scenes' and SDF scenes' kernels of the shipped library (kernels.hip under -DRPT_PEROP_BUILD); rptlaunch::render forwards to it
-namespace rptlaunch_perop {
-hipError_t render(const rptdev::SceneSmallSdf& small_scene, const rptdev::SceneLarge& large_scene, bool large, bool nested,
-                  const rptdev::RenderParams& rp, uint32_t nblocks, hipStream_t st, const rptdev::SceneSmallSdf* small_scene_dev = nullptr,
-                  bool media = false);
-}  // namespace rptlaunch_perop

@@ -46,7 +46,7 @@ pub struct RptSceneDesc {
 }
 #[repr(C)] #[derive(Clone, Copy)] pub struct RptUniqueId { pub bytes: [c_char; 128] }
 
-pub const RPT_ABI_VERSION: u32 = 3;
+pub const RPT_ABI_VERSION: u32 = 4;
 // Constants of include/rpt.h (tests/test_rust_binding.py compares every one of them with the header).
 pub const RPT_OK: i32 = 0;
 pub const RPT_ERR_INVALID_ARG: i32 = -1;
@@ -72,15 +72,9 @@ pub const RPT_SCENE_MEDIA: u32 = 4;
 pub const RPT_RENDER_DEFAULT: u32 = 0;
 pub const RPT_RENDER_NESTED_LOOPS: u32 = 1;
 pub const RPT_RENDER_FAST_MATH: u32 = 2;
-pub const RPT_RENDER_SDF_INLINE_MARCH: u32 = 4;
-pub const RPT_RENDER_GRID_RESUMABLE_WALK: u32 = 8;
-pub const RPT_RENDER_SDF_POOL_MARCH: u32 = 0x10;
 pub const RPT_RENDER_RUSSIAN_ROULETTE: u32 = 0x20;
-pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x40;
-pub const RPT_RENDER_LARGE_MEGAKERNEL: u32 = 0x80;
 pub const RPT_RENDER_SMALL_COMPACT: u32 = 0x100;
-pub const RPT_RENDER_SDF_COMPACT: u32 = 0x200;
-pub const RPT_RENDER_SDF_THREE_ROOM_MARCH: u32 = 0x400;
+pub const RPT_RENDER_ALL_FLAGS: u32 = 0x123;
 
 impl RptSceneDesc {
     /// All zeros (no primitives, no SDF object): the starting point of every `describe()`.

@@ -25,6 +25,10 @@ def load_package():
     return mod
 
 
+# The tests run on the TEST BUILD: the product's own objects linked with the hooks of include/rpt_test.h (probes, dispatch
+# read-outs, the knob reload).  tests/test_shipped_library.py checks the product library itself: its exports, and that it renders
+# the same frames.  RPT_LIB overrides (experiment builds).
+os.environ.setdefault("RPT_LIB", os.path.join(PKG_DIR, "librpt_hip_test.so"))
 load_package()
 
 
@@ -63,24 +67,15 @@ def rpt():
     return load_package()
 
 
-def ab_built():
-    """Does the library under test hold the kernel forms kept for A/B runs (include/rpt.h, rpt_build_has_ab_kernels)?  The shipped
-    library does not; `python rust-pathtracer_amd/build.py --ab` + RPT_LIB=rust-pathtracer_amd/librpt_hip_ab.so runs the tests on one that does."""
-    return bool(load_package().lib().rpt_build_has_ab_kernels())
-
-
-def only_in_ab_builds(*items):
-    """`items` when the library holds the A/B kernel forms, nothing otherwise: for loops over kernel forms."""
-    return tuple(items) if ab_built() else ()
-
-
-@pytest.hookimpl(hookwrapper=True)
-def pytest_runtest_call(item):
-    """A test that asks the shipped library for an A/B-only kernel form is skipped from there on (what it checked before stands)."""
-    outcome = yield
-    exc = outcome.excinfo
-    if exc and exc[0].__name__ == "RptError" and "-DRPT_AB_KERNELS" in str(exc[1]):
-        outcome.force_exception(pytest.skip.Exception("needs a library with the A/B kernel forms (build.py --ab): %s" % exc[1]))
+@pytest.fixture(autouse=True)
+def _knobs_follow_the_environment():
+    """The library reads its environment knobs ONCE per process (csrc/knobs.h).  Tests that change one call the test build's
+    rpt_debug_reload_knobs themselves; behind every test the knobs are read again, so that a change undone by monkeypatch (or a
+    `finally`) does not leak into the next test."""
+    yield
+    pkg = load_package()
+    if pkg._lib._lib is not None and pkg._lib._lib.rpt_build_has_test_hooks():
+        pkg._lib._lib.rpt_debug_reload_knobs()
 
 
 def has_gpu():

@@ -8,20 +8,31 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "rpt.h")).read()
+def _declared_functions(header="rpt.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(rpt_[a-z0-9_]+)\s*\(", src)))
 
 
-def test_library_exports_every_declared_symbol(rpt):
+def _exported(lib_name):
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "rust-pathtracer_amd", lib_name)], check=True, capture_output=True, text=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if " T " in line)
+
+
+def test_library_exports_every_declared_symbol_and_nothing_else(rpt):
+    """The product library's dynamic symbol table is EXACTLY include/rpt.h (it is built with -fvisibility=hidden): no test hook, no
+    launch wrapper, no device stub.  The test build adds exactly include/rpt_test.h."""
     names = _declared_functions()
-    assert len(names) >= 14
-    lib = C.CDLL(os.path.join(ROOT, "rust-pathtracer_amd", "librpt_hip.so"))
-    for n in names:
-        assert hasattr(lib, n), "librpt_hip.so does not export %s" % n
+    hooks = _declared_functions("rpt_test.h")
+    assert len(names) >= 14 and len(hooks) >= 5 and not set(names) & set(hooks)
+    assert _exported("librpt_hip.so") == names
+    assert _exported("librpt_hip_test.so") == sorted(names + hooks)
     assert sorted(rpt._abi.SYMBOLS) == names, "ctypes mirror and header disagree"
+    assert sorted(rpt._abi.TEST_SYMBOLS) == hooks, "ctypes mirror and test header disagree"
     assert rpt.lib().rpt_abi_version() == rpt._abi.RPT_ABI_VERSION
+    product = C.CDLL(os.path.join(ROOT, "rust-pathtracer_amd", "librpt_hip.so"))
+    product.rpt_build_has_test_hooks.restype = C.c_uint32
+    assert product.rpt_build_has_test_hooks() == 0 and rpt.lib().rpt_build_has_test_hooks() == 1
 
 
 def test_struct_layout_matches_c(rpt, tmp_path):
@@ -114,7 +125,7 @@ def test_multi_gpu_entry_points_validate_without_gpu(rpt):
     assert lib.rpt_set_tile_rows(None, 2) == A.RPT_ERR_INVALID_ARG
     assert lib.rpt_set_dispatch(None, 1, 12, 64, 0) == A.RPT_ERR_INVALID_ARG
     assert lib.rpt_host_pin(None, 16) == A.RPT_ERR_INVALID_ARG and lib.rpt_host_unpin(None) == A.RPT_ERR_INVALID_ARG
-    assert lib.rpt_build_has_ab_kernels() in (0, 1)
+    assert lib.rpt_build_has_test_hooks() in (0, 1)
     assert lib.rpt_debug_sched_read(None, None, 0, None) == A.RPT_ERR_INVALID_ARG
     assert lib.rpt_world(None, None, None, None) == A.RPT_ERR_INVALID_ARG
     assert lib.rpt_resident_gather_device(None, None) == A.RPT_ERR_INVALID_ARG

@@ -75,10 +75,8 @@ def test_more_samples_than_the_kernel_tables_hold_is_one_launch(rpt, oracle, tor
 def test_every_kernel_family_takes_chunks(rpt, oracle, torch_cuda):
     from rust_pathtracer_amd import scenes
     A = rpt._abi
-    cases = [("sdf two rooms", scenes.sdf_scene(), 0), ("300 spheres", scenes.random_spheres_scene(300, 5), A.RPT_RENDER_LARGE_MEGAKERNEL),
+    cases = [("sdf two rooms", scenes.sdf_scene(), 0), ("300 spheres", scenes.random_spheres_scene(300, 5), 0),
              ("media", scenes.media_scene(), 0), ("roulette", rpt.AnalyticalScene(), A.RPT_RENDER_RUSSIAN_ROULETTE)]
-    cases += conftest.only_in_ab_builds(("sdf three rooms", scenes.sdf_scene(), A.RPT_RENDER_SDF_THREE_ROOM_MARCH),
-                                        ("sdf inline march", scenes.sdf_scene(), A.RPT_RENDER_SDF_INLINE_MARCH))
     w, h, spp = 112, 80, 6
     for name, scene, flags in cases:
         oflags = flags & A.RPT_RENDER_RUSSIAN_ROULETTE

@@ -115,7 +115,7 @@ def test_context_scratch_is_ordered_across_streams(rpt, oracle):
     streams = [torch.cuda.Stream() for _ in range(2)]
     # the megakernel's dispatch tables (tile costs, order, hand-off words: rpt_set_dispatch) and, in A/B builds, the wavefront form's
     # path buffers
-    for form, flags in (("megakernel in one-sample chunks", 0),) + conftest.only_in_ab_builds(("wavefront", rpt._abi.RPT_RENDER_LARGE_WAVEFRONT)):
+    for form, flags in (("megakernel in one-sample chunks", 0),):
         t.flags = flags
         t.set_dispatch(1, 1000, 1, 4)
         bufs = [rpt.DeviceColorBuffer(w, h) for _ in range(4)]

@@ -74,7 +74,7 @@ def test_random_small_scenes_with_media_match_oracle(rpt, oracle, seed):
     w, h, spp = int(rng.integers(8, 70)), int(rng.integers(8, 50)), int(rng.integers(1, 4))
     rr = A.RPT_RENDER_RUSSIAN_ROULETTE if seed % 4 == 3 else 0
     t = rpt.Tracer(s, device=0, seed=seed)
-    t.flags = (A.RPT_RENDER_NESTED_LOOPS if conftest.ab_built() else 0, 0, A.RPT_RENDER_SMALL_COMPACT)[seed % 3] | rr
+    t.flags = (0, 0, A.RPT_RENDER_SMALL_COMPACT)[seed % 3] | rr
     buf = rpt.ColorBuffer(w, h)
     t.render_n(buf, spp)
     want = oracle.render(s.describe(), w, h, spp, seed=seed, render_flags=rr)
@@ -95,9 +95,7 @@ def test_sdf_object_full_of_fog_matches_oracle_in_every_sdf_form(rpt, oracle):
     s.materials[1] = rpt.Material(rgb=(1.0, 0.6, 0.3), roughness=0.1, spec_trans=1.0, ior=1.4, medium=dict(type="absorb", density=2.0, color=(1.0, 0.4, 0.1)))
     w, h, spp = 80, 60, 3
     want = oracle.render(s.describe(), w, h, spp, seed=4)
-    for name, flags in (("march kernel (two rooms)", 0),) + conftest.only_in_ab_builds(
-            ("march kernel (three rooms)", A.RPT_RENDER_SDF_THREE_ROOM_MARCH), ("inline march", A.RPT_RENDER_SDF_INLINE_MARCH),
-            ("nested loops", A.RPT_RENDER_NESTED_LOOPS)):
+    for name, flags in (("march kernel (two rooms)", 0),):
         t = rpt.Tracer(s, device=0, seed=4)
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
@@ -106,7 +104,7 @@ def test_sdf_object_full_of_fog_matches_oracle_in_every_sdf_form(rpt, oracle):
         t.close()
 
 
-@pytest.mark.parametrize("form", ["megakernel", "wavefront", "nested"])
+@pytest.mark.parametrize("form", ["megakernel"])
 @pytest.mark.parametrize("n_spheres,rr", [(300, False), (700, True)])
 def test_large_scene_with_media_matches_oracle(rpt, oracle, form, n_spheres, rr):
     from rust_pathtracer_amd import scenes
@@ -116,7 +114,7 @@ def test_large_scene_with_media_matches_oracle(rpt, oracle, form, n_spheres, rr)
     rflag = A.RPT_RENDER_RUSSIAN_ROULETTE if rr else 0
     w, h, spp = 72, 40, 2
     t = rpt.Tracer(s, device=0, seed=6)
-    t.flags = {"megakernel": A.RPT_RENDER_LARGE_MEGAKERNEL, "wavefront": A.RPT_RENDER_LARGE_WAVEFRONT, "nested": A.RPT_RENDER_NESTED_LOOPS}[form] | rflag
+    t.flags = rflag
     buf = rpt.ColorBuffer(w, h)
     t.render_n(buf, spp)
     t.render_n(buf, 1)

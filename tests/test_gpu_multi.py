@@ -177,12 +177,6 @@ def test_multi_context_large_scene_and_progressive_gathers(rpt, oracle, torch_cu
     assert_bit_identical(t.resident_to_host(w, h).image(), oracle.render(desc, w, h, 1, seed=3), "large scene, step 1")
     t.render_resident(w, h, 2)
     assert_bit_identical(t.resident_to_host(w, h).image(), oracle.render(desc, w, h, 3, seed=3), "large scene, step 2")
-    # the wavefront form on every rank's tile (each device keeps its own path buffers; the tiles are ragged: 64-pixel rows
-    # in 2-row blocks dealt to 3 ranks)
-    if conftest.ab_built():
-        t.flags = rpt._abi.RPT_RENDER_LARGE_WAVEFRONT
-        t.render_resident(w, h, 2)
-        assert_bit_identical(t.resident_to_host(w, h).image(), oracle.render(desc, w, h, 5, seed=3), "large scene, step 3 (wavefront)")
     t.close()
 
 

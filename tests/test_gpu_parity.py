@@ -335,9 +335,8 @@ def test_large_scene_matches_oracle(rpt, oracle, n_spheres, n_lights):
     s = scenes.random_spheres_scene(n_spheres=n_spheres, n_lights=n_lights, seed=0x5EED0005)
     w, h, spp = 96, 54, 3
     t = rpt.Tracer(s, device=0, seed=5)
-    # the default form (at this size: the grid walk inside the megakernel, from 64 spheres up); nested loops; then both forms
-    # forced: the wavefront (walks in their own kernel) and the megakernel (scenes without a grid ignore the two flags)
-    for flags in (0, rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL) + conftest.only_in_ab_builds(rpt._abi.RPT_RENDER_NESTED_LOOPS, rpt._abi.RPT_RENDER_LARGE_WAVEFRONT):
+    # (from 64 spheres up: the grid walk inside the megakernel; below: its brute-force loops)
+    for flags in (0,):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -355,13 +354,14 @@ def test_large_scene_both_tiers_of_cell_lists(rpt, oracle, cam, look, reach, mon
     bounce).  All bit-identical to the oracle's ordered loop over every sphere, in both forms."""
     from rust_pathtracer_amd import scenes
     if reach is not None:
-        monkeypatch.setenv("RPT_GRID_NEAR_REACH", reach)              # read when the scene is uploaded
+        monkeypatch.setenv("RPT_GRID_NEAR_REACH", reach)              # (the library reads its knobs once per process:
+        rpt.lib().rpt_debug_reload_knobs()                            #  the test build's hook reads them again)
     s = scenes.random_spheres_scene(n_spheres=1200, n_lights=9, seed=0x5EED0011)
     s.camera = rpt.Pinhole(cam, look, 40.0)
     w, h, spp = 112, 63, 3
     t = rpt.Tracer(s, device=0, seed=7)
     want = oracle.render(s.describe(), w, h, spp, seed=7)
-    for flags in (rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL,) + conftest.only_in_ab_builds(rpt._abi.RPT_RENDER_LARGE_WAVEFRONT):
+    for flags in (0,):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -370,24 +370,20 @@ def test_large_scene_both_tiers_of_cell_lists(rpt, oracle, cam, look, reach, mon
 
 
 @pytest.mark.parametrize("w,h,spp,depth,rr", [(70, 37, 5, 4, False), (33, 65, 3, 9, True), (200, 120, 2, 1, False), (64, 64, 40, 30, True)])
-def test_large_scene_wavefront_form_matches_oracle(rpt, oracle, w, h, spp, depth, rr):
-    """The wavefront form of large scenes (include/rpt.h RPT_RENDER_LARGE_WAVEFRONT) over ragged tiles (sizes that are not
-    multiples of the 64-slot segments), depth 1, deep paths with Russian roulette (the launch bound gets long enough for the
-    early-out read-back), and a resumed accumulation: bit-identical to the oracle."""
+def test_large_scene_ragged_tiles_deep_paths_and_resume(rpt, oracle, w, h, spp, depth, rr):
+    """Large scenes over ragged tiles (sizes that are not multiples of the 16x16 tile), depth 1, deep paths with Russian roulette,
+    and a resumed accumulation: bit-identical to the oracle."""
     from rust_pathtracer_amd import scenes
     s = scenes.random_spheres_scene(n_spheres=400, n_lights=5, seed=0x5EED0007)
     s.max_depth = depth
     rflags = rpt._abi.RPT_RENDER_RUSSIAN_ROULETTE if rr else 0
     t = rpt.Tracer(s, device=0, seed=9)
-    t.flags = rpt._abi.RPT_RENDER_LARGE_WAVEFRONT | rflags
+    t.flags = rflags
     buf = rpt.ColorBuffer(w, h)
     t.render_n(buf, spp)
     t.render_n(buf, 2)                                                # resumes at frames_done = spp
     want = oracle.render(s.describe(), w, h, spp + 2, seed=9, render_flags=rflags)
-    assert_bit_identical(buf.image(), want, "wavefront %dx%d spp %d depth %d" % (w, h, spp, depth))
-    t.flags |= rpt._abi.RPT_RENDER_LARGE_MEGAKERNEL
-    with pytest.raises(rpt.RptError):
-        t.render_n(rpt.ColorBuffer(w, h), 1)
+    assert_bit_identical(buf.image(), want, "large scene %dx%d spp %d depth %d" % (w, h, spp, depth))
     t.close()
 
 
@@ -414,7 +410,7 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
         s.any_hit_uses_max_dist = use_max
         t = rpt.Tracer(s, device=0, seed=9)
         want = oracle.render(s.describe(), w, h, spp, seed=9)
-        for flags in (0,) + conftest.only_in_ab_builds(rpt._abi.RPT_RENDER_SDF_THREE_ROOM_MARCH, rpt._abi.RPT_RENDER_SDF_INLINE_MARCH, rpt._abi.RPT_RENDER_NESTED_LOOPS):
+        for flags in (0,):
             t.flags = flags
             buf = rpt.ColorBuffer(w, h)
             t.render_n(buf, spp)
@@ -672,7 +668,7 @@ def test_random_large_scenes_match_oracle_in_both_forms(rpt, oracle, seed):
     rflags = A.RPT_RENDER_RUSSIAN_ROULETTE if seed % 3 == 0 else 0
     want = oracle.render(s.describe(), w, h, spp, seed=seed, render_flags=rflags)
     t = rpt.Tracer(s, device=0, seed=seed)
-    for form in (A.RPT_RENDER_LARGE_MEGAKERNEL,) + conftest.only_in_ab_builds(A.RPT_RENDER_LARGE_WAVEFRONT):
+    for form in (0,):
         t.flags = form | rflags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -706,7 +702,7 @@ def test_random_sdf_scenes_match_oracle(rpt, oracle, seed):
     w, h, spp = int(rng.integers(8, 90)), int(rng.integers(8, 60)), int(rng.integers(1, 4))
     want = oracle.render(s.describe(), w, h, spp, seed=seed)
     t = rpt.Tracer(s, device=0, seed=seed)
-    for flags in (0,) + conftest.only_in_ab_builds(A.RPT_RENDER_SDF_THREE_ROOM_MARCH, A.RPT_RENDER_SDF_INLINE_MARCH, A.RPT_RENDER_NESTED_LOOPS):
+    for flags in (0,):
         t.flags = flags
         buf = rpt.ColorBuffer(w, h)
         t.render_n(buf, spp)
@@ -749,6 +745,7 @@ def test_full_size_config5_frame(rpt, torch_cuda, oracle):
     for r, want in _oracle_rows(oracle, s.describe(), w, h, spp, (1800, 3000)).items():
         assert_bit_identical(img[r], want, "c5 row %d" % r)
     os.environ["RPT_NO_GRID"] = "1"
+    rpt.lib().rpt_debug_reload_knobs()                     # (knobs are read once per process: the test build's hook reads them again)
     try:
         t.upload_scene()                                   # re-upload without the grid
         brute = rpt.DeviceColorBuffer(w, h)
@@ -791,42 +788,22 @@ def test_full_config5_all_512_spp_pixels_match_oracle(rpt, torch_cuda, oracle):
     t.close()
 
 
-def test_wavefront_long_launch_equals_megakernel(rpt, torch_cuda):
-    """A launch long enough for the wavefront form's host early-out (more than 512 iterations: 150 spp x depth 4) and a short one,
-    on a large tile, and the default form: whole frames bit-identical to the megakernel's (which the oracle tests pin)."""
-    from rust_pathtracer_amd import scenes
-    torch = torch_cuda
-    A = rpt._abi
-    s = scenes.random_spheres_scene(3000, 8)
-    w, h = 1600, 1000
-    t = rpt.Tracer(s, device=0, seed=6)
-    frames = {}
-    for name, flags, steps in (("mega", A.RPT_RENDER_LARGE_MEGAKERNEL, (150, 8)), ("wave", A.RPT_RENDER_LARGE_WAVEFRONT, (150, 8)), ("default", 0, (150, 8))):
-        t.flags = flags
-        buf = rpt.DeviceColorBuffer(w, h)
-        for spp in steps:
-            t.render_n(buf, spp)
-        torch.cuda.synchronize()
-        frames[name] = buf.pixels.view(torch.int32).clone()
-    assert torch.equal(frames["mega"], frames["wave"])
-    assert torch.equal(frames["mega"], frames["default"])
-    t.close()
-
-
-def test_ab_kernels_are_not_in_the_shipped_library(rpt, torch_cuda):
-    """The measured-slower kernel forms (csrc/ab/) are only built with -DRPT_AB_KERNELS: the shipped library refuses
-    their flags loudly instead of silently running something else."""
+def test_reserved_flag_bits_are_refused(rpt, torch_cuda):
+    """Until ABI 3 seven more render flags named measured-slower kernel forms kept for A/B runs; the forms are gone and their bits
+    are reserved: the library answers them with RPT_ERR_INVALID_ARG instead of silently running something else."""
     from rust_pathtracer_amd import scenes
     t = rpt.Tracer(scenes.sdf_scene(), device=0, seed=1)
     buf = rpt.DeviceColorBuffer(16, 16)
-    for flag in (rpt._abi.RPT_RENDER_SDF_POOL_MARCH, rpt._abi.RPT_RENDER_SDF_COMPACT, rpt._abi.RPT_RENDER_GRID_RESUMABLE_WALK):
-        t.flags = flag
-        try:
+    for bit in (2, 3, 4, 6, 7, 9, 10, 11, 31):
+        t.flags = 1 << bit
+        with pytest.raises(rpt.RptError) as e:
             t.render_n(buf, 1)
-        except rpt.RptError as e:
-            assert e.status == rpt._abi.RPT_ERR_UNSUPPORTED
-        else:
-            pytest.skip("this library was built with -DRPT_AB_KERNELS")
+        assert e.value.status == rpt._abi.RPT_ERR_INVALID_ARG
+    # the nested-loop baseline exists for the reference's scene class only
+    t.flags = rpt._abi.RPT_RENDER_NESTED_LOOPS
+    with pytest.raises(rpt.RptError) as e:
+        t.render_n(buf, 1)
+    assert e.value.status == rpt._abi.RPT_ERR_UNSUPPORTED
     t.close()
 
 
@@ -926,8 +903,7 @@ def test_fast_math_mode_in_the_other_kernels(rpt, torch_cuda):
     from rust_pathtracer_amd import scenes
     A = rpt._abi
     cases = [("compact", rpt.AnalyticalScene(), A.RPT_RENDER_SMALL_COMPACT, 256, 144, 32),
-             ("large scene", scenes.random_spheres_scene(n_spheres=400, n_lights=6), A.RPT_RENDER_LARGE_MEGAKERNEL, 192, 108, 24)]
-    cases += conftest.only_in_ab_builds(("wavefront", scenes.random_spheres_scene(n_spheres=400, n_lights=6), A.RPT_RENDER_LARGE_WAVEFRONT, 192, 108, 24))
+             ("large scene", scenes.random_spheres_scene(n_spheres=400, n_lights=6), 0, 192, 108, 24)]
     for name, scene, form, w, h, spp in cases:
         t = rpt.Tracer(scene, device=0, seed=2)
         t.flags = form

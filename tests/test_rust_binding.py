@@ -280,6 +280,6 @@ def test_scene_desc_size_export_matches_c(rpt):
 
 def test_checker_catches_a_wrong_flag_value(tmp_path):
     src = open(RUST).read()
-    assert "pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x40;" in src
-    broken = src.replace("pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x40;", "pub const RPT_RENDER_LARGE_WAVEFRONT: u32 = 0x80;")
-    assert any("RPT_RENDER_LARGE_WAVEFRONT" in p for p in check_binding(broken, tmp_path))
+    assert "pub const RPT_RENDER_RUSSIAN_ROULETTE: u32 = 0x20;" in src
+    broken = src.replace("pub const RPT_RENDER_RUSSIAN_ROULETTE: u32 = 0x20;", "pub const RPT_RENDER_RUSSIAN_ROULETTE: u32 = 0x80;")
+    assert any("RPT_RENDER_RUSSIAN_ROULETTE" in p for p in check_binding(broken, tmp_path))

@@ -1,5 +1,5 @@
 """One-line timings for A/B runs of library variants (RPT_LIB) and knobs (RPT_* environment): which = c2 | c2s (32 spp) | c4 | c5 (2048^2 x 32,
-megakernel) | c5full (4096^2 x 512: configs[4] in one call) | c5w (2048^2 x 8, wavefront).   python tools/ab_time.py c2 [reps]"""
+megakernel) | c5full (4096^2 x 512: configs[4] in one call).   python tools/ab_time.py c2 [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 import conftest, torch
@@ -27,11 +27,10 @@ if which == "dn":                                   # the denoiser: 3 iterations
     sys.exit(0)
 A = rpt._abi
 cfg = {"c2": (rpt.AnalyticalScene, 1920, 1080, 256, 0), "c2s": (rpt.AnalyticalScene, 1920, 1080, 32, 0), "c4": (scenes.sdf_scene, 1920, 1080, 64, 0),
-       "c5": (lambda: scenes.random_spheres_scene(10000, 16), 2048, 2048, 32, A.RPT_RENDER_LARGE_MEGAKERNEL),
-       "c5l": (lambda: scenes.random_spheres_scene(10000, 16), 1024, 1024, 256, A.RPT_RENDER_LARGE_MEGAKERNEL),
-       "c5full": (lambda: scenes.random_spheres_scene(10000, 16), 4096, 4096, 512, A.RPT_RENDER_LARGE_MEGAKERNEL),   # BASELINE.json configs[4], one call
-       "c5x": (lambda: scenes.random_spheres_scene(10000, 16), 4096, 4096, 8, 0),
-       "c5w": (lambda: scenes.random_spheres_scene(10000, 16), 2048, 2048, 8, A.RPT_RENDER_LARGE_WAVEFRONT)}[which]
+       "c5": (lambda: scenes.random_spheres_scene(10000, 16), 2048, 2048, 32, 0),
+       "c5l": (lambda: scenes.random_spheres_scene(10000, 16), 1024, 1024, 256, 0),
+       "c5full": (lambda: scenes.random_spheres_scene(10000, 16), 4096, 4096, 512, 0),   # BASELINE.json configs[4], one call
+       "c5x": (lambda: scenes.random_spheres_scene(10000, 16), 4096, 4096, 8, 0)}[which]
 t = rpt.Tracer(cfg[0](), device=0, seed=1)
 t.flags = cfg[4]
 w, h, spp = cfg[1:4]

@@ -1,8 +1,6 @@
 """Per-block lane utilisation and time shares of the megakernel (csrc/dev_prof.h).
 
-  python tools/block_profile.py build      # here: cross-compile librpt_hip_prof.so (-DRPT_PROFILE_BLOCKS) and librpt_hip_prof_perop.so
-                                           # (the same with -DRPT_GUARD_PER_OP: one object, the range tests next to every operation —
-                                           # how the shipped large / SDF kernels are built; the counters live in one object only)
+  python tools/block_profile.py build      # here: cross-compile librpt_hip_prof.so (the product's translation units with -DRPT_PROFILE_BLOCKS)
   python tools/block_profile.py [spp] [c2|c4|c5]   # on the GPU box: render that config with it and print the table
 """
 import ctypes as C
@@ -15,18 +13,16 @@ PKG = os.path.join(ROOT, "rust-pathtracer_amd")
 PROF_LIB = os.path.join(PKG, "librpt_hip_prof.so")
 BLOCKS = ["TRACE", "  closest_hit", "  background", "  finalize", "  finish+camera", "SHADE", "  make_frame", "  nee_sample", "  any_hit",
           "  disney_eval", "  disney_sample", "    lobe diffuse", "    lobe clearcoat", "    lobe spec", "  tail", "PASS", "    grid begin", "    grid cell",
-          "WALK wave (wavefront)", "  fetch entries", "  ray set-up", "  cell iteration"]
+          "    grid cell (shadow)", "      list trip > 1", "      candidate root", "    walk head", "    lights"]
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     spec = importlib.util.spec_from_file_location("_rpt_build", os.path.join(PKG, "build.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     print(b.build(force=True, extra_flags=["-DRPT_PROFILE_BLOCKS"], lib=PROF_LIB, objdir_name="build_prof"))
-    print(b.build(force=True, extra_flags=["-DRPT_PROFILE_BLOCKS", "-DRPT_GUARD_PER_OP"], lib=PROF_LIB.replace(".so", "_perop.so"), objdir_name="build_prof_perop"))
     sys.exit(0)
 
-# small scenes' megakernel is profiled as shipped (range trackers); every other config in the one-object per-operation build
-os.environ["RPT_LIB"] = PROF_LIB if (len(sys.argv) <= 2 or sys.argv[2] == "c2") else PROF_LIB.replace(".so", "_perop.so")
+os.environ["RPT_LIB"] = PROF_LIB
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import conftest  # noqa: E402
 import torch  # noqa: E402
@@ -36,15 +32,9 @@ from rust_pathtracer_amd import scenes  # noqa: E402
 
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 which = sys.argv[2] if len(sys.argv) > 2 else "c2"
-w, h = (2048, 2048) if which in ("c5", "c5w") else (1920, 1080)
-scene = {"c5w": lambda: scenes.random_spheres_scene(10000, 16), "c2": rpt.AnalyticalScene, "c4": scenes.sdf_scene, "c4i": scenes.sdf_scene, "c4p": scenes.sdf_scene, "c5": lambda: scenes.random_spheres_scene(10000, 16)}[which]()
+w, h = (2048, 2048) if which == "c5" else (1920, 1080)
+scene = {"c2": rpt.AnalyticalScene, "c4": scenes.sdf_scene, "c5": lambda: scenes.random_spheres_scene(10000, 16)}[which]()
 t = rpt.Tracer(scene, device=0, seed=1)
-if which == "c5w":
-    t.flags = rpt._abi.RPT_RENDER_LARGE_WAVEFRONT          # walk kernel scopes: shares are of the WALK waves' time
-if which == "c4p":
-    t.flags = rpt._abi.RPT_RENDER_SDF_POOL_MARCH           # the workgroup march pool
-if which == "c4i":
-    t.flags = rpt._abi.RPT_RENDER_SDF_INLINE_MARCH         # c4: the march kernel (closest_hit row = one march step, TRACE = RESOLVE)
 buf = rpt.DeviceColorBuffer(w, h)
 lib = rpt.lib()
 lib.rpt_prof_read.restype = C.c_int
@@ -58,13 +48,10 @@ assert lib.rpt_prof_read(out) == 0
 n_samples = w * h * spp
 print("profiled build, %s: %dx%d x %d spp in %.2f ms (%.0f Msamples/s with the counters on)" % (which, w, h, spp, e0.elapsed_time(e1), n_samples / e0.elapsed_time(e1) / 1e3))
 pass_cycles = out[BLOCKS.index("PASS") * 3 + 2]
-if which == "c5w":
-    print("wavefront form: the WALK rows are shares of the walk kernel's wave time (the shading kernel carries no scopes of its own)")
-walk_cycles = out[BLOCKS.index("WALK wave (wavefront)") * 3 + 2]
 print("%-20s %12s %9s %8s %10s %12s" % ("block", "wave execs", "lanes/64", "share", "execs/smp", "lane-exec/smp"))
 for i, name in enumerate(BLOCKS):
     ex, ln, cy = out[i * 3], out[i * 3 + 1], out[i * 3 + 2]
     if ex == 0:
         continue
-    denom = walk_cycles if (i >= BLOCKS.index("WALK wave (wavefront)") and walk_cycles) else pass_cycles
+    denom = pass_cycles
     print("%-20s %12d %8.1f%% %7.1f%% %10.3f %12.3f" % (name, ex, 100.0 * ln / (64.0 * ex), 100.0 * cy / denom, 64.0 * ex / n_samples, ln / n_samples))

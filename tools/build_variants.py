@@ -86,12 +86,18 @@ VARIANTS = {
     "cg_clause4": ["-mllvm", "-amdgpu-max-memory-clause=4"],
     "cg_no_cluster": ["-mllvm", "-misched-cluster=0"],
     "cg_exec_pre_ra0": ["-mllvm", "-amdgpu-opt-exec-mask-pre-ra=0"],
+    # round 5
+    "dn_xcd": ["-DRPT_DENOISE_XCD"],                           # the denoiser's tiles dealt so that every XCD filters one band of the image (halos hit its L2)
+    "dn_xcd32": ["-DRPT_DENOISE_XCD", "-DRPT_DENOISE_TILE=32"],
     "cg_licm_on": [],        # (built with RPT_TUNING_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp": machine LICM back on)
 }
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(VARIANTS)
     for n in names:
+        if "=" in n:                                             # ad hoc: name=-DFLAG,-DOTHER=1
+            n, _, fl = n.partition("=")
+            VARIANTS[n] = [f for f in fl.split(",") if f]
         flags = VARIANTS[n] if n in VARIANTS else []
         lib = os.path.join(ROOT, "rust-pathtracer_amd", "variants", n + ".so")
         try:
