@@ -22,7 +22,7 @@ def test_probe_exp_log(rpt, torch_cuda, tracer, oracle):
     assert_bit_identical(_probe(rpt, torch_cuda, tracer, rpt._abi.RPT_PROBE_LOG, b), oracle.math(8, b), "log")
 
 
-FORMS = [("megakernel", 0, 5), ("nested loops", "RPT_RENDER_NESTED_LOOPS", 3), ("compacting (default at 1 spp)", 0, 1),
+FORMS = [("megakernel", 0, 5), ("compacting (default at 1 spp)", 0, 1),
          ("compacting, forced", "RPT_RENDER_SMALL_COMPACT", 4)]
 
 
