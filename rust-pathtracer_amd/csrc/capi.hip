@@ -894,7 +894,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
             std::string why;
             if (!build_accel(s->spheres, s->n_spheres, accel, why)) { set_err(ctx, "rpt_upload_scene: %s", why.c_str()); return RPT_ERR_UNSUPPORTED; }
         }
-        // The spherical lights once more as {centre, radius} records with their indices, padded to whole groups of four: what
+        // The spherical lights once more as {centre, radius * radius} records with their indices, padded to whole groups of four: what
         // Scene::sample_lights' loop streams (dev_scene_large.h, closest_geom_finish).  Only when every light that DOES something
         // in sample_lights is spherical: always, unless the scene samples the other light types and has a rectangular one.
         bool lights_fast = true;
@@ -902,7 +902,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         std::vector<uint32_t> lids;
         for (uint32_t i = 0; i < s->n_lights; ++i) {
             const rpt_light& l = s->lights[i];
-            if (l.type == RPT_LIGHT_SPHERICAL) { lsph.insert(lsph.end(), {l.position[0], l.position[1], l.position[2], l.radius}); lids.push_back(i); }
+            if (l.type == RPT_LIGHT_SPHERICAL) { lsph.insert(lsph.end(), {l.position[0], l.position[1], l.position[2], l.radius * l.radius}); lids.push_back(i); }
             else if (l.type == RPT_LIGHT_RECTANGULAR && (s->flags & RPT_SCENE_SAMPLE_ALL_LIGHT_TYPES)) lights_fast = false;
         }
         const uint32_t n_light_spheres = (uint32_t)lids.size();

@@ -160,7 +160,7 @@ struct SceneLarge {
     uint32_t near_cell_off;           // shorter), cell_start[near_cell_off + c]; near_r2 < 0: there is none
     const uint32_t* cell_start;
     const uint32_t* cell_items;
-    const float4* cell_spheres;       // spheres[cell_items[k]] stored at k: a cell's spheres are one dependent load away, not two
+    const float4* cell_spheres;       // {centre, r * r} of spheres[cell_items[k]] stored at k: a cell's spheres are one dependent load away, not two
     uint32_t n_oversize;              // spheres kept out of the grid (far larger than the rest: host_scene.h), tested by every walk
     const uint32_t* oversize;
     // Scene::sample_lights' loop (closest_geom_finish): the spherical lights as {centre, radius} in index order, in whole groups of

@@ -347,7 +347,7 @@ RPT_DEV bool closest_walk_cell(const SceneLarge& sc, const RayD& ray, ClosestWal
             const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
             const float tca = dot3(l, ray.d);
             const float d2 = dot3(l, l) - tca * tca;
-            const float radius2 = sp[j].w * sp[j].w;
+            const float radius2 = sp[j].w;                      // (the list-ordered copy holds r * r: host_grid.h)
             if ((k + j < k1) && !(d2 > radius2)) {
                 if (c_k == 0xFFFFFFFFu) { c_tca = tca; c_rd = radius2 - d2; c_k = k + j; }
                 else resolve(tca, radius2 - d2, k + j);
@@ -437,7 +437,7 @@ RPT_DEV bool grid_any_sphere(const SceneLarge& sc, const RayD& ray, bool use_max
                 const v3 l = mk3(sp[j].x, sp[j].y, sp[j].z) - ray.o;
                 const float tca = dot3(l, ray.d);
                 const float d2 = dot3(l, l) - tca * tca;
-                const float radius2 = sp[j].w * sp[j].w;
+                const float radius2 = sp[j].w;                      // (the list-ordered copy holds r * r: host_grid.h)
                 cand[j] = (k + j < k1) && !(d2 > radius2);
                 any_cand = any_cand || cand[j];
                 c_tca[j] = tca;
@@ -514,7 +514,7 @@ RPT_DEV bool closest_geom_finish(const SceneLarge& sc, const RayD& ray, PathStat
             const v3 l = mk3(rec[4u * j], rec[4u * j + 1u], rec[4u * j + 2u]) - ray.o;
             const float tca = dot3(l, ray.d);
             const float d2 = dot3(l, l) - tca * tca;
-            const float radius2 = rec[4u * j + 3u] * rec[4u * j + 3u];
+            const float radius2 = rec[4u * j + 3u];              // ({centre, r * r}: capi.hip, rpt_upload_scene)
             cand[j] = (i + j < sc.n_light_spheres) && !(d2 > radius2);
             any_cand = any_cand || cand[j];
             c_tca[j] = tca;

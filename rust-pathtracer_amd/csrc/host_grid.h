@@ -181,7 +181,7 @@ constexpr size_t kSpareListEntries = 8;
 
 struct HostAccelData {
     HostGrid grid;
-    std::vector<float> cell_spheres;          // {cx, cy, cz, r} of items[k] at k: a cell's spheres are one load away from its bounds
+    std::vector<float> cell_spheres;          // {cx, cy, cz, r * r} of items[k] at k: a cell's spheres are one load away from its bounds
     size_t sz_cstart = 0, sz_items = 0, sz_cell_sph = 0, sz_oversize = 0;
 
     size_t bytes() const { return sz_cstart + sz_items + sz_cell_sph + sz_oversize; }
@@ -205,7 +205,7 @@ inline bool build_accel(const rpt_sphere* sph, uint32_t count, HostAccelData& a,
     for (size_t k = 0; k < a.grid.items.size(); ++k) {
         const rpt_sphere& s = sph[a.grid.items[k]];
         a.cell_spheres[4 * k + 0] = s.center[0]; a.cell_spheres[4 * k + 1] = s.center[1];
-        a.cell_spheres[4 * k + 2] = s.center[2]; a.cell_spheres[4 * k + 3] = s.radius;
+        a.cell_spheres[4 * k + 2] = s.center[2]; a.cell_spheres[4 * k + 3] = s.radius * s.radius;   // (f32: the test's own radius2, analytical.rs:173)
     }
     a.sz_cstart = (sizeof(uint32_t) * a.grid.cell_start.size() + 15) & ~(size_t)15;
     a.sz_items = (sizeof(uint32_t) * a.grid.items.size() + 15) & ~(size_t)15;

@@ -53,7 +53,7 @@ static void check_accel(const std::vector<rpt_sphere>& sph, const rpthost::HostA
                 CHECK(i < sph.size() && !oversize[i], "%s: item %u", what, i);
                 CHECK(k == k0 || g.items[k - 1] < i, "%s: cell lists ascend", what);
                 seen[i] = 1;
-                CHECK(a.cell_spheres[4 * k + 3] == sph[i].radius && a.cell_spheres[4 * k] == sph[i].center[0], "%s: cell_spheres[%u]", what, k);
+                CHECK(a.cell_spheres[4 * k + 3] == sph[i].radius * sph[i].radius && a.cell_spheres[4 * k] == sph[i].center[0], "%s: cell_spheres[%u]", what, k);
                 // the sphere's own centre cell must list it when the centre is inside the grid
             }
         }
