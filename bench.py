@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector
-GPU_CLOCK_HZ = 2.4e9           # the same table's engine clock (the PMC passes measured 2.37e9 under this kernel)
+GPU_CLOCK_HZ = 2.4e9           # the same table's engine clock: what FP32_PEAK_TFLOPS is quoted at (the kernels run at 2.1-2.4 GHz: traffic.json, shader_cycles_per_launch)
 C2 = (1920, 1080, 256)         # BASELINE.json configs[1]
 C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
 # Rows per block of the cyclic row tiling for N > 1.  One rank's share of configs[2] on one GPU (tools/tile_rows_time.py, 8 virtual ranks,
@@ -41,8 +41,7 @@ C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
 # ranks still balance.
 TILE_ROWS = 8
 SECONDARY_LIMIT_S = int(os.environ.get("RPT_BENCH_SECONDARY_LIMIT_S", "150"))        # N > 1: the legs after the headline (weak scaling, the one-GPU frame, configs[4]) may take this long together
-PROFILES = os.path.join("profiles", "r4")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
-TRAFFIC_JSON = os.path.join(PROFILES, "c2_bench", "traffic.json")
+PROFILES = os.path.join("profiles", "r5")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
 # What a correctly rounded f32 divide / square root costs the VALU in this library (csrc/dev_math.h): a quotient is v_rcp + 2 fma
 # shared by the numerators of one denominator, then mul + 2 fma + v_div_fixup each; a root is v_rsq + 2 mul + 2 fma; plus the range
 # test.  Small scenes' megakernel tracks the operands (v_frexp_exp + v_max3 per divide, v_frexp_exp + v_min per root; the two DS
@@ -50,10 +49,44 @@ TRAFFIC_JSON = os.path.join(PROFILES, "c2_bench", "traffic.json")
 # other kernels test next to the operation (v_max3, v_frexp_exp, two compares; subtract + compare for a root): 11 / 7.3 — 9 is used —
 # and 7.  (Rounds 1-3 priced both at hipcc's expansions, 12 and 15, which the library no longer executes.)
 DIV_INSTRUCTIONS, SQRT_INSTRUCTIONS = 9, 7
-# VALU wave-instructions per SIMD per quad-cycle (at 2.4 GHz) of a kernel of nothing but independent v_fma_f32 chains at 5 waves per SIMD:
-# what the hardware issues at the render kernels' occupancy (tools/microbench/valu_issue_peak.hip, profiles/r4/valu_issue_peak.txt)
-VALU_ISSUE_CEILING = 1.48
+# VALU wave-instructions per SIMD per quad-cycle of a kernel of nothing but independent v_fma_f32 chains at 5 waves per SIMD, at the
+# MEASURED clock (GRBM_GUI_ACTIVE of the same launch): tools/microbench/valu_issue_peak.hip, profiles/r5/valu_issue_peak.txt
+# (1 / 2 / 4 / 5 / 8 waves per SIMD: 0.68 / 1.32 / 1.50 / 1.58 / 1.68; v_pk_fma_f32: 0.93 at 8).  Round 4 quoted 1.48 for this — its C
+# loop had been SLP-packed into half as many v_pk_fma_f32 and priced at an assumed 2.4 GHz; the two errors nearly cancelled.
+VALU_ISSUE_FMA_STREAM = 1.58
 DIV_INSTRUCTIONS_TRACKED, SQRT_INSTRUCTIONS_TRACKED = 8, 7
+
+
+def source_hash():
+    """sha256 over the sources a library is built from (csrc/, include/, build.py): what a traffic.json is stamped with beside the
+    library's own hash, so that counters survive a rebuild of identical sources and nothing else."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    pkg = os.path.join(ROOT, "rust-pathtracer_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(pkg, "build.py")])
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read() + b"\0")
+    return h.hexdigest()
+
+
+def counters_for(name, lib_path):
+    """The committed PMC figures of profiles/<round>/<name>/traffic.json — IF they were collected from the library that is loaded
+    (its sha256, or failing that the sha256 of the sources it is built from).  Returns (dict or None, why)."""
+    import hashlib
+    path = os.path.join(ROOT, PROFILES, name, "traffic.json")
+    rel = os.path.join(PROFILES, name, "traffic.json")
+    if not os.path.exists(path):
+        return None, "%s does not exist" % rel
+    t = json.load(open(path))
+    lib_hash = hashlib.sha256(open(lib_path, "rb").read()).hexdigest() if os.path.exists(lib_path) else None
+    if t.get("library_sha256") and t["library_sha256"] == lib_hash:
+        return t, "%s: rocprofv3 PMC passes of the loaded library (sha256 %s...), committed (%s)" % (rel, lib_hash[:12], t["correction"])
+    if t.get("source_sha256") and t["source_sha256"] == source_hash():
+        return t, "%s: rocprofv3 PMC passes of a library built from these very sources (source sha256 %s...), committed (%s)" % (rel, t["source_sha256"][:12], t["correction"])
+    return None, "%s was collected from another build (library sha256 %s..., loaded %s...): the counters are not this code's" % (
+        rel, str(t.get("library_sha256"))[:12], str(lib_hash)[:12])
 
 
 def weak_frame(n_gpus):
@@ -114,13 +147,10 @@ def roofline_block(ops, launch_samples, kernel_s, kernel, launches, pixels, trac
             "hbm_algorithmic_GBs": round(hbm, 3), "hbm_frac": round(hbm / HBM_PEAK_GBS, 6)}
 
 
-def committed_traffic(name):
-    """HBM bytes per launch from the committed PMC passes of a profile directory (profiles/r4/<name>/traffic.json), or None."""
-    path = os.path.join(ROOT, PROFILES, name, "traffic.json")
-    if not os.path.exists(path):
-        return None, None
-    t = json.load(open(path))
-    return t["hbm_bytes_per_launch"], "%s: rocprofv3 PMC passes, committed (%s)" % (os.path.join(PROFILES, name, "traffic.json"), t["correction"])
+def committed_traffic(name, lib_path):
+    """HBM bytes per launch from the committed PMC passes of a profile directory, or None when they are another build's (counters_for)."""
+    t, why = counters_for(name, lib_path)
+    return (t["hbm_bytes_per_launch"] if t else None), why
 
 
 def other_configs(rpt, torch, device, small):
@@ -146,6 +176,7 @@ def other_configs(rpt, torch, device, small):
         return sum(ms) / len(ms) / 1e3
 
     out = {}
+    out.update(headline_variants(rpt, torch, device, small))
     # The headline workload once more with the device listed TWICE in its context (include/rpt.h, rpt_create_multi): two ranks on one
     # GPU, each with its own stream and every other block of 16 rows, the frame resident in the context, steps issued back to back —
     # one rank's launch fills the tail of the other's.  Not the headline `value`: a step is then two concurrent launches.
@@ -194,30 +225,30 @@ def other_configs(rpt, torch, device, small):
     sdf = scenes.sdf_scene()
     w, h, spp = 1920 // div, 1080 // div, 64 // (4 if small else 1)
     t = run(sdf, w, h, spp, 3)
-    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march2_sized_table_kernel_perop<3u>", 1, w * h)
+    blk = roofline_block(op_counts(sdf.describe(), (240, 136, 2)), w * h * spp, t, "render_sdf_march2_sized_table_kernel<3u>", 1, w * h)
     blk.update({"workload": "SDF sphere-march scene %dx%d x %d spp per step (BASELINE.json configs[3])" % (w, h, spp),
                 "value": round(w * h * spp / t / 1e6, 2), "value_unit": "Msamples/s"})
     if not small:
-        blk["traffic"], blk["traffic_source"] = committed_traffic("c4")
+        blk["traffic"], blk["traffic_source"] = committed_traffic("c4", rpt._lib.LIB_PATH)
     out["roofline_c4"] = blk
     big = scenes.random_spheres_scene(10000, 16)
     ops = op_counts(big.describe(), (128, 128, 1), skip_missed_sphere_tests=True)
     w = h = 4096 // div
     full = 512 // (16 if small else 1)
     t_full = run(big, w, h, full, 1)
-    blk = roofline_block(ops, w * h * full, t_full, "render_large_regen_kernel_perop", 1, w * h)
+    blk = roofline_block(ops, w * h * full, t_full, "render_large_regen_kernel", 1, w * h)
     blk.update({"workload": "10k spheres + 16 lights %dx%d x %d spp in one call (BASELINE.json configs[4], the whole frame on one GPU)" % (w, h, full),
                 "value": round(w * h * full / t_full / 1e6, 2), "value_unit": "Msamples/s",
                 "note": "flops per sample exclude ray/sphere tests that missed (brute_force_flops_per_sample is the oracle's loop); "
                         "the grid walk's own arithmetic is not algorithmic work and is not counted"})
     t8 = run(big, w, h, 8, 2)
-    blk["progressive_8spp"] = {"kernel": "render_large_regen_kernel_perop",
+    blk["progressive_8spp"] = {"kernel": "render_large_regen_kernel",
                                "kernel_ms": round(t8 * 1e3, 3), "value": round(w * h * 8 / t8 / 1e6, 2),
                                "frac": round(ops["flops_per_sample"] * w * h * 8 / t8 / 1e12 / FP32_PEAK_TFLOPS, 5)}
     if not small:
         # (the committed counters: of this very launch, and of the same kernel on the 2048 x 2048 x 32-spp frame: 2 x 16 B per pixel + the spills)
-        blk["traffic"], blk["traffic_source"] = committed_traffic("c5_full")
-        blk["progressive_8spp"]["traffic_2048x2048x32"] = committed_traffic("c5")[0]
+        blk["traffic"], blk["traffic_source"] = committed_traffic("c5_full", rpt._lib.LIB_PATH)
+        blk["progressive_8spp"]["traffic_2048x2048x32"] = committed_traffic("c5", rpt._lib.LIB_PATH)[0]
     out["roofline_c5"] = blk
     # the denoiser (include/rpt.h, project-defined): an HBM pass, 32 B per pixel per iteration
     for name, (dw, dh) in (("roofline_denoise_1080p", (1920 // div, 1080 // div)), ("roofline_denoise_4k", (3840 // div, 2160 // div))):
@@ -237,13 +268,101 @@ def other_configs(rpt, torch, device, small):
         del res
         t = min(ms) / 1e3
         gbs = iters * 32.0 * dw * dh / t / 1e9
-        tr, tr_src = committed_traffic("denoise_1080p" if name.endswith("1080p") else "denoise_4k") if not small else (None, None)
+        tr, tr_src = committed_traffic("denoise_1080p" if name.endswith("1080p") else "denoise_4k", rpt._lib.LIB_PATH) if not small else (None, None)
         out[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "traffic": tr, **({"traffic_source": tr_src} if tr_src else {}),
                      "kernel": "denoise_tile_kernel<1>, <2>, <4>", "kernel_ms": round(t * 1e3, 4),
                      "algorithmic_bytes_per_step": iters * 32.0 * dw * dh,
                      "workload": "a-trous denoiser, %d iterations on a %dx%d RGBA f32 buffer (16 B read + 16 B written per pixel per iteration)" % (iters, dw, dh)}
         del buf
+    return out
+
+
+def timed_steps(torch, tracer, buf, spp, steps):
+    """Mean device time of `steps` launches of `spp` samples (HIP events on the launch stream), in seconds."""
+    tracer.render_n(buf, spp)
+    torch.cuda.synchronize()
+    ms = []
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        tracer.render_n(buf, spp)
+        e1.record()
+        e1.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return sum(ms) / len(ms) / 1e3
+
+
+def general_kernels_leg(small):
+    """`bench.py --general-kernels-leg` (a process of its own: the library reads its knobs once): configs[1] with
+    RPT_NO_SIZED_KERNELS=1 RPT_NO_MATERIAL_TABLE=1, i.e. through the kernel any small scene OTHER than the reference's takes."""
+    import torch
+    import __graft_entry__ as entry
+    rpt = entry._load_package()
+    w, h, spp = (C2[0] // 8, C2[1] // 8, max(1, C2[2] // 16)) if small else C2
+    tracer = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
+    buf = rpt.DeviceColorBuffer(w, h, device="cuda:0")
+    t = timed_steps(torch, tracer, buf, spp, 5)
+    tracer.close()
+    print("GENERAL " + json.dumps({"value": round(w * h * spp / t / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(t * 1e3, 3),
+                                   "kernel": "render_small_regen_kernel",
+                                   "workload": "AnalyticalScene %dx%d x %d spp per step with RPT_NO_SIZED_KERNELS=1 RPT_NO_MATERIAL_TABLE=1" % (w, h, spp)}))
+
+
+def headline_variants(rpt, torch, device, small):
+    """What the headline does NOT say (N = 1, after the timed region):
+    general_kernels  the headline kernel is instantiated for exactly the reference scene's table sizes (2 spheres / 1 plane / 1
+                     light) and reads a hit's material from a 32-row table that exists for <= 3 primitives; every other small
+                     scene takes render_small_regen_kernel.  The same frame through THAT kernel.
+    relaxed          SURVEY.md 8c tier T1: configs[1] under RPT_RENDER_FAST_MATH (hipcc's fast divide / sqrt, FMA contraction) —
+                     Msamples/s, and against the strict frame after the same 256 spp: whole-frame RMSE and the number of pixels with
+                     |delta| > 1e-4 in some channel (an ulp flips a branch now and then: a sample changes by O(1), a pixel by O(1/spp)).
+                     What bit-exact IEEE divides and roots cost, and what they buy."""
+    import subprocess
+    out = {}
+    w, h, spp = (C2[0] // 8, C2[1] // 8, max(1, C2[2] // 16)) if small else C2
+    try:
+        env = dict(os.environ, RPT_NO_SIZED_KERNELS="1", RPT_NO_MATERIAL_TABLE="1", HIP_VISIBLE_DEVICES=os.environ.get("HIP_VISIBLE_DEVICES", str(device)))
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--general-kernels-leg"] + (["--small"] if small else []),
+                           capture_output=True, text=True, timeout=300, env=env)
+        line = [l for l in r.stdout.splitlines() if l.startswith("GENERAL ")]
+        out["general_kernels"] = json.loads(line[-1][8:]) if line else {"error": (r.stderr or r.stdout)[-400:]}
+        if line:
+            out["general_kernels"]["note"] = ("what any small scene other than the reference's gets: table sizes as data, the material built "
+                                              "per hit; the headline value is the sized + material-table instantiation of the same kernel")
+    except Exception as e:      # noqa: BLE001 - a secondary leg must not cost the line
+        out["general_kernels"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        A = rpt._abi
+        strict = rpt.Tracer(rpt.AnalyticalScene(), device=device, seed=1)
+        fast = rpt.Tracer(rpt.AnalyticalScene(), device=device, seed=1)
+        fast.flags = A.RPT_RENDER_FAST_MATH
+        fs = rpt.DeviceColorBuffer(w, h, device="cuda:%d" % device)
+        ff = rpt.DeviceColorBuffer(w, h, device="cuda:%d" % device)
+        strict.render_n(fs, spp)
+        fast.render_n(ff, spp)
+        torch.cuda.synchronize()
+        d = (ff.pixels[..., :3].double() - fs.pixels[..., :3].double())
+        finite = torch.isfinite(d).all(dim=-1)
+        dd = torch.where(torch.isfinite(d), d, torch.zeros_like(d))
+        rmse = float(torch.sqrt((dd * dd).mean()).item())
+        outliers = int(((dd.abs() > 1e-4).any(dim=-1) | ~finite).sum().item())
+        same = int((ff.pixels.view(torch.int32) == fs.pixels.view(torch.int32)).all(dim=-1).sum().item())
+        tbuf = rpt.DeviceColorBuffer(w, h, device="cuda:%d" % device)
+        t_fast = timed_steps(torch, fast, tbuf, spp, 5)
+        t_strict = timed_steps(torch, strict, tbuf, spp, 5)
+        out["relaxed"] = {"value": round(w * h * spp / t_fast / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(t_fast * 1e3, 3),
+                          "strict_value_same_run": round(w * h * spp / t_strict / 1e6, 2),
+                          "kernel": "render_small_regen_kernel_fast", "flags": "RPT_RENDER_FAST_MATH",
+                          "rmse_vs_strict": rmse, "pixels_over_1e-4": outliers, "pixels_bit_identical": same, "pixels": w * h,
+                          "max_abs_delta": float(dd.abs().max().item()),
+                          "workload": "AnalyticalScene %dx%d, both frames after %d spp from an empty buffer, seed 1" % (w, h, spp),
+                          "note": "NOT the headline arithmetic: v_rcp / v_rsq based divide and sqrt (~2.5 ulp) and FMA contraction; the relaxed "
+                                  "build has no sized / material-table instantiation, so compare with general_kernels.value for the price of "
+                                  "the correctly rounded operations alone"}
+        strict.close(); fast.close()
+    except Exception as e:      # noqa: BLE001
+        out["relaxed"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -316,7 +435,7 @@ def config1_line(rpt, torch, device, threads):
     return {"workload": "AnalyticalScene 800x600 x 1 spp per call (BASELINE.json configs[0]: one reference render())",
             "cpu_ms_per_call": round(cpu_s * 1e3, 3), "cpu_value": round(w * h / cpu_s / 1e6, 2), "cpu_cores": threads, "cpu_kind": "port",
             "gpu_ms_per_call": round(gpu_s * 1e3, 4), "gpu_value": round(w * h / gpu_s / 1e6, 1), "unit": "Msamples/s",
-            "gpu_kernel": "render_small_compact_dense_sized_table_kernel_perop", "gpu_over_cpu": round(cpu_s / gpu_s, 1)}
+            "gpu_kernel": "render_small_compact_dense_sized_table_kernel", "gpu_over_cpu": round(cpu_s / gpu_s, 1)}
 
 
 class TorchGatherRender:
@@ -376,7 +495,10 @@ def main():
                          "duplicate devices), to exercise the N>1 control flow on a 1-GPU box; the numbers mean nothing")
     ap.add_argument("--force-multi", action="store_true", help="TEST ONLY: take the N > 1 path with however many ranks there are (one, without a launcher)")
     ap.add_argument("--small", action="store_true", help="TEST ONLY: 1/8-size frames and 1/16 of the samples (control-flow rehearsals)")
+    ap.add_argument("--general-kernels-leg", action="store_true", help="INTERNAL: the `general_kernels` secondary leg (a process of its own: see headline_variants)")
     args = ap.parse_args()
+    if args.general_kernels_leg:
+        return general_kernels_leg(args.small)
 
     import torch
     import __graft_entry__ as entry
@@ -422,14 +544,23 @@ def main():
         torch.cuda.synchronize()
 
     scene = rpt.AnalyticalScene()
-    extra = {}                          # secondary results of the JSON line
+    extra = {}                          # secondary results of the JSON line (written under emit_lock once the watchdog runs)
     emitted = []
+    emit_lock = threading.Lock()        # the line is printed ONCE, by whoever gets here first — the end of main or the watchdog —, and whole
 
     def emit():
-        """Rank 0 prints the ONE JSON line (once, whoever asks first: the end of main or the secondary legs' timer)."""
-        if rank != 0 or emitted:
+        """Rank 0 prints the ONE JSON line.  Holds emit_lock from the look at `emitted` to the end of the print, so that the other
+        caller waits for the line instead of leaving the process under it."""
+        if rank != 0:
             return
-        emitted.append(True)
+        with emit_lock:
+            if emitted:
+                return
+            emit_locked()
+            sys.stdout.flush()
+            emitted.append(True)
+
+    def emit_locked():
         samples = width * height * spp * args.steps
         value = samples / elapsed / 1e6
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
@@ -438,31 +569,35 @@ def main():
         launch_samples = local_pixels * spp
         algo_bytes = 32.0 * local_pixels          # 16 B read + 16 B write of the running mean per pixel per launch sequence
         hbm = algo_bytes / avg_kernel_s / 1e9
-        launches = 1                              # one launch whatever spp is (kernels.hip: a launch is tiles x chunks of samples)
-        kernel = "render_small_regen_sized_table_kernel" if spp > 1 else "render_small_compact_sized_table_kernel_perop"     # (capi.hip: RPT_COMPACT_MAX_SPP; kernels.hip: sized_scene)
+        launches = 1                              # one launch whatever spp is (kernel_common.h: a launch is tiles x chunks of samples)
+        kernel = "render_small_regen_sized_table_kernel" if spp > 1 else "render_small_compact_sized_table_kernel"     # (capi.hip: launch_render, KernelChoice)
         roofline = roofline_block(ops, launch_samples, avg_kernel_s, kernel, launches, local_pixels, tracked=spp > 1)
         roofline["note"] = ("algorithmic flops (add/mul/div/sqrt = 1 each, counted by the oracle's op-counting build); a correctly "
                             "rounded f32 divide or sqrt costs 8-13 VALU instructions in this library (ieee_expanded_*); kernel_ms = HIP events on the launch stream")
-        tj = os.path.join(ROOT, TRAFFIC_JSON)
-        if not multi and not args.small and os.path.exists(tj):
-            t = json.load(open(tj))
-            roofline["traffic"] = t["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "%s: rocprofv3 PMC passes of this command, committed (%s); bench.py cannot collect counters itself" % (
-                TRAFFIC_JSON, t["correction"])
-            if "valu_insts_per_launch" in t:
-                # How busy the vector ALUs are, from the same committed PMC passes and THIS run's kernel time: a SIMD issues one
-                # wave64 VALU instruction per quad-cycle, two when two waves have one ready (SQ_ACTIVE_INST_VALU2), which is
-                # what the 157 TFLOP/s peak assumes.  SIMD cycles = 1 024 SIMDs x kernel time x the clock.
-                simd_quads = 1024.0 * avg_kernel_s * GPU_CLOCK_HZ / 4.0
+        if not multi and not args.small:
+            t, why = counters_for("c2_bench", rpt._lib.LIB_PATH)
+            roofline["traffic_source"] = why + ("" if t is None else "; bench.py cannot collect counters itself")
+            if t is not None:
+                roofline["traffic"] = t["hbm_bytes_per_launch"]
+            if t is not None and "valu_insts_per_launch" in t:
+                # How busy the vector ALUs are, from the same committed PMC passes: VALU wave-instructions over the SIMDs' quad-cycles
+                # of the profiled launch itself (GRBM_GUI_ACTIVE / 8: no clock is assumed).  2.0 per quad-cycle is the nominal issue
+                # peak the 157 TFLOP/s figure assumes; a stream of nothing but independent v_fma_f32 reaches VALU_ISSUE_FMA_STREAM.
+                cyc = t.get("shader_cycles_per_launch") or avg_kernel_s * GPU_CLOCK_HZ
+                simd_quads = 1024.0 * cyc / 4.0
+                rate = t["valu_insts_per_launch"] / simd_quads
+                lanes = t.get("valu_lane_utilisation", 0.0)
                 roofline["valu_issue"] = {
-                    "insts_per_launch": t["valu_insts_per_launch"], "lane_utilisation": round(t.get("valu_lane_utilisation", 0.0), 3),
-                    "insts_per_simd_quad_cycle": round(t["valu_insts_per_launch"] / simd_quads, 3),
-                    "frac_of_dual_issue_peak": round(t["valu_insts_per_launch"] / simd_quads / 2.0, 3),
-                    "measured_fma_only_ceiling": VALU_ISSUE_CEILING,
-                    "frac_of_measured_ceiling": round(t["valu_insts_per_launch"] / simd_quads / VALU_ISSUE_CEILING, 3),
-                    "note": "VALU wave-instructions per SIMD per 4 cycles (rocprofv3's VALUBusy / 100); 2.0 is the nominal issue peak; a "
-                            "kernel of nothing but independent fused multiply-adds reaches measured_fma_only_ceiling at this occupancy "
-                            "(profiles/r4/valu_issue_peak.txt); x lane_utilisation = the share of the ALU lanes doing path work"}
+                    "insts_per_launch": t["valu_insts_per_launch"], "lane_utilisation": round(lanes, 3),
+                    "insts_per_simd_quad_cycle": round(rate, 3),
+                    "frac_of_dual_issue_peak": round(rate / 2.0, 3),
+                    "frac_of_lane_issue_capacity": round(rate / 2.0 * lanes, 3),
+                    "fma_stream_at_5_waves": VALU_ISSUE_FMA_STREAM,
+                    "clock_GHz": round(cyc / (avg_kernel_s * 1e9), 3) if t.get("shader_cycles_per_launch") else None,
+                    "note": "VALU wave-instructions per SIMD per 4 cycles, cycles counted (GRBM_GUI_ACTIVE / 8) in the same launch; 2.0 is the "
+                            "nominal issue peak; frac_of_dual_issue_peak is the issue figure, x lane_utilisation = the share of the ALU lanes' "
+                            "issue capacity doing path work; a stream of nothing but independent v_fma_f32 issues fma_stream_at_5_waves "
+                            "at this occupancy (profiles/r5/valu_issue_peak.txt)"}
         out = {
             "metric": "Msamples/s (pixels x spp) on AnalyticalScene 1920x1080 f32; 1/2/4/8-GPU scaling",
             "value": round(value, 2), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -479,7 +614,7 @@ def main():
                              "algorithmic_bytes_per_step": algo_bytes,
                              "note": "32/S bytes per pixel-sample: the honest signature of an ALU-bound path, not the binding roofline"},
         }
-        out.update(extra)
+        out.update(dict(extra))
         if not multi and not args.headline_only:
             out.update(other_configs(rpt, torch, local_rank, args.small))
         if not multi and not args.no_cpu_baseline and not args.small:
@@ -558,7 +693,7 @@ def main():
                                              "timed region (BASELINE.json configs[4])" % (bw, bh, bspp, TILE_ROWS, world),
                                  "steps": 1, "ms_per_step": round(float(t.item()) * 1e3, 3),
                                  "value": round(bw * bh * bspp / float(t.item()) / 1e6, 2), "unit": "Msamples/s",
-                                 "note": "render_large_regen_kernel_perop; the one-GPU figure of the same frame is roofline_c5.value of the N = 1 line"}
+                                 "note": "render_large_regen_kernel; the one-GPU figure of the same frame is roofline_c5.value of the N = 1 line"}
             if tracer:
                 tracer._scene = scene
                 tracer.upload_scene()
@@ -597,14 +732,21 @@ def main():
             # The library's own communicator (rpt_create_rank).  If it cannot be set up on this node, every rank falls
             # back TOGETHER to per-rank tiles + a torch.distributed (RCCL) gather, and the JSON line says so.
             why = ""
+            t_init = t_first = None
             try:
-                tracer = tiling.rank_tracer(scene, local_rank, seed=1)
+                tc = time.perf_counter()
+                tracer = tiling.rank_tracer(scene, local_rank, seed=1)                # rpt_comm_unique_id on rank 0, the id over gloo, ncclCommInitRank
+                t_init = time.perf_counter() - tc
+                tc = time.perf_counter()
                 first = tiling.TiledRender(tracer, 64, 64, tile_rows=TILE_ROWS)       # the communicator's first exchange, on a small frame
                 first.render_n(1)
                 first.gather()
+                t_first = time.perf_counter() - tc
                 del first
             except Exception as e:          # noqa: BLE001 - any failure of the collective set-up takes the fallback
                 tracer, why = None, "%s: %s" % (type(e).__name__, e)
+            setup = {"rank": rank, "device": local_rank, "comm_init_s": None if t_init is None else round(t_init, 3),
+                     "first_exchange_s": None if t_first is None else round(t_first, 3), "error": why or None}
             ok = torch.tensor([1 if tracer else 0])
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
@@ -613,6 +755,13 @@ def main():
                 tracer = rpt.Tracer(scene, device=local_rank, seed=1)
                 gather_mode = "torch.distributed RCCL gather (fallback: the library communicator failed to initialise%s)" % (
                     ": " + why if why else " on another rank")
+            # Every rank says how its set-up went — on stderr at once (a run that dies later still leaves it in the log's tail) and, through
+            # gloo, in rank 0's JSON line: a driver-run scaling file is then diagnosable from what it kept.
+            setup["gather"] = gather_mode
+            print("[bench rank %d/%d] %s" % (rank, world, json.dumps(setup)), file=sys.stderr, flush=True)
+            all_setup = [None] * world
+            dist.all_gather_object(all_setup, setup)
+            extra["rank_setup"] = all_setup
         if gather_mode.startswith("torch"):
             job_of = lambda w, h: TorchGatherRender(tracer, tiling, w, h, TILE_ROWS, rank, world, local_rank)     # noqa: E731
         else:
@@ -654,10 +803,15 @@ def main():
         # A leg that raises is recorded and ends the legs on this rank; ranks that then wait for it in a collective — or a leg that
         # hangs — are cut off by a timer that emits the line with what there is and leaves.
         def cut_off():
-            extra["secondary_legs"] = "cut off after %d s" % SECONDARY_LIMIT_S
+            # The legs hang (or a rank never reached them): the line goes out with what there is, and the process ends with a
+            # status that says so — a hung rank must not look like success to the launcher.
+            with emit_lock:
+                if not emitted:
+                    extra["secondary_legs"] = "cut off after %d s" % SECONDARY_LIMIT_S
             emit()
             sys.stdout.flush()
-            os._exit(0)
+            sys.stderr.flush()
+            os._exit(3)
 
         watchdog = threading.Timer(SECONDARY_LIMIT_S, cut_off)
         watchdog.daemon = True
@@ -665,7 +819,8 @@ def main():
         try:
             secondary_legs()
         except Exception as e:              # noqa: BLE001
-            extra["secondary_legs"] = "stopped by %s: %s" % (type(e).__name__, e)
+            with emit_lock:
+                extra["secondary_legs"] = "stopped by %s: %s" % (type(e).__name__, e)
         dist.barrier()
         watchdog.cancel()
 

@@ -58,10 +58,11 @@ def gather_tiles(tile, world, group=None, dst=0):
     return torch.stack(out) if rank == dst else None
 
 
-def rank_tracer(scene, local_device, seed=1, group=None):
+def rank_tracer(scene, local_device, seed=1, group=None, probe=None):
     """One process per GPU: build this rank's Tracer.  Rank 0 asks the library for an RCCL unique id, the job's
     torch.distributed group (gloo or nccl, it only carries 128 bytes) hands it to everybody, and every rank joins
-    the library's own communicator (collective).
+    the library's own communicator (collective).  `probe`: tests only — a callable that stands for "can this rank load RCCL and
+    open its device" (raises if not), so that the agreement protocol can be driven with mixed outcomes on a box without a GPU.
 
     Every rank makes the same sequence of group calls whatever fails where: what can fail on one rank alone (the
     library or RCCL not loading, no usable device) is tried first and agreed on with an all_reduce, and rank 0's id
@@ -70,8 +71,11 @@ def rank_tracer(scene, local_device, seed=1, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     why = ""
     try:
-        comm_unique_id()                                  # RCCL loads in this process (the id itself is thrown away)
-        Tracer(scene, device=local_device, seed=seed).close()   # the device is there and is a gfx950
+        if probe is not None:
+            probe()
+        else:
+            comm_unique_id()                              # RCCL loads in this process (the id itself is thrown away)
+            Tracer(scene, device=local_device, seed=seed).close()   # the device is there and is a gfx950
     except Exception as e:                                # noqa: BLE001 - reported on every rank below
         why = "rank %d: %s: %s" % (rank, type(e).__name__, e)
     ok = torch.tensor([0 if why else 1])

@@ -104,6 +104,54 @@ def test_rank_tracer_fails_on_every_rank_together(tmp_path):
         assert ok == "0" and "cannot be set up" in why, (r, ok, why)
 
 
+def _protocol_worker(rank, world, port, out_dir, failing):
+    sys.path.insert(0, HERE)
+    import conftest  # noqa: F401
+    import rust_pathtracer_amd as rpt
+    from rust_pathtracer_amd import tiling
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    def probe():
+        if rank in failing:
+            raise OSError("this rank's device is gone")
+
+    try:
+        kind, why = "", ""
+        try:
+            tiling.rank_tracer(rpt.AnalyticalScene(), 0, seed=1, probe=probe)
+        except Exception as e:              # noqa: BLE001 - which exception, on which rank, is what the test looks at
+            kind, why = type(e).__name__, str(e)
+        ok = torch.tensor([0 if why else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # the job's next collective (bench.py's agreement on the fallback)
+        open(os.path.join(out_dir, "rank%d.txt" % rank), "w").write("%d|%s|%s" % (int(ok.item()), kind, why))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("failing", [(2,), (0,), (1, 3), ()])
+def test_rank_tracer_agreement_protocol_with_four_ranks(tmp_path, failing):
+    """tiling.rank_tracer with world = 4 and mixed outcomes of the per-rank pre-check (a stand-in for "RCCL loads and the device
+    opens"): whichever ranks fail — a middle one, rank 0 (which would have made the unique id), two at once — EVERY rank raises the same
+    error, none is left in the broadcast or inside ncclCommInitRank, and the job's next collective completes.  With no failing rank
+    the protocol goes on to the library's communicator, which on a box without a GPU fails on every rank alike (no device)."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU (on a GPU box four ranks would need four devices)")
+    world = 4
+    port = 33500 + (os.getpid() % 2000) + 7 * len(failing) + sum(failing)
+    mp.spawn(_protocol_worker, args=(world, port, str(tmp_path), tuple(failing)), nprocs=world, join=True)
+    got = [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read().split("|", 2) for r in range(world)]
+    assert all(g[0] == "0" for g in got), got                # the next collective ran on every rank, and says "fallback"
+    assert len({g[1] for g in got}) == 1, got                # the same exception type everywhere
+    if failing:
+        for g in got:
+            assert g[1] == "RuntimeError" and "cannot be set up" in g[2], g
+            assert any("rank %d:" % f in g[2] for f in failing) or "another rank" in g[2], g
+    else:
+        assert all(g[2] for g in got), got                   # no device here: every rank failed, together, after the agreement
+
+
 def test_tile_copy_plan_covers_exactly_the_ranks_rows(rpt):
     """rpt_tile_copy_plan (what rpt_render / rpt_resident_upload follow for their one strided copy per device) against
     the row-by-row definition rpt_tile_global_row, for every rank of many image / block / world sizes."""

@@ -50,6 +50,20 @@ if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
         out["valu_active_quad_cycles_per_launch"] = g("SQ_ACTIVE_INST_VALU")
     if g("SQ_ACTIVE_INST_VALU") and g("SQ_THREAD_CYCLES_VALU"):
         out["valu_lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
+    if g("GRBM_GUI_ACTIVE"):
+        out["shader_cycles_per_launch"] = g("GRBM_GUI_ACTIVE") / 8.0            # the counter sums the 8 XCDs
+    # Which code the counters belong to: bench.py prints them only for the library (or the sources) they were collected from.
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    lib = os.environ.get("RPT_PROFILED_LIB", os.path.join(root, "rust-pathtracer_amd", "librpt_hip.so"))
+    if os.path.exists(lib):
+        out["library_sha256"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+    sys.path.insert(0, root)
+    try:
+        import bench
+        out["source_sha256"] = bench.source_hash()
+    except Exception as e:      # noqa: BLE001
+        out["source_sha256_error"] = str(e)
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
     print("HBM bytes per launch         %.4g (2 x FETCH + WRITE)" % out["hbm_bytes_per_launch"])
 ks = os.path.join(d, "kernel_stats.csv")
