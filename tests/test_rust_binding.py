@@ -225,7 +225,7 @@ def check_binding(rust_src, tmp_path):
     # constants: every `pub const RPT_*` must have the header's value (gcc evaluates the enumerators), and every render /
     # scene flag and status code of the header must be there
     r_consts = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"pub const (RPT_[A-Z0-9_]+): [iu]32 = (-?(?:0x[0-9A-Fa-f]+|\d+));", rust_src)}
-    hdr_names = sorted(set(re.findall(r"\b(RPT_(?:RENDER|SCENE|ERR|LIGHT|BG|MEDIUM)_[A-Z0-9_]+|RPT_OK|RPT_MAT_ALL|RPT_MAT_MEDIUM)\s*=", open(HEADER).read())))
+    hdr_names = sorted(set(re.findall(r"\b(RPT_(?:RENDER|SCENE|ERR|LIGHT|BG|MEDIUM|MAT|PROC)_[A-Z0-9_]+|RPT_OK)\s*=", open(HEADER).read())))
     prog = os.path.join(str(tmp_path), "consts.c")
     with open(prog, "w") as f:
         f.write('#include <stdio.h>\n#include "rpt.h"\nint main(void) {\n')
@@ -283,3 +283,105 @@ def test_checker_catches_a_wrong_flag_value(tmp_path):
     assert "pub const RPT_RENDER_RUSSIAN_ROULETTE: u32 = 0x20;" in src
     broken = src.replace("pub const RPT_RENDER_RUSSIAN_ROULETTE: u32 = 0x20;", "pub const RPT_RENDER_RUSSIAN_ROULETTE: u32 = 0x80;")
     assert any("RPT_RENDER_RUSSIAN_ROULETTE" in p for p in check_binding(broken, tmp_path))
+
+
+# ---- the scene adapter: SceneDescBuilder, the From / patch helpers, AnalyticalScene's describe(), AutoTracer ------
+ADAPTER = os.path.join(ROOT, "rust", "analytical_gpu.rs")
+
+
+def _rust_fn_body(src, signature_start):
+    """The text between the braces of the first fn whose signature starts with `signature_start`."""
+    i = src.index(signature_start)
+    j = src.index("{", i)
+    depth, k = 0, j
+    while True:
+        depth += src[k] == "{"
+        depth -= src[k] == "}"
+        if depth == 0:
+            return src[j + 1:k]
+        k += 1
+
+
+def test_the_rust_builder_describes_the_stock_scene_like_the_library(rpt):
+    """rust/analytical_gpu.rs builds AnalyticalScene's descriptor from the Rust side's own values (lights through Scene::light_at,
+    closest_hit's literals restated) with SceneDescBuilder.  Through the Python mirror of that builder and of that describe()
+    (rust-pathtracer_amd/scene_builder.py, statement for statement): every byte of the descriptor and of its four tables equals
+    the library's rpt_scene_analytical."""
+    import ctypes as C
+    from rust_pathtracer_amd import scene_builder as sb
+
+    def dump(d):
+        out = [d.abi_version, d.flags, bytes(d.camera), bytes(d.background), d.eps, d.max_depth, d.n_spheres, d.n_planes, d.n_lights, d.n_materials, d.sdf.n_prims]
+        out += [bytes(d.spheres[i]) for i in range(d.n_spheres)] + [bytes(d.planes[i]) for i in range(d.n_planes)]
+        out += [bytes(d.lights[i]) for i in range(d.n_lights)] + [bytes(d.materials[i]) for i in range(d.n_materials)]
+        return out
+
+    lib_desc = rpt._abi.rpt_scene_desc()
+    assert rpt.lib().rpt_scene_analytical(C.byref(lib_desc)) == 0
+    built = sb.analytical_describe(sb.RefAnalyticalScene())
+    assert built.with_desc(dump) == dump(lib_desc)
+    # ... and it is a scene the library accepts as it is (argument checks run without a GPU)
+    assert built.with_desc(lambda d: rpt.lib().rpt_upload_scene(None, C.byref(d))) == rpt._abi.RPT_ERR_INVALID_ARG      # (NULL context: the descriptor was not the problem)
+    # a full patch zeroes nothing; the helper that canonicalises a patch keeps exactly the masked fields
+    m = sb.RptMaterial.full(sb.RefMaterial()).zero_unmasked().c
+    assert (m.ior, m.roughness, tuple(m.rgb)) == (C.c_float(1.45).value, 0.5, (1.5, 1.5, 1.5))
+    m = sb.RptMaterial.patch(sb.RefMaterial(), rpt._abi.RPT_MAT_ROUGHNESS).zero_unmasked().c
+    assert (m.ior, m.roughness, tuple(m.rgb)) == (0.0, 0.5, (0.0, 0.0, 0.0))
+
+
+def test_the_python_mirror_is_the_rust_adapter():
+    """The mirror can only stand for the Rust files if it IS them: SceneDescBuilder's and RptMaterial's public methods are the same
+    set on both sides, and describe() of rust/analytical_gpu.rs and scene_builder.analytical_describe make the same builder calls
+    with the same literals in the same order."""
+    import inspect
+    from rust_pathtracer_amd import scene_builder as sb
+    rust = strip_comments(open(RUST).read())
+    impl = rust[rust.index("impl SceneDescBuilder {"):rust.index("pub trait GpuScene")]
+    rust_methods = set(re.findall(r"pub fn (\w+)", impl))
+    py_methods = {n for n, _ in inspect.getmembers(sb.SceneDescBuilder, inspect.isfunction) if not n.startswith("_")}
+    assert rust_methods - {"new", "flags"} == py_methods - {"set_flags"}, (rust_methods, py_methods)      # (`new` is __init__; `flags` is an attribute's name in Python)
+    impl = rust[rust.index("impl RptMaterial {"):rust.index("pub struct SceneDescBuilder")]
+    assert set(re.findall(r"pub fn (\w+)", impl)) == {n for n, _ in inspect.getmembers(sb.RptMaterial, inspect.isfunction) if not n.startswith("_")}
+    # the two describe() bodies: builder calls and numeric literals, in order
+    body = _rust_fn_body(strip_comments(open(ADAPTER).read()), "fn describe(&self)")
+    py = inspect.getsource(sb.analytical_describe)
+    py = py[py.index('"""', py.index('"""') + 3) + 3:]
+    calls = lambda s: re.findall(r"\bb\s*\.\s*(\w+)\s*\(", s)                               # noqa: E731
+    r_calls = [c for c in calls(body) if c != "materials"]
+    p_calls = [c for c in calls(py) if c != "materials"]
+    assert r_calls == p_calls, (r_calls, p_calls)
+    nums = lambda s: [float(x) for x in re.findall(r"(?<![\w.])-?\d+\.\d+(?:e-?\d+)?", s)]   # noqa: E731
+    assert nums(body.replace("F3::new_x(1.0)", "F3::new(1.0, 1.0, 1.0)")) == nums(py), (nums(body), nums(py))
+    masks = lambda s: re.findall(r"RPT_MAT_\w+", s)                                          # noqa: E731
+    assert masks(body) == masks(py)
+
+
+def test_the_rust_surface_the_integration_guide_promises():
+    """Items INTEGRATION.md names, with the signatures that make them a drop-in: a Result-returning constructor that hands the scene
+    back, scene() typed like tracer.rs:629, render() that cannot panic on a library error, AutoTracer with the CPU fallback on
+    RPT_ERR_NO_DEVICE, the conversions from the reference's own types."""
+    src = strip_comments(open(RUST).read())
+    for needle in ("pub struct RptError { pub status: i32, pub message: String }",
+                   "pub fn try_new(scene: Box<dyn Scene>, describe: Describer) -> Result<Self, (RptError, Box<dyn Scene>)>",
+                   "pub fn scene(&mut self) -> &mut Box<dyn Scene>",
+                   "pub fn try_render(&mut self, buffer: &mut ColorBuffer) -> Result<(), RptError>",
+                   "pub fn render(&mut self, buffer: &mut ColorBuffer)",
+                   "pub enum AutoTracer", "AutoTracer::Cpu(Tracer::new(scene))", "pub fn backend(&self) -> &'static str",
+                   "impl From<&AnalyticalLight> for RptLight", "impl From<&Light> for RptLight",
+                   "pub fn patch(m: &Material, mask: u32) -> Self", "pub fn with_desc<R>(&self, f: impl FnOnce(&RptSceneDesc) -> R) -> R",
+                   "pub type Describer = fn(&mut dyn Scene) -> Option<SceneDescBuilder>;",
+                   "pub fn describer_of<T: GpuScene + 'static>(scene: &mut dyn Scene) -> Option<SceneDescBuilder>",
+                   "pub fn no_device(&self) -> bool { self.status == RPT_ERR_NO_DEVICE }"):
+        assert needle in src, needle
+    # render() must not panic on a library error: no assert!/panic!/unwrap/expect inside it, nor inside AutoTracer::render
+    gpu_impl = src[src.index("impl GpuTracer {"):src.index("impl Drop for GpuTracer")]
+    render_body = _rust_fn_body(gpu_impl, "pub fn render(&mut self, buffer: &mut ColorBuffer)")
+    auto_body = _rust_fn_body(src[src.index("impl AutoTracer {"):], "pub fn render(&mut self, buffer: &mut ColorBuffer)")
+    for body in (render_body, auto_body, _rust_fn_body(gpu_impl, "pub fn try_render_n")):
+        assert not re.search(r"\b(assert!|panic!|unwrap\(|expect\()", body), body
+    adapter = strip_comments(open(ADAPTER).read())
+    assert "impl GpuScene for AnalyticalScene" in adapter and "rpt_scene_analytical" not in adapter and "lights_of(self)" in adapter
+    # every fn the extern block declares is used, or marked as deliberately unused
+    ext = src[src.index('extern "C" {'):src.index("}", src.index('extern "C" {'))]
+    for m in re.finditer(r"(#\[allow\(dead_code\)\]\s*)?fn (rpt_\w+)\(", ext):
+        assert m.group(1) or src.count(m.group(2) + "(") >= 2, "%s is declared and never called" % m.group(2)
