@@ -87,8 +87,7 @@ VARIANTS = {
     "cg_no_cluster": ["-mllvm", "-misched-cluster=0"],
     "cg_exec_pre_ra0": ["-mllvm", "-amdgpu-opt-exec-mask-pre-ra=0"],
     # round 5
-    "dn_xcd": ["-DRPT_DENOISE_XCD"],                           # the denoiser's tiles dealt so that every XCD filters one band of the image (halos hit its L2)
-    "dn_xcd32": ["-DRPT_DENOISE_XCD", "-DRPT_DENOISE_TILE=32"],
+    "dn_unfused": ["-DRPT_DENOISE_UNFUSED"],                   # the denoiser one pass per iteration (round 4's form) against the fused first three
     "cg_licm_on": [],        # (built with RPT_TUNING_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp": machine LICM back on)
 }
 
