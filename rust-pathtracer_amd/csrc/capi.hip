@@ -221,7 +221,7 @@ struct SchedLayout {
     size_t sync() const { return 10 * n; }                          // kSyncTimeout (kept), then from kSyncTicket on: zeroed before a chunked launch
     size_t total() const { return 10 * n + 32 + n; }
 };
-constexpr size_t kSyncTimeoutWord = 0, kSyncZeroFrom = 16, kSyncDoneFrom = 32;     // = kernels.hip's kSyncTimeout / kSyncTicket / kSyncDone
+constexpr size_t kSyncTimeoutWord = 0, kSyncZeroFrom = 16, kSyncDoneFrom = 32;     // = kernel_common.h's kSyncTimeout / kSyncTicket / kSyncDone
 
 // Dispatch policy of a context (include/rpt.h, rpt_set_dispatch); the environment gives the defaults.
 struct DispatchPolicy {
@@ -235,7 +235,7 @@ static DispatchPolicy policy_of(const rpt_ctx* ctx)
     return DispatchPolicy{ctx->dispatch[0], ctx->dispatch[1], ctx->dispatch[2], ctx->dispatch[3]};
 }
 
-// How many chunks of samples a launch of `nblocks` tiles x `spp` samples is cut into (kernels.hip, units): enough for
+// How many chunks of samples a launch of `nblocks` tiles x `spp` samples is cut into (kernel_common.h, units): enough for
 // `unit_rounds` rounds of workgroups on the device, no chunk shorter than `unit_min_spp` samples; 1 when the tiles alone are
 // that many rounds, or fit the device at once (then nothing waits for a slot and there is nothing to balance).  Measured
 // (tools/tile_rows_time.py, tools/launch_size_time.py): one rank's share of configs[2] (3.2 rounds, 1 024 spp) 1 / 2 / 4 / 8

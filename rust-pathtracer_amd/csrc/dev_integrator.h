@@ -169,39 +169,6 @@ RPT_DEV float sdf_eval(const DevSdf& sd, v3 p)
     return dd;
 }
 
-// The same function with the primitive records read from LDS instead of the kernarg segment (the two-room march kernel stages them
-// once per workgroup: prims[2 * i] = {kind bits, cx, cy, cz}, prims[2 * i + 1] = {p0, p1, -, -}).  Every lane reads the same
-// address (a broadcast), the next record is requested before the current one is evaluated, and nothing of it occupies a scalar
-// register.  Read through the scalar cache a march step loads each record and waits for it — a quarter of the march kernel's
-// wave time was s_waitcnt lgkmcnt on those loads (profiles/r3/c4_final) — and requesting records ahead there costs SGPRs the
-// kernel does not have (42 spilled, -5 %).  Same operations in the same order on the same values: bit-identical.
-RPT_DEV float sdf_eval_lds(const DevSdf& sd, const float4* prims, v3 p)
-{
-    const float k = sd.smooth_k;
-    const uint32_t n = sd.n_prims;
-    float4 a = prims[0], b = prims[1];
-    float dd = 0.0f;
-    for (uint32_t i = 0; i < n; ++i) {
-        const float4 ca = a, cb = b;
-        if (i + 1u < n) { a = prims[2u * i + 2u]; b = prims[2u * i + 3u]; }       // the next record, in flight during this one's arithmetic
-        const v3 q = p - mk3(ca.y, ca.z, ca.w);
-        float v;
-        if (rpt_f2u(ca.x) == RPT_SDF_TORUS_Y) {
-            const float qx = fsqrt(q.x * q.x + q.z * q.z) - cb.x;
-            v = fsqrt(qx * qx + q.y * q.y) - cb.y;
-        } else {
-            v = len3(q) - cb.x;
-        }
-        if (i == 0u) dd = v;
-        else {
-            const float h = rmax(k - __builtin_fabsf(dd - v), 0.0f) * sd.inv_smooth_k;
-            const float m = (dd < v) ? dd : v;
-            dd = m - h * h * k * 0.25f;
-        }
-    }
-    return dd;
-}
-
 // Sphere marching.  Lanes leave the loop at different step counts; the loop runs until
 // the wave's last lane is done (no cross-lane compaction inside a bounce: the parked-lane
 // vote of the kernel works at bounce granularity).
@@ -680,7 +647,7 @@ struct MaterialPerHit {
     static constexpr bool kTable = false;
     typedef Mat MatType;
 };
-// A kernel for scenes of at most kMatTableBits primitives (kernels.hip) computes every case once per workgroup, with the same
+// A kernel for scenes of at most kMatTableBits primitives (k_small.hip, k_compact.hip, k_sdf.hip) computes every case once per workgroup, with the same
 // functions, into rows of LDS (material_table_row) and SHADE keeps its row's address: what the BSDF code needs of the material it
 // reads there, where it needs it (dev_bsdf.h, MatRow) — for what was ~45 selects behind uniform branches on the patches' masks, a
 // square root and nine divides per hit, and more inside disney_eval / disney_sample.  The checker itself stays per ray.

@@ -68,7 +68,7 @@ RPT_DEV v3 scale3(v3 a, float f) { return v3{a.x * f, a.y * f, a.z * f}; }      
 //   RPT_MATH_MODE 2 (the shipped strict kernels): the range tests are TRACKERS.  Every operation folds its operands into two words per
 //     lane in LDS with no-return DS min / max — no VALU result to wait for, no vote, no branch: the basic block goes on — and the kernel
 //     looks at them ONCE PER SAMPLE (guard_sample_ok); a sample that saw an operand outside the range is recomputed from its camera
-//     ray with the plain operations (namespace rptplain, "two passes" below; kernels.hip sample_guard).  Per operation that is 2 VALU + 2 DS
+//     ray with the plain operations (namespace rptplain, "two passes" below; kernel_common.h sample_guard).  Per operation that is 2 VALU + 2 DS
 //     where the vote below costs 6 VALU, 3 scalar instructions and a branch that ends the scheduler's block: configs[1] 11.7 -> 12.6
 //     Gsamples/s (round 4; without any test at all: 13.3).
 //       lo_e  min of v_frexp_exp_i32_f32 over every numerator and every root's argument: floor(log2 |x|) + 1 for finite non-zero x
@@ -79,20 +79,20 @@ RPT_DEV v3 scale3(v3 a, float f) { return v3{a.x * f, a.y * f, a.z * f}; }      
 //     so inside a good sample every n is 0, NaN or in [2^-60, 2^60), every d NaN or in (2^-60, 2^60), every root's argument +0 or in
 //     [2^-60, 2^60): inside what the proofs cover.  (+0 under the root: 0 x rsq(0) would be 0 x inf; with rsq clamped it is 0, and so
 //     is the correction.)
-//   RPT_MATH_MODE 1 (A/B builds, -DRPT_AB_KERNELS or -DRPT_GUARD_PER_OP: the forms whose paths change lanes or kernels): the test next
+//   RPT_MATH_MODE 1 (-DRPT_GUARD_PER_OP: k_compact.hip, k_sdf.hip, k_large.hip — kernels whose walks, marches and barriers wait at every step): the test next
 //     to the operation, operands outside the range take hipcc's sequence in the lanes concerned behind a wave vote (rounds 3-4).
 //   RPT_MATH_MODE 0 (namespace rptplain; the relaxed build, where `/` and sqrtf are hipcc's fast ones): the plain operations.
 //
 // TWO PASSES.  dev_math.h, dev_bsdf.h, dev_media.h, dev_integrator.h, dev_scene_large.h (and dev_probes.h) hold FUNCTIONS (and the types
 // only they use) and can be included twice by one translation unit: normally — namespace rptdev, the mode above that the build asks
 // for — and once more under `#define RPT_PLAIN_PASS` + `#define RPT_NS rptplain` — the same functions in RPT_MATH_MODE 0, what a
-// kernel recomputes a flagged sample with (kernels.hip does the second inclusion).  Their include guards are per pass.  The types both
+// kernel recomputes a flagged sample with (kernel_common.h does the second inclusion).  Their include guards are per pass.  The types both
 // passes and the host share are in dev_scene.h, namespace rptscene, which holds no function over them: argument-dependent lookup
 // cannot mix the passes.
 #undef RPT_MATH_MODE
 #if defined(RPT_PLAIN_PASS) || defined(RPT_RELAXED_BUILD) || defined(RPT_PLAIN_MATH)
 #define RPT_MATH_MODE 0
-#elif defined(RPT_AB_KERNELS) || defined(RPT_GUARD_PER_OP)
+#elif defined(RPT_GUARD_PER_OP)
 #define RPT_MATH_MODE 1
 #else
 #define RPT_MATH_MODE 2

@@ -1,6 +1,6 @@
 // dev_probes.h — the bodies of the test probes (include/rpt.h: rpt_probe_math, rpt_probe_fn, rpt_probe_rays): one library function per
 // record, the same device functions the megakernels inline.  Re-includable like the headers it uses (dev_math.h, "two passes"): the probe kernels
-// (kernels.hip) run the normal pass and, for a record whose operands left the range of the short divide / square root (dev_math.h, range
+// (k_probes.hip) run the normal pass and, for a record whose operands left the range of the short divide / square root (dev_math.h, range
 // trackers), the plain pass — as the render kernels do per sample.
 #ifndef RPT_NS                        // (the namespace of this pass: dev_math.h, "two passes")
 #define RPT_NS rptdev

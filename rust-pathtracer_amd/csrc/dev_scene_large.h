@@ -42,12 +42,8 @@ typedef const RPT_CONST_AS uint32_t* cuint_p;
 template <class T>
 RPT_DEV T gather32(const T* table, uint32_t index)
 {
-#ifdef RPT_GATHER_PLAIN
-    return table[index];
-#else
     const uint32_t off = index * (uint32_t)sizeof(T);
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(table) + off);
-#endif
 }
 
 RPT_DEV float4 sphere_uniform(const SceneLarge& sc, uint32_t i)     // i wave-uniform -> scalar load
@@ -180,36 +176,12 @@ RPT_DEV GridWalk grid_begin(const SceneLarge& sc, const RayD& ray)
     return g;
 }
 
-// What grid_begin derives from the ray alone — the steps, the increments, the tier — for a walk whose cell and exit parameters come from
-// somewhere else (a parked walk: kernels.hip, render_large_resume_body).  The same operations on the same operands: the same values.
-RPT_DEV void grid_increments(const SceneLarge& sc, const RayD& ray, GridWalk& g)
-{
-    g.coff = grid_tier(sc, ray);
-    const float d[3] = {ray.d.x, ray.d.y, ray.d.z};
-    int step[3];
-    float tdel[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const bool fwd = d[a] > 0.0f, flat = d[a] == 0.0f;
-        const float inv = __builtin_amdgcn_rcpf(flat ? 1.0f : d[a]);
-        step[a] = flat ? 0 : (fwd ? 1 : -1);
-        tdel[a] = flat ? 3.40282347e+38f : sc.cell_size[a] * __builtin_fabsf(inv);
-    }
-    g.sx = step[0]; g.sy = step[1]; g.sz = step[2];
-    g.tdx = tdel[0]; g.tdy = tdel[1]; g.tdz = tdel[2];
-    g.alive = true;
-}
-
 // cell_start[c], cell_start[c + 1] in one 8-byte load (dword-aligned)
 RPT_DEV void cell_bounds(const SceneLarge& sc, uint32_t c, uint32_t& k0, uint32_t& k1)
 {
-#ifdef RPT_CELL_BOUNDS_TWO_LOADS
-    k0 = sc.cell_start[c]; k1 = sc.cell_start[c + 1];
-#else
     struct __attribute__((packed, aligned(4))) Pair { uint32_t a, b; };
     const Pair r = *reinterpret_cast<const Pair*>(reinterpret_cast<const char*>(sc.cell_start) + c * 4u);      // (a 32-bit byte offset: gather32)
     k0 = r.a; k1 = r.b;
-#endif
 }
 
 RPT_DEV uint32_t grid_cell_index(const SceneLarge& sc, const GridWalk& g)
@@ -222,13 +194,6 @@ RPT_DEV float grid_cell_exit(const GridWalk& g)
 {
     float m = g.tmx < g.tmy ? g.tmx : g.tmy;
     return m < g.tmz ? m : g.tmz;
-}
-
-RPT_DEV void grid_step(const SceneLarge& sc, GridWalk& g)                   // (the wavefront walk and csrc/ab/: a step with its in-range test)
-{
-    if (g.tmx <= g.tmy && g.tmx <= g.tmz) { g.ix += g.sx; g.tmx += g.tdx; g.alive = (g.ix >= 0) && (g.ix < (int)sc.gn[0]); }
-    else if (g.tmy <= g.tmz) { g.iy += g.sy; g.tmy += g.tdy; g.alive = (g.iy >= 0) && (g.iy < (int)sc.gn[1]); }
-    else { g.iz += g.sz; g.tmz += g.tdz; g.alive = (g.iz >= 0) && (g.iz < (int)sc.gn[2]); }
 }
 
 // The megakernel's step (round 4).  Selects, not a three-way branch: every lane of a wave takes its own way, so all three arms ran

@@ -45,17 +45,6 @@ RPT_DEV bool march_step(const DevSdf& sd, v3 origin, MarchRegs& m)
     return (m.t > sd.max_t) || (m.t > m.t_useful);
 }
 
-// march_step with the primitive records in LDS (sdf_eval_lds)
-RPT_DEV bool march_step_lds(const DevSdf& sd, const float4* prims, v3 origin, MarchRegs& m)
-{
-    if (m.steps >= sd.max_steps) return true;
-    float dist = sdf_eval_lds(sd, prims, origin + m.t * m.d);
-    if (dist < sd.hit_eps * m.t) { m.hit = true; return true; }
-    m.t = m.t + dist;
-    m.steps += 1;
-    return (m.t > sd.max_t) || (m.t > m.t_useful);
-}
-
 // Scene queries answered from a finished march.
 struct SdfInjectedQuery {
     SdfMarchResult r;
@@ -111,7 +100,7 @@ RPT_DEV bool march_begin_shadow(const SceneSmallSdf& sc, PathRegs& p, v3 fhp, v3
 
 // ---- two rooms instead of three (render_sdf_march2_kernel) -------------------------------------------------------------
 // The shadow ray of next-event estimation is marched one bounce LATE, right before the next path ray, the way the wavefront
-// form of large scenes walks its shadow rays (dev_wavefront.h): SHADE computes the light sample's contribution as if the
+// form of large scenes walked its shadow rays (rounds 2-4): SHADE computes the light sample's contribution as if the
 // light were visible and parks it; once the shadow march has answered, it is added — or not — before anything else touches
 // the radiance, so the additions and their order are the reference's.  A bounce is then ONE block (finish closest_hit,
 // shade, set up the next ray) between marches, not RESOLVE -> march -> SHADE: two waiting rooms for a 64-lane wave instead of

@@ -18,18 +18,6 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
     __shared__ float s_weight[kMaxSppPerLaunchSdf];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
-#ifdef RPT_SDF_PRIMS_IN_LDS
-    // A/B: the SDF object's primitive records staged in LDS and read from there with broadcast reads
-    // (sdf_eval_lds) instead of through the scalar cache.  Bit-identical and 1.6 % SLOWER on configs[3] (2 973-2 985 against
-    // 3 026-3 031 Msamples/s, two alternating runs each: profiles/r4/experiments/sdf_prims_in_lds.txt): the records then sit in
-    // VGPRs the kernel does not have (9 spilled instead of 8), and an LDS read's latency is no shorter than a scalar-cache hit's.
-    __shared__ float4 s_prims[2 * kMaxSdfPrims];
-    if (threadIdx.x < sc.sdf.n_prims) {                             // (lane_setup's barrier publishes them)
-        const DevSdfPrim& pr = sc.sdf.prims[threadIdx.x];
-        s_prims[2u * threadIdx.x] = make_float4(rpt_u2f(pr.kind), pr.cx, pr.cy, pr.cz);
-        s_prims[2u * threadIdx.x + 1u] = make_float4(pr.p0, pr.p1, 0.0f, 0.0f);
-    }
-#endif
     __shared__ float4 s_march[256];                                 // a lane's march between passes: t, t_useful, steps (bit 31: hit), accepted
                                                                     // analytic primitives (of the path ray's march, also while the shadow ray is marched)
     float4* const s_sho = g_sdf_sho;                                // the parked shadow ray and light sample of each lane (dev_sdf_path.h);
@@ -79,11 +67,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
             for (;;) {
                 if (state <= S2_MARCH_P) {
                     RPT_PROF(PB_CLOSEST);                           // (block profile: one march step of the wave)
-#ifdef RPT_SDF_PRIMS_IN_LDS
-                    if (march_step_lds(sc.sdf, s_prims, mo, m)) {
-#else
                     if (march_step(sc.sdf, mo, m)) {
-#endif
                         if (state == S2_MARCH_S) {
                             lit = !(m.hit && (!use_max || m.t < s_sho[tid].w));      // any_hit_small's SDF term
                             if (ending) state = S2_WAIT;

@@ -32,7 +32,6 @@ VARIANTS = {
     "gridbatch2any2": ["-DRPT_GRID_BATCH=2", "-DRPT_GRID_BATCH_ANY=2"],
     "gridbatch2any4": ["-DRPT_GRID_BATCH=2", "-DRPT_GRID_BATCH_ANY=4"],
     "gridany2": ["-DRPT_GRID_BATCH_ANY=2"],
-    "bounds2loads": ["-DRPT_CELL_BOUNDS_TWO_LOADS"],
     "gridpark": ["-DRPT_GRID_PARK"],
     "parkany": ["-DRPT_GRID_PARK_ANY"],
     "batch3": ["-DRPT_GRID_BATCH=3"],
@@ -43,7 +42,6 @@ VARIANTS = {
     "gridbatch1": ["-DRPT_GRID_BATCH=1", "-DRPT_GRID_BATCH_ANY=1"],
     "compact8": ["-DRPT_COMPACT_WAVES_PER_SIMD=8"],
     # BASELINE.json's "scene/material/light tables staged in LDS": the headline kernel reading its tables from LDS instead of SGPRs
-    "scene_in_lds": ["-DRPT_AB_KERNELS", "-DRPT_SCENE_IN_LDS"],
     "plain_divides": ["-DRPT_PLAIN_DIVIDES"],
     "plain_sqrt": ["-DRPT_PLAIN_SQRT"],
     "scalar_plain": ["-DRPT_SCALAR_DIVIDES_PLAIN"],
@@ -61,7 +59,6 @@ VARIANTS = {
     "pair_w6": ["-DRPT_LARGE_PAIR_WAVES_PER_SIMD=6"],
     # round 4
     "denoise_tile32": ["-DRPT_DENOISE_TILE=32"],              # the denoiser's LDS tiles 32 x 32 (1 024 threads) instead of 16 x 16: halos 1.32 instead of 1.69 loads per pixel
-    "sdf_prims_lds": ["-DRPT_SDF_PRIMS_IN_LDS"],               # the SDF primitive records staged in LDS instead of read through the scalar cache
     # round 4: code-generation options that cannot change a result (scheduling, register allocation, branch shape)
     "cg_early_ifcvt": ["-mllvm", "-amdgpu-early-ifcvt"],
     "cg_wave_prio": ["-mllvm", "-amdgpu-set-wave-priority"],
