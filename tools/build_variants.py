@@ -84,6 +84,7 @@ VARIANTS = {
     "cg_no_cluster": ["-mllvm", "-misched-cluster=0"],
     "cg_exec_pre_ra0": ["-mllvm", "-amdgpu-opt-exec-mask-pre-ra=0"],
     # round 5
+    "perop": ["-DRPT_GUARD_PER_OP"],                           # every kernel with the range tests next to the operation (k_small too): the differential partner of the range trackers (tools/range_soak.py)
     "dn_unfused": ["-DRPT_DENOISE_UNFUSED"],                   # the denoiser one pass per iteration (round 4's form) against the fused first three
     "cg_licm_on": [],        # (built with RPT_TUNING_FLAGS="-mllvm -amdgpu-sched-strategy=max-ilp": machine LICM back on)
 }

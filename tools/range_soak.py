@@ -1,8 +1,8 @@
 """Differential soak of the range trackers (csrc/dev_math.h, RPT_MATH_MODE 2) against the tests per operation: random SMALL scenes — 1-8
 spheres with random full materials (metal, clearcoat, glass), 1-4 lights, depth 1-8, with and without roulette, every length scaled
 by a random power of two between 2^-33 and 2^33 so that none / some / all samples leave the short sequences' range — rendered by the
-library RPT_LIB names, one hash per scene.  Run it once with the shipped library and once with librpt_hip_ab.so (per-operation tests
-throughout) and compare the outputs: they must be identical.   python tools/range_soak.py [n_scenes] [first_seed] [ref]
+library RPT_LIB names, one hash per scene.  Run it once with the shipped library and once with the `perop` variant of tools/build_variants.py (per-operation tests
+throughout: -DRPT_GUARD_PER_OP) and compare the outputs: they must be identical.   python tools/range_soak.py [n_scenes] [first_seed] [ref]
 `ref`: every scene has the reference scene's table sizes (2 spheres, 1 plane, 1 light) and takes the kernels that know them — run once
 as is and once with RPT_NO_SIZED_KERNELS=1."""
 import hashlib
