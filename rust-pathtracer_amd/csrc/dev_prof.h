@@ -37,6 +37,7 @@ enum ProfBlock : uint32_t {
     PB_GRID_RESOLVE,   //   the square-root half of a candidate (either walk)
     PB_WALK_HEAD,      // large scenes: sphere 0, oversize spheres, the grid-or-brute decision before a closest-hit walk
     PB_LIGHTS,         // large scenes: sample_lights' loop over the light spheres
+    PB_ALIVE,          // one pass again, `lanes` = the lanes that still have samples to render, WEIGHTED by the pass's cycles (RPT_PROF_ALIVE)
     PB_COUNT
 };
 
@@ -65,6 +66,8 @@ struct ProfScope {
     uint32_t lanes;
     bool leader;
     uint64_t t0;
+    bool weighted = false;
+    __device__ __forceinline__ ProfScope(uint32_t i, uint32_t alive) : ProfScope(i) { lanes = alive; weighted = true; }
     __device__ __forceinline__ explicit ProfScope(uint32_t i) : id(i)
     {
         const uint64_t ex = __ballot(1);
@@ -78,7 +81,7 @@ struct ProfScope {
         if (leader) {
             uint32_t* c = &s_prof[(threadIdx.x >> 6) * PB_COUNT * 3 + id * 3];
             atomicAdd(c + 0, 1u);
-            atomicAdd(c + 1, lanes);
+            atomicAdd(c + 1, weighted ? (lanes * (uint32_t)(t1 - t0)) >> 6 : lanes);      // weighted: lanes/64 x cycles, against cycles[id]
             atomicAdd(c + 2, (uint32_t)(t1 - t0));
         }
     }
@@ -92,10 +95,12 @@ inline hipError_t prof_read(unsigned long long* out)
     return hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zeros, sizeof(zeros));
 }
 #define RPT_PROF(id) ::rptdev::ProfScope rpt_prof_scope_##id(::rptdev::id)
+#define RPT_PROF_ALIVE(alive) ::rptdev::ProfScope rpt_prof_scope_alive(::rptdev::PB_ALIVE, (alive))
 #define RPT_PROF_INIT() ::rptdev::prof_init()
 #define RPT_PROF_FLUSH() ::rptdev::prof_flush()
 #else
 #define RPT_PROF(id) do { } while (0)
+#define RPT_PROF_ALIVE(alive) do { } while (0)
 #define RPT_PROF_INIT() do { } while (0)
 #define RPT_PROF_FLUSH() do { } while (0)
 #endif

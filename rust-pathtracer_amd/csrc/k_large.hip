@@ -2,7 +2,7 @@
 // (dev_scene_large.h).  Built with the range tests next to every operation (kernel_common.h).
 #include "kernel_common.h"
 
-enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u };
+enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u, ST_BLOCKED = 4u };
 
 // The same kernel with FINISH un-voted at the top of every pass and the background inside TRACE (round 2's schedule): what large
 // scenes and the inline-march SDF form keep — there TRACE carries the grid walks / sphere marches, a lane parked in a finishing room
@@ -16,11 +16,15 @@ RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& launch)
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
+    __shared__ uint32_t s_count[256];                               // share_* (kernel_common.h): each pixel's samples handed out and blended
     const uint32_t tid = threadIdx.x;
+    share_init(s_count, false);                                     // (until the lane is known to have a pixel)
     RenderParams rp;                                                // this workgroup's unit of the launch
     if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
+    share_init(s_count, true);
 
     uint32_t s = 0;
+    uint32_t q = tid;                                               // the pixel this lane renders a sample of: its own while that has any
     uint32_t state = ST_TRACE;
     PathRegs p;
     GeomHit g;                                                      // what a lane waiting for SHADE parks: one dword
@@ -32,21 +36,28 @@ RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& launch)
 
     for (;;) {
         RPT_PROF(PB_PASS);
-        if (state == ST_FINISH) {
+        RPT_PROF_ALIVE((uint32_t)__popcll(__ballot(state != ST_DONE)));
+        const uint32_t own = share_handed_out(s_count);             // (every lane of the wave: who still has samples to hand out)
+        const uint64_t needy = __ballot(own < rp.spp);
+        if (state == ST_FINISH || state == ST_BLOCKED) {
             // blend the finished sample into the running mean and start the next one (or retire); one site for
             // the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
             RPT_PROF(PB_FINISH);
-            float4 acc = s_acc[tid];
-            { const float4 c = s_pix[tid]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
-            blend(acc, p.radiance, s_weight[s]);
-            s_acc[tid] = acc;
-            s += 1;
-            if (s >= rp.spp) {
-                state = ST_DONE;
+            if (!share_my_turn(s_count, q, s)) {
+                state = ST_BLOCKED;                                 // an earlier sample of the pixel is still on its way: asked again every pass
             } else {
-                const float4 c = s_pix[tid];
-                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
-                state = ST_TRACE;
+                float4 acc = s_acc[q];
+                { const float4 c = s_pix[q]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
+                blend(acc, p.radiance, s_weight[s]);
+                s_acc[q] = acc;
+                share_blended(s_count, q);
+                if (!share_next(s_count, rp.spp, own, needy, q, s)) {
+                    state = ST_DONE;
+                } else {
+                    const float4 c = s_pix[q];
+                    path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
+                    state = ST_TRACE;
+                }
             }
         }
         if (state == ST_TRACE) {
@@ -55,7 +66,9 @@ RPT_DEV void render_regen_body_tf(const S& sc, const RenderParams& launch)
         }
         const uint64_t m_shade = __ballot(state == ST_SHADE);
         const uint64_t m_go = __ballot(state == ST_TRACE || state == ST_FINISH);
-        if ((m_shade | m_go) == 0ull) break;
+        // (a blocked lane is in neither vote; it keeps the loop alive: the lane it waited for may have blended in this very pass, after
+        //  both looked at the count)
+        if ((m_shade | m_go | __ballot(state == ST_BLOCKED)) == 0ull) break;
         if ((uint32_t)__popcll(m_shade) >= rp.shade_threshold || m_go == 0ull) {
             if (state == ST_SHADE) {
                 RPT_PROF(PB_SHADE);

@@ -8,7 +8,9 @@
 //   material, light sample (parked), BSDF, next ray -> the marches again.
 // Per wave each pass either marches (while at least `march_min_lanes` lanes are marching, or nobody waits) or runs the block
 // for the lanes that wait.
-enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u };
+// A lane whose pixel has no sample left takes samples of another pixel of its wave (kernel_common.h, share_next; `q`: the pixel a lane
+// works for); a sample that is finished before its predecessor has been blended waits in S2_BLOCKED.
+enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u, S2_BLOCKED = 4u };
 
 template <class MS = MaterialPerHit, class S>
 RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, const MS& materials = MS{})
@@ -23,16 +25,21 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
     float4* const s_sho = g_sdf_sho;                                // the parked shadow ray and light sample of each lane (dev_sdf_path.h);
     float4* const s_shd = g_sdf_shd;                                // gain.w: t_useful of the path ray's march while the shadow ray is marched first
     float4* const s_gain = g_sdf_gain;
+    __shared__ uint32_t s_count[256];                               // share_*: each pixel's samples handed out and blended
     const uint32_t tid = threadIdx.x;
+    share_init(s_count, false);                                     // (until the lane is known to have a pixel)
     RenderParams rp;                                                // this workgroup's unit of the launch
     if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
+    share_init(s_count, true);
 
     uint32_t s = 0;
+    uint32_t q = tid;                                               // the pixel this lane renders a sample of
     uint32_t state = S2_MARCH_P;
     PathRegs p;
     bool pending = false;                                           // a light sample is parked, its shadow ray not answered yet
     bool lit = false;                                               // ... answered: it got through
     bool ending = false;                                            // the path is over once the parked sample is resolved
+    bool blend_only = false;                                        // the sample is complete: it waits for its turn to be blended
     {
         const float4 c = s_pix[tid];
         path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
@@ -44,6 +51,8 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
 
     for (;;) {
         RPT_PROF(PB_PASS);
+        RPT_PROF_ALIVE((uint32_t)__popcll(__ballot(state != S2_DONE)));
+        if (__ballot(state == S2_BLOCKED) != 0ull) { if (state == S2_BLOCKED && share_my_turn(s_count, q, s)) state = S2_WAIT; }
         const uint32_t n_march = (uint32_t)__popcll(__ballot(state <= S2_MARCH_P));
         const uint32_t n_wait = (uint32_t)__popcll(__ballot(state == S2_WAIT));
         if (n_march == 0u && n_wait == 0u) break;
@@ -87,45 +96,53 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                 if (left == 0u || left < rp.march_min_lanes) break;
             }
             if (mine) s_march[tid] = make_float4(m.t, m.t_useful, rpt_u2f(m.steps | (m.hit ? 0x80000000u : 0u)), rpt_u2f(m.accepted));
-        } else if (state == S2_WAIT) {
+        } else {
+          const uint32_t own_started = share_handed_out(s_count);              // (every lane of the wave: who still has samples to hand out)
+          const uint64_t needy = __ballot(own_started < rp.spp);
+          if (state == S2_WAIT) {
             RPT_PROF(PB_SHADE);
             if (pending) {                                          // last bounce's light sample: visible unless its march hit the object
                 if (lit) { const float4 gn = s_gain[tid]; p.radiance = p.radiance + mk3(gn.x, gn.y, gn.z); }
                 pending = false;
             }
-            bool over = ending;
+            bool over = ending || blend_only;
             ending = false;
             if (!over) {
                 GeomHit g;
                 g.code = 0u;
                 const float4 r = s_march[tid];                      // the finished march of the path's ray
-                const SdfDeferredQuery q{{(rpt_f2u(r.z) & 0x80000000u) != 0u, r.x}, AnalyticPre{r.y, rpt_f2u(r.w)}};
-                const uint32_t what = path_trace_geom_split(sc, q, p, g);
+                const SdfDeferredQuery query{{(rpt_f2u(r.z) & 0x80000000u) != 0u, r.x}, AnalyticPre{r.y, rpt_f2u(r.w)}};
+                const uint32_t what = path_trace_geom_split(sc, query, p, g);
                 if (what == 0u) { p.radiance = p.radiance + background(sc, p.ray) * p.throughput; over = true; }
                 else if (what == 1u) over = true;
                 else {
                     // (pending comes back through the parked ray: the query marks it in the slot's direction.w)
                     s_shd[tid].w = 1.0f;
-                    over = path_shade_full(sc, q, p, g, nullptr, nullptr, materials);
+                    over = path_shade_full(sc, query, p, g, nullptr, nullptr, materials);
                     pending = s_shd[tid].w == 0.0f;
                 }
             }
             // what comes next for this lane: [the parked shadow ray] then the path's ray (or the end of the path)
             bool new_ray = !over;
             ending = pending && over;
-            if (over && !pending) {                                 // blend, next sample of the pixel (or retire)
+            if (over && !pending) {                                 // blend, the next sample (or retire)
                 RPT_PROF(PB_FINISH);
-                float4 acc = s_acc[tid];
-                { const float4 c = s_pix[tid]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
-                blend(acc, p.radiance, s_weight[s]);
-                s_acc[tid] = acc;
-                s += 1;
-                if (s >= rp.spp) {
-                    state = S2_DONE;
+                blend_only = !share_my_turn(s_count, q, s);                    // an earlier sample of the pixel is still on its way
+                if (blend_only) {
+                    state = S2_BLOCKED;
                 } else {
-                    const float4 c = s_pix[tid];
-                    path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
-                    new_ray = true;
+                    float4 acc = s_acc[q];
+                    { const float4 c = s_pix[q]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
+                    blend(acc, p.radiance, s_weight[s]);
+                    s_acc[q] = acc;
+                    share_blended(s_count, q);
+                    if (!share_next(s_count, rp.spp, own_started, needy, q, s)) {
+                        state = S2_DONE;
+                    } else {
+                        const float4 c = s_pix[q];
+                        path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
+                        new_ray = true;
+                    }
                 }
             }
             float np_tu = 0.0f;                                     // the path ray's march: t_useful and the accepted analytic primitives
@@ -144,6 +161,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                 s_march[tid] = make_float4(0.0f, np_tu, rpt_u2f(0u), rpt_u2f(np_acc));
                 state = S2_MARCH_P;
             }
+          }
         }
     }
     RPT_PROF_FLUSH();

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void RPT_K(render_small_nested_kernel)(const S
 //    `shade_threshold` lanes are parked (wave ballot + popcount), or nobody is left to trace.  The
 //    expensive block therefore executes with most lanes active, while the cheap one absorbs the
 //    divergence.
-enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_FINISH = 3u, ST_MISS = 4u };
+enum : uint32_t { ST_TRACE = 0u, ST_SHADE = 1u, ST_DONE = 2u, ST_BLOCKED = 3u, ST_FINISH = 4u, ST_MISS = 5u };    // (the finishing room: state >= ST_FINISH)
 
 // Three blocks, two waiting rooms.  TRACE (closest_hit's geometry pass + the emitter exit) runs at once for every lane that has a
 // ray; afterwards each live lane waits in one of two rooms: SHADE (a surface was hit) or FINISH (the path is over: the
@@ -61,11 +61,15 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch, const M&
     __shared__ float s_weight[kMaxSppPerLaunch];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
+    __shared__ uint32_t s_count[256];                               // share_* (kernel_common.h): each pixel's samples handed out and blended
     const uint32_t tid = threadIdx.x;
+    share_init(s_count, false);                                     // (until the lane is known to have a pixel)
     RenderParams rp;                                                // this workgroup's unit of the launch
     if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
+    share_init(s_count, true);
 
     uint32_t s = 0;
+    uint32_t q = tid;                                               // the pixel this lane renders a sample of: its own while that has any
     uint32_t state = ST_TRACE;
     PathRegs p;
     GeomHit g;                                                      // what a lane waiting for SHADE parks: one dword
@@ -77,6 +81,8 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch, const M&
 
     for (;;) {
         RPT_PROF(PB_PASS);
+        RPT_PROF_ALIVE((uint32_t)__popcll(__ballot(state != ST_DONE)));
+        if (__ballot(state == ST_BLOCKED) != 0ull) { if (state == ST_BLOCKED && share_my_turn(s_count, q, s)) state = ST_FINISH; }
         if (state == ST_TRACE) {
             RPT_PROF(PB_TRACE);
             const uint32_t what = path_trace_geom_split(sc, DirectQuery{}, p, g);
@@ -84,30 +90,38 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch, const M&
         }
         const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == ST_SHADE));
         const uint32_t n_fin = (uint32_t)__popcll(__ballot(state >= ST_FINISH));
-        if ((n_shade | n_fin) == 0u) break;
+        if ((n_shade | n_fin) == 0u) break;                         // (a blocked lane waits for one that is in a room)
         if (n_shade >= rp.shade_threshold || (n_fin < rp.finish_threshold && n_shade >= n_fin)) {
             if (state == ST_SHADE) {
                 RPT_PROF(PB_SHADE);
                 state = path_shade_full(sc, DirectQuery{}, p, g, nullptr, nullptr, materials) ? ST_FINISH : ST_TRACE;
             }
-        } else if (state >= ST_FINISH) {
-            // one site for the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
-            if (state == ST_MISS) {
-                RPT_PROF(PB_BACKGROUND);
-                p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
-            }
-            RPT_PROF(PB_FINISH);
-            float4 acc = s_acc[tid];
-            { const float4 c = s_pix[tid]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
-            blend(acc, p.radiance, s_weight[s]);
-            s_acc[tid] = acc;
-            s += 1;
-            if (s >= rp.spp) {
-                state = ST_DONE;
-            } else {
-                const float4 c = s_pix[tid];
-                path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
-                state = ST_TRACE;
+        } else {
+            const uint32_t own = share_handed_out(s_count);         // (every lane of the wave: who still has samples to hand out)
+            const uint64_t needy = __ballot(own < rp.spp);
+            if (state >= ST_FINISH) {
+                // one site for the paths that ended in TRACE (miss, emitter) and in SHADE (pdf <= 0, depth)
+                if (state == ST_MISS) {
+                    RPT_PROF(PB_BACKGROUND);
+                    p.radiance = p.radiance + background(sc, p.ray) * p.throughput;
+                }
+                RPT_PROF(PB_FINISH);
+                if (!share_my_turn(s_count, q, s)) {
+                    state = ST_BLOCKED;                             // an earlier sample of the pixel is still on its way
+                } else {
+                    float4 acc = s_acc[q];
+                    { const float4 c = s_pix[q]; sample_guard<true>(sc, p.radiance, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w)); }
+                    blend(acc, p.radiance, s_weight[s]);
+                    s_acc[q] = acc;
+                    share_blended(s_count, q);
+                    if (!share_next(s_count, rp.spp, own, needy, q, s)) {
+                        state = ST_DONE;
+                    } else {
+                        const float4 c = s_pix[q];
+                        path_begin<true>(sc, p, c.x, c.y, s_fkey[s], rpt_f2u(c.z), rpt_f2u(c.w));
+                        state = ST_TRACE;
+                    }
+                }
             }
         }
     }

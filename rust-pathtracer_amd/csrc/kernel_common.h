@@ -321,9 +321,13 @@ RPT_DEV const S& sized_sdf_scene(const S& s)
 #define RPT_MAX_SPP_PER_LAUNCH 512
 #endif
 constexpr uint32_t kMaxSppPerLaunch = RPT_MAX_SPP_PER_LAUNCH;
-// ... of the SDF march kernel: its workgroup also parks four float4 per lane and keeps a material table (4 KB); 192 entries leave it
-// within the 32 KB that let five workgroups share a CU's LDS
-constexpr uint32_t kMaxSppPerLaunchSdf = RPT_MAX_SPP_PER_LAUNCH < 192 ? RPT_MAX_SPP_PER_LAUNCH : 192;
+// ... of the SDF march kernel: its workgroup also parks four float4 per lane, keeps a material table (4 KB) and counts each pixel's
+// samples (1 KB).  LDS is handed out in pieces of 1 280 B (160 KB / 128; measured, round 5: 31 004 B per workgroup runs five workgroups
+// per CU, 32 028 B four — 26 pieces x 5 > 160 KB), so five workgroups share a CU up to 25 pieces = 32 000 B: 176 entries.
+#ifndef RPT_MAX_SPP_SDF
+#define RPT_MAX_SPP_SDF 176
+#endif
+constexpr uint32_t kMaxSppPerLaunchSdf = RPT_MAX_SPP_PER_LAUNCH < RPT_MAX_SPP_SDF ? RPT_MAX_SPP_PER_LAUNCH : RPT_MAX_SPP_SDF;
 
 // Minimum waves per SIMD the register allocator must leave room for (2nd argument of
 // __launch_bounds__ = waves per SIMD on gfx950); see DESIGN.md for the measurements.
@@ -376,6 +380,36 @@ RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderPa
     const uint32_t pix_a = pcg_hash(ps.pixel_index);
     lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(pix_a), rpt_u2f(pcg_hash(pix_a)));
     sample_guard_begin();
+    return true;
+}
+
+// Sharing a wave's samples among its lanes (round 5).  A lane renders its own pixel's samples one after the other; when they are all
+// handed out it takes samples of ANOTHER pixel of its wave that still has some — a wave's lanes would otherwise wait for its slowest
+// pixel (block profile: 4 % of the lanes' time on configs[1] at 256 spp, 9 % on configs[3], 10 % on 10 k spheres at 32 spp).  Which lane
+// renders a sample never changes it (its random stream is keyed by pixel and frame).  What must not change is the ORDER in which a pixel's
+// samples enter its running mean (tracer.rs:105-117 is sequential): a finished sample s of pixel q is blended only when s - 1 has
+// been; until then its lane waits (a BLOCKED state the kernels count in no vote: the lane that holds s - 1 is in the same wave and
+// never waits for a later sample, so every wait ends).  Per pixel one dword of LDS: samples handed out (low half; the owner's first
+// is handed out at set-up) and samples blended (high half); only the pixel's own wave touches it.
+RPT_DEV void share_init(uint32_t* count, bool has_pixel) { count[threadIdx.x] = has_pixel ? 1u : 0xFFFFu; }
+RPT_DEV uint32_t share_handed_out(const uint32_t* count) { return count[threadIdx.x] & 0xFFFFu; }      // of this lane's own pixel
+RPT_DEV bool share_my_turn(const uint32_t* count, uint32_t q, uint32_t s) { return (count[q] >> 16) == s; }
+RPT_DEV void share_blended(uint32_t* count, uint32_t q) { atomicAdd(&count[q], 0x10000u); }
+// The next sample for a lane that has just blended one: of its own pixel while it has any (`own`: share_handed_out at the top of the
+// block, read by every lane of the wave; `needy`: the ballot of own < spp), else of a pixel of its wave that has.  False: none left.
+RPT_DEV bool share_next(uint32_t* count, uint32_t spp, uint32_t own, uint64_t needy, uint32_t& q, uint32_t& s)
+{
+    const uint32_t tid = threadIdx.x;
+    uint32_t ns = spp, nq = tid;
+    if (own < spp) ns = atomicAdd(&count[tid], 1u) & 0xFFFFu;
+    if (ns >= spp && needy != 0ull) {
+        const uint32_t from = (tid * 13u + 1u) & 63u;               // (lanes start their search at different places)
+        const uint64_t rot = (needy >> from) | ((needy << 1) << (63u - from));
+        nq = (tid & ~63u) | ((from + (uint32_t)__builtin_ctzll(rot)) & 63u);
+        ns = atomicAdd(&count[nq], 1u) & 0xFFFFu;
+    }
+    if (ns >= spp) return false;
+    q = nq; s = ns;
     return true;
 }
 

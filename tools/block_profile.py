@@ -13,7 +13,7 @@ PKG = os.path.join(ROOT, "rust-pathtracer_amd")
 PROF_LIB = os.path.join(PKG, "librpt_hip_prof.so")
 BLOCKS = ["TRACE", "  closest_hit", "  background", "  finalize", "  finish+camera", "SHADE", "  make_frame", "  nee_sample", "  any_hit",
           "  disney_eval", "  disney_sample", "    lobe diffuse", "    lobe clearcoat", "    lobe spec", "  tail", "PASS", "    grid begin", "    grid cell",
-          "    grid cell (shadow)", "      list trip > 1", "      candidate root", "    walk head", "    lights"]
+          "    grid cell (shadow)", "      list trip > 1", "      candidate root", "    walk head", "    lights", "ALIVE"]
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
     spec = importlib.util.spec_from_file_location("_rpt_build", os.path.join(PKG, "build.py"))
@@ -54,4 +54,7 @@ for i, name in enumerate(BLOCKS):
     if ex == 0:
         continue
     denom = pass_cycles
+    if name == "ALIVE":                       # lanes that still have samples to render, averaged over the waves' time
+        print("lanes with samples left, cycle-weighted: %.1f %% (the rest: pixels whose samples are done, waiting for the wave's last)" % (100.0 * ln / cy))
+        continue
     print("%-20s %12d %8.1f%% %7.1f%% %10.3f %12.3f" % (name, ex, 100.0 * ln / (64.0 * ex), 100.0 * cy / denom, 64.0 * ex / n_samples, ln / n_samples))
