@@ -11,6 +11,10 @@
 // A lane whose pixel has no sample left takes samples of another pixel of its wave (kernel_common.h, share_next; `q`: the pixel a lane
 // works for); a sample that is finished before its predecessor has been blended waits in S2_BLOCKED.
 enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u, S2_BLOCKED = 4u };
+// A lane's two marches between passes.  Its shadow march (the lane's own work always): s_march = {t, t_useful, steps, -}.  Its path
+// march, which ANY lane of the wave may run: t in the parked ray's direction.w, t_useful in the parked gain's .w, s_pjob = steps | hit | over;
+// s_march.w: the analytic primitives accepted before it.
+constexpr uint32_t kPjobSteps = 0x1FFFFu, kPjobHit = 1u << 30, kPjobDone = 1u << 31;
 
 template <class MS = MaterialPerHit, class S>
 RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, const MS& materials = MS{})
@@ -20,12 +24,12 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
     __shared__ float s_weight[kMaxSppPerLaunchSdf];
     __shared__ float4 s_acc[256];
     __shared__ float4 s_pix[256];
-    __shared__ float4 s_march[256];                                 // a lane's march between passes: t, t_useful, steps (bit 31: hit), accepted
-                                                                    // analytic primitives (of the path ray's march, also while the shadow ray is marched)
+    __shared__ float4 s_march[256];
     float4* const s_sho = g_sdf_sho;                                // the parked shadow ray and light sample of each lane (dev_sdf_path.h);
-    float4* const s_shd = g_sdf_shd;                                // gain.w: t_useful of the path ray's march while the shadow ray is marched first
+    float4* const s_shd = g_sdf_shd;
     float4* const s_gain = g_sdf_gain;
     __shared__ uint32_t s_count[256];                               // share_*: each pixel's samples handed out and blended
+    __shared__ uint32_t s_pjob[256];                                // kPjob*
     const uint32_t tid = threadIdx.x;
     share_init(s_count, false);                                     // (until the lane is known to have a pixel)
     RenderParams rp;                                                // this workgroup's unit of the launch
@@ -40,12 +44,14 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
     bool lit = false;                                               // ... answered: it got through
     bool ending = false;                                            // the path is over once the parked sample is resolved
     bool blend_only = false;                                        // the sample is complete: it waits for its turn to be blended
+    bool p_done = false;                                            // this lane's path march is over (its own work or a helper's)
     {
         const float4 c = s_pix[tid];
         path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
         MarchRegs m;
         march_begin_primary(sc, p, m);
-        s_march[tid] = make_float4(0.0f, m.t_useful, rpt_u2f(0u), rpt_u2f(m.accepted));
+        s_march[tid] = make_float4(0.0f, 0.0f, rpt_u2f(0u), rpt_u2f(m.accepted));
+        s_shd[tid].w = 0.0f; s_gain[tid].w = m.t_useful; s_pjob[tid] = 0u;
     }
     const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
 
@@ -59,43 +65,94 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
         if (n_march >= rp.march_min_lanes || n_wait == 0u) {
             // Nothing of a march is live in registers across the block: a marching lane takes its march from LDS here and puts it
             // back behind the loop (direction and origin are the path's ray or the parked shadow ray).
-            const bool mine = state <= S2_MARCH_P;
+            // A lane that marches its shadow ray has a SECOND march waiting behind it, its path ray's.  Lanes with nothing to march
+            // (their marches are over, they wait for the block; or they are done) take such marches over: every kHelpEvery steps idle
+            // lanes and waiting path marches are paired by rank, the helper fetches the ray from its owner's registers (ds_bpermute)
+            // and the march's state from the owner's slots, and leaves the outcome — or, when the phase ends first, how far it got — there.
+            // A march is a function of its ray alone: who runs it, and in how many pieces, changes nothing.
+#ifndef RPT_SDF_HELP_EVERY
+#define RPT_SDF_HELP_EVERY 4
+#endif
+#ifndef RPT_SDF_HELP_MIN_IDLE
+#define RPT_SDF_HELP_MIN_IDLE 1
+#endif
+            constexpr uint32_t kHelpEvery = RPT_SDF_HELP_EVERY, kHelpMinIdle = RPT_SDF_HELP_MIN_IDLE;
+            const uint32_t lane = tid & 63u, base = tid & ~63u;
+            uint32_t work = 0u;                                     // 0 idle, 1 the lane's shadow march, 2 a path march: lane `job`'s
+            uint32_t job = tid;
+            bool p_given = false;                                   // this lane's waiting path march is with a helper (for this phase)
+            bool s_over = false;                                    // this lane's shadow march ended in this phase
             MarchRegs m;
             v3 mo = mk3(0.0f, 0.0f, 0.0f);
             m.d = mk3(0.0f, 0.0f, 0.0f); m.t = 0.0f; m.t_useful = 0.0f; m.steps = 0u; m.accepted = 0u; m.hit = false;
-            if (mine) {
-                const float4 r = s_march[tid];
-                m.t = r.x; m.t_useful = r.y; m.steps = rpt_f2u(r.z); m.accepted = rpt_f2u(r.w);
-                if (state == S2_MARCH_S) {
-                    const float4 so = s_sho[tid], sd = s_shd[tid];
-                    mo = mk3(so.x, so.y, so.z); m.d = mk3(sd.x, sd.y, sd.z);
-                } else {
-                    mo = p.ray.o; m.d = p.ray.d;
-                }
+            if (state == S2_MARCH_S) {
+                const float4 r = s_march[tid], so = s_sho[tid], sd = s_shd[tid];
+                m.t = r.x; m.t_useful = r.y; m.steps = rpt_f2u(r.z);
+                mo = mk3(so.x, so.y, so.z); m.d = mk3(sd.x, sd.y, sd.z);
+                work = 1u;
+            } else if (state == S2_MARCH_P) {
+                mo = p.ray.o; m.d = p.ray.d;
+                m.t = s_shd[tid].w; m.t_useful = s_gain[tid].w; m.steps = s_pjob[tid] & kPjobSteps;
+                work = 2u;
             }
-            for (;;) {
-                if (state <= S2_MARCH_P) {
+            for (uint32_t step = 0u;; ++step) {
+                if ((step & (kHelpEvery - 1u)) == 0u) {
+                    const bool offers = work == 1u && !ending && !p_given && !p_done;      // (a path march nobody has started behind a shadow march in flight)
+                    const uint64_t D = __ballot(offers), I = __ballot(work == 0u);
+                    if (D != 0ull && (uint32_t)__popcll(I) >= kHelpMinIdle) {
+                        const uint32_t nD = (uint32_t)__popcll(D), nI = (uint32_t)__popcll(I);
+                        const uint32_t dr = __builtin_amdgcn_mbcnt_hi((uint32_t)(D >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)D, 0u));
+                        const uint32_t ir = __builtin_amdgcn_mbcnt_hi((uint32_t)(I >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)I, 0u));
+                        // lane k receives the lane of the k-th offer (the others push theirs to lane 63, which then is no offer's rank)
+                        const int tbl = __builtin_amdgcn_ds_permute((int)((offers ? dr : 63u) * 4u), (int)lane);
+                        const uint32_t src = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(ir * 4u), tbl) & 63u;
+                        const float ox = rpt_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src * 4u), (int)rpt_f2u(p.ray.o.x)));
+                        const float oy = rpt_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src * 4u), (int)rpt_f2u(p.ray.o.y)));
+                        const float oz = rpt_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src * 4u), (int)rpt_f2u(p.ray.o.z)));
+                        const float dx = rpt_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src * 4u), (int)rpt_f2u(p.ray.d.x)));
+                        const float dy = rpt_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src * 4u), (int)rpt_f2u(p.ray.d.y)));
+                        const float dz = rpt_u2f((uint32_t)__builtin_amdgcn_ds_bpermute((int)(src * 4u), (int)rpt_f2u(p.ray.d.z)));
+                        if (work == 0u && ir < nD) {
+                            job = base + src;
+                            mo = mk3(ox, oy, oz); m.d = mk3(dx, dy, dz);
+                            m.t = s_shd[job].w; m.t_useful = s_gain[job].w; m.steps = s_pjob[job] & kPjobSteps; m.hit = false;
+                            work = 2u;
+                        }
+                        if (offers && dr < nI) p_given = true;
+                    }
+                }
+                if (work != 0u) {
                     RPT_PROF(PB_CLOSEST);                           // (block profile: one march step of the wave)
                     if (march_step(sc.sdf, mo, m)) {
-                        if (state == S2_MARCH_S) {
+                        if (work == 1u) {
                             lit = !(m.hit && (!use_max || m.t < s_sho[tid].w));      // any_hit_small's SDF term
-                            if (ending) state = S2_WAIT;
-                            else {
+                            s_over = true;
+                            work = 0u;
+                            if (!ending && !p_given && !p_done) {
                                 // the path ray's march, prepared by the block (march_begin_primary's analytic part is ~400
-                                // instructions: it must not run here, for the one lane of the wave whose shadow march just ended)
-                                march_begin(m, p.ray.d, s_gain[tid].w);     // (m.accepted is the path ray's already)
-                                mo = p.ray.o;
-                                state = S2_MARCH_P;
+                                // instructions: it must not run here, for the one lane of the wave whose shadow march just ended);
+                                // from where a helper of an earlier phase left it
+                                job = tid;
+                                mo = p.ray.o; m.d = p.ray.d;
+                                m.t = s_shd[tid].w; m.t_useful = s_gain[tid].w; m.steps = s_pjob[tid] & kPjobSteps; m.hit = false;
+                                work = 2u;
                             }
                         } else {
-                            state = S2_WAIT;
+                            s_shd[job].w = m.t; s_pjob[job] = m.steps | (m.hit ? kPjobHit : 0u) | kPjobDone;
+                            work = 0u;
                         }
                     }
                 }
-                const uint32_t left = (uint32_t)__popcll(__ballot(state <= S2_MARCH_P));
+                const uint32_t left = (uint32_t)__popcll(__ballot(work != 0u));
                 if (left == 0u || left < rp.march_min_lanes) break;
             }
-            if (mine) s_march[tid] = make_float4(m.t, m.t_useful, rpt_u2f(m.steps | (m.hit ? 0x80000000u : 0u)), rpt_u2f(m.accepted));
+            // what is unfinished goes back to its slot; then every lane learns where its own marches stand
+            if (work == 1u) { s_march[tid].x = m.t; s_march[tid].z = rpt_u2f(m.steps); }
+            if (work == 2u) { s_shd[job].w = m.t; s_pjob[job] = m.steps; }
+            if (state <= S2_MARCH_P) {
+                p_done = (s_pjob[tid] & kPjobDone) != 0u;
+                if (state == S2_MARCH_P || s_over) state = (p_done || ending) ? S2_WAIT : S2_MARCH_P;
+            }
         } else {
           const uint32_t own_started = share_handed_out(s_count);              // (every lane of the wave: who still has samples to hand out)
           const uint64_t needy = __ballot(own_started < rp.spp);
@@ -110,8 +167,8 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
             if (!over) {
                 GeomHit g;
                 g.code = 0u;
-                const float4 r = s_march[tid];                      // the finished march of the path's ray
-                const SdfDeferredQuery query{{(rpt_f2u(r.z) & 0x80000000u) != 0u, r.x}, AnalyticPre{r.y, rpt_f2u(r.w)}};
+                // the finished march of the path's ray
+                const SdfDeferredQuery query{{(s_pjob[tid] & kPjobHit) != 0u, s_shd[tid].w}, AnalyticPre{s_gain[tid].w, rpt_f2u(s_march[tid].w)}};
                 const uint32_t what = path_trace_geom_split(sc, query, p, g);
                 if (what == 0u) { p.radiance = p.radiance + background(sc, p.ray) * p.throughput; over = true; }
                 else if (what == 1u) over = true;
@@ -153,13 +210,15 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                 np_tu = sdf_primary_t_useful(sc, ah);
                 np_acc = ah.accepted;
             }
-            if (pending) {
-                s_march[tid] = make_float4(0.0f, sdf_shadow_t_useful(sc, s_sho[tid].w), rpt_u2f(0u), rpt_u2f(np_acc));
-                s_gain[tid].w = np_tu;
-                state = S2_MARCH_S;
-            } else if (new_ray) {
-                s_march[tid] = make_float4(0.0f, np_tu, rpt_u2f(0u), rpt_u2f(np_acc));
+            if (new_ray) {
+                s_march[tid].w = rpt_u2f(np_acc);
+                s_shd[tid].w = 0.0f; s_gain[tid].w = np_tu; s_pjob[tid] = 0u;
+                p_done = false;
                 state = S2_MARCH_P;
+            }
+            if (pending) {
+                s_march[tid].x = 0.0f; s_march[tid].y = sdf_shadow_t_useful(sc, s_sho[tid].w); s_march[tid].z = rpt_u2f(0u);
+                state = S2_MARCH_S;
             }
           }
         }

@@ -323,9 +323,10 @@ RPT_DEV const S& sized_sdf_scene(const S& s)
 constexpr uint32_t kMaxSppPerLaunch = RPT_MAX_SPP_PER_LAUNCH;
 // ... of the SDF march kernel: its workgroup also parks four float4 per lane, keeps a material table (4 KB) and counts each pixel's
 // samples (1 KB).  LDS is handed out in pieces of 1 280 B (160 KB / 128; measured, round 5: 31 004 B per workgroup runs five workgroups
-// per CU, 32 028 B four — 26 pieces x 5 > 160 KB), so five workgroups share a CU up to 25 pieces = 32 000 B: 176 entries.
+// per CU, 32 028 B four — 26 pieces x 5 > 160 KB), so five workgroups share a CU up to 25 pieces = 32 000 B: 96 entries
+// (the kernel also keeps a dword per lane for marches handed from lane to lane).
 #ifndef RPT_MAX_SPP_SDF
-#define RPT_MAX_SPP_SDF 176
+#define RPT_MAX_SPP_SDF 96
 #endif
 constexpr uint32_t kMaxSppPerLaunchSdf = RPT_MAX_SPP_PER_LAUNCH < RPT_MAX_SPP_SDF ? RPT_MAX_SPP_PER_LAUNCH : RPT_MAX_SPP_SDF;
 
