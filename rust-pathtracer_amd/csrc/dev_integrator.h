@@ -141,6 +141,16 @@ RPT_DEV float sdf_prim(const DevSdfPrim& pr, v3 p)
 // A primitive's record as the two scalar loads it is laid out for (dev_scene.h, DevSdfPrim): {cx, cy, cz, p0} and {p1, kind}, both
 // requested before anything is computed.  (Left to itself the compiler fetches the fields one by one, each right before its use and
 // each behind its own wait: it is saving scalar registers.)
+// One primitive's distance from its record's values.
+RPT_DEV float sdf_prim_value(float cx, float cy, float cz, float p0, float p1, uint32_t kind, v3 p)
+{
+    const v3 q = p - mk3(cx, cy, cz);
+    if (kind == RPT_SDF_TORUS_Y) {
+        const float qx = fsqrt(q.x * q.x + q.z * q.z) - p0;
+        return fsqrt(qx * qx + q.y * q.y) - p1;
+    }
+    return len3(q) - p0;
+}
 RPT_DEV float sdf_prim_at(const DevSdf& sd, uint32_t i, v3 p)
 {
     typedef float rpt_f4 __attribute__((ext_vector_type(4)));
@@ -148,24 +158,54 @@ RPT_DEV float sdf_prim_at(const DevSdf& sd, uint32_t i, v3 p)
     const RPT_CONST_AS char* rec = (const RPT_CONST_AS char*)&sd.prims[i];
     const rpt_f4 a = *(const RPT_CONST_AS rpt_f4*)rec;
     const rpt_f2 b = *(const RPT_CONST_AS rpt_f2*)(rec + 16);
-    const v3 q = p - mk3(a.x, a.y, a.z);
-    if (rpt_f2u(b.y) == RPT_SDF_TORUS_Y) {
-        const float qx = fsqrt(q.x * q.x + q.z * q.z) - a.w;
-        return fsqrt(qx * qx + q.y * q.y) - b.x;
-    }
-    return len3(q) - a.w;
+    return sdf_prim_value(a.x, a.y, a.z, a.w, b.x, rpt_f2u(b.y), p);
+}
+// the smooth union's step: the object so far (dd) and one more primitive (b)
+RPT_DEV float sdf_smooth_union(float dd, float b, float k, float inv_k)
+{
+    float h = rmax(k - __builtin_fabsf(dd - b), 0.0f) * inv_k;
+    float m = (dd < b) ? dd : b;
+    return m - h * h * k * 0.25f;
 }
 
 RPT_DEV float sdf_eval(const DevSdf& sd, v3 p)
 {
     const float k = sd.smooth_k;
     float dd = sdf_prim_at(sd, 0u, p);
-    for (uint32_t i = 1; i < sd.n_prims; ++i) {
-        float b = sdf_prim_at(sd, i, p);
-        float h = rmax(k - __builtin_fabsf(dd - b), 0.0f) * sd.inv_smooth_k;
-        float m = (dd < b) ? dd : b;
-        dd = m - h * h * k * 0.25f;
+    for (uint32_t i = 1; i < sd.n_prims; ++i) dd = sdf_smooth_union(dd, sdf_prim_at(sd, i, p), k, sd.inv_smooth_k);
+    return dd;
+}
+
+// The object's records held in scalar registers across a loop of evaluations (a march phase of k_sdf.hip's kernels that know the number
+// of primitives): sdf_eval above fetches every record again at every evaluation, three scalar loads each behind its own wait per march
+// step for three primitives.  Same values, same operations.
+template <uint32_t N>
+struct SdfRegs {
+    float k, inv_k;
+    float cx[N], cy[N], cz[N], p0[N], p1[N];
+    uint32_t kind[N];
+};
+template <uint32_t N>
+RPT_DEV void sdf_regs_load(const DevSdf& sd, SdfRegs<N>& r)
+{
+    typedef float rpt_f4 __attribute__((ext_vector_type(4)));
+    typedef float rpt_f2 __attribute__((ext_vector_type(2)));
+    r.k = uniform_here(sd.smooth_k); r.inv_k = uniform_here(sd.inv_smooth_k);
+#pragma unroll
+    for (uint32_t i = 0; i < N; ++i) {
+        const RPT_CONST_AS char* rec = (const RPT_CONST_AS char*)&sd.prims[i];
+        const rpt_f4 a = *(const RPT_CONST_AS rpt_f4*)rec;
+        const rpt_f2 b = *(const RPT_CONST_AS rpt_f2*)(rec + 16);
+        r.cx[i] = uniform_here(a.x); r.cy[i] = uniform_here(a.y); r.cz[i] = uniform_here(a.z); r.p0[i] = uniform_here(a.w);
+        r.p1[i] = uniform_here(b.x); r.kind[i] = uniform_here(rpt_f2u(b.y));
     }
+}
+template <uint32_t N>
+RPT_DEV float sdf_eval(const SdfRegs<N>& r, v3 p)
+{
+    float dd = sdf_prim_value(r.cx[0], r.cy[0], r.cz[0], r.p0[0], r.p1[0], r.kind[0], p);
+#pragma unroll
+    for (uint32_t i = 1; i < N; ++i) dd = sdf_smooth_union(dd, sdf_prim_value(r.cx[i], r.cy[i], r.cz[i], r.p0[i], r.p1[i], r.kind[i], p), r.k, r.inv_k);
     return dd;
 }
 

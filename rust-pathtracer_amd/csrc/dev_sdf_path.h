@@ -34,16 +34,19 @@ RPT_DEV void march_begin(MarchRegs& m, v3 dir, float t_useful)
     m.hit = false;
 }
 
-// One iteration of sdf_march()'s loop; true when the march is over (m.hit / m.t hold its result).
-RPT_DEV bool march_step(const DevSdf& sd, v3 origin, MarchRegs& m)
+// One iteration of sdf_march()'s loop; true when the march is over (m.hit / m.t hold its result).  `eval`: the object — a DevSdf, or
+// its records in registers (SdfRegs).
+template <class E>
+RPT_DEV bool march_step(const DevSdf& sd, const E& eval, v3 origin, MarchRegs& m)
 {
     if (m.steps >= sd.max_steps) return true;
-    float dist = sdf_eval(sd, origin + m.t * m.d);
+    float dist = sdf_eval(eval, origin + m.t * m.d);
     if (dist < sd.hit_eps * m.t) { m.hit = true; return true; }
     m.t = m.t + dist;
     m.steps += 1;
     return (m.t > sd.max_t) || (m.t > m.t_useful);
 }
+RPT_DEV bool march_step(const DevSdf& sd, v3 origin, MarchRegs& m) { return march_step(sd, sd, origin, m); }
 
 // Scene queries answered from a finished march.
 struct SdfInjectedQuery {

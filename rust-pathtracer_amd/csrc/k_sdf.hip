@@ -16,7 +16,7 @@ enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u, 
 // s_march.w: the analytic primitives accepted before it.
 constexpr uint32_t kPjobSteps = 0x1FFFFu, kPjobHit = 1u << 30, kPjobDone = 1u << 31;
 
-template <class MS = MaterialPerHit, class S>
+template <uint32_t NPRIMS = 0u, class MS = MaterialPerHit, class S>
 RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, const MS& materials = MS{})
 {
     RPT_PROF_INIT();
@@ -95,6 +95,9 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                 m.t = s_shd[tid].w; m.t_useful = s_gain[tid].w; m.steps = s_pjob[tid] & kPjobSteps;
                 work = 2u;
             }
+            // (a kernel that knows the number of primitives keeps their records in scalar registers for the phase)
+            SdfRegs<(NPRIMS != 0u ? NPRIMS : 1u)> sdf_regs;
+            if constexpr (NPRIMS != 0u) sdf_regs_load(sc.sdf, sdf_regs);
             for (uint32_t step = 0u;; ++step) {
                 if ((step & (kHelpEvery - 1u)) == 0u) {
                     const bool offers = work == 1u && !ending && !p_given && !p_done;      // (a path march nobody has started behind a shadow march in flight)
@@ -123,7 +126,10 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                 }
                 if (work != 0u) {
                     RPT_PROF(PB_CLOSEST);                           // (block profile: one march step of the wave)
-                    if (march_step(sc.sdf, mo, m)) {
+                    bool over;
+                    if constexpr (NPRIMS != 0u) over = march_step(sc.sdf, sdf_regs, mo, m);
+                    else over = march_step(sc.sdf, mo, m);
+                    if (over) {
                         if (work == 1u) {
                             lit = !(m.hit && (!use_max || m.t < s_sho[tid].w));      // any_hit_small's SDF term
                             s_over = true;
@@ -232,7 +238,7 @@ void RPT_K(render_sdf_march2_kernel)(const SceneSmallSdf sc, const RenderParams 
 #ifndef RPT_RELAXED_BUILD
 template <uint32_t NPRIMS>
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD)
-void RPT_K(render_sdf_march2_sized_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body(sized_sdf_scene<NPRIMS>(kernarg_scene(sc)), rp); }
+void RPT_K(render_sdf_march2_sized_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body<NPRIMS>(sized_sdf_scene<NPRIMS>(kernarg_scene(sc)), rp); }
 // ... with the material table (dev_integrator.h, MaterialTable): at most one analytical sphere beside the plane and the object
 template <uint32_t NPRIMS>
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD)
@@ -240,7 +246,7 @@ void RPT_K(render_sdf_march2_sized_table_kernel)(const SceneSmallSdf sc, const R
 {
     __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
     const SceneSmallSdf& s = sized_sdf_scene<NPRIMS>(kernarg_scene(sc));
-    render_sdf_march2_body(s, rp, material_table_build<true>(s, s.n_spheres, 1u, s_rows));
+    render_sdf_march2_body<NPRIMS>(s, rp, material_table_build<true>(s, s.n_spheres, 1u, s_rows));
 }
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march2_body(kernarg_scene(sc), rp); }
 #endif
