@@ -354,13 +354,13 @@ def headline_variants(rpt, torch, device, small):
         t_strict = timed_steps(torch, strict, tbuf, spp, 5)
         out["relaxed"] = {"value": round(w * h * spp / t_fast / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(t_fast * 1e3, 3),
                           "strict_value_same_run": round(w * h * spp / t_strict / 1e6, 2),
-                          "kernel": "render_small_regen_kernel_fast", "flags": "RPT_RENDER_FAST_MATH",
+                          "kernel": "render_small_regen_sized_table_kernel_fast", "flags": "RPT_RENDER_FAST_MATH",
                           "rmse_vs_strict": rmse, "pixels_over_1e-4": outliers, "pixels_bit_identical": same, "pixels": w * h,
                           "max_abs_delta": float(dd.abs().max().item()),
                           "workload": "AnalyticalScene %dx%d, both frames after %d spp from an empty buffer, seed 1" % (w, h, spp),
-                          "note": "NOT the headline arithmetic: v_rcp / v_rsq based divide and sqrt (~2.5 ulp) and FMA contraction; the relaxed "
-                                  "build has no sized / material-table instantiation, so compare with general_kernels.value for the price of "
-                                  "the correctly rounded operations alone"}
+                          "note": "NOT the headline arithmetic: v_rcp / v_rsq based divide and sqrt (~2.5 ulp) and FMA contraction, in the same "
+                                  "instantiation as the headline (sized tables, material table: since round 5); strict_value_same_run / value "
+                                  "is the price of the correctly rounded operations"}
         strict.close(); fast.close()
     except Exception as e:      # noqa: BLE001
         out["relaxed"] = {"error": "%s: %s" % (type(e).__name__, e)}

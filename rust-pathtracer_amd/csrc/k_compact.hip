@@ -183,7 +183,6 @@ __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_
 // in scratch (116 B per lane, L1/L2-resident at this launch size) — and it is worth it: 800x600 x 1 spp 0.0809 ms against 0.0914
 // with five per CU and no spill to speak of (round 4, tools/compact_time.py); from 1080p up the five-per-CU build is 1 % faster.
 __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_kernel)(const SceneSmall sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
-#ifndef RPT_RELAXED_BUILD
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_sized_kernel)(const SceneSmall sc, const RenderParams rp)
 {
     render_compact_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
@@ -207,6 +206,7 @@ __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_sized
     const SceneSmall& s = sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc));
     render_compact_body(s, rp, material_table_build<false>(s, sizes[0], sizes[1], s_rows));
 }
+#ifndef RPT_RELAXED_BUILD                                           // (media have no relaxed form)
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
 #endif
 
@@ -217,18 +217,17 @@ hipError_t render_compact(const SceneSmall& sc, bool media, const RenderParams& 
     const dim3 tiles(nblocks), wg(256);
     (void)hipGetLastError();
     const bool dense = nblocks <= 3072u;                             // (six workgroups per CU: see render_small_compact_dense_kernel)
+    if (media) {
 #ifdef RPT_RELAXED_BUILD
-    (void)kc;
-    if (media) return hipErrorNotSupported;
+        return hipErrorNotSupported;
 #else
-    if (media) hipLaunchKernelGGL(RPT_K(render_small_compact_media_kernel), tiles, wg, 0, st, WithMedia<SceneSmall>(sc), rp);
-    else if (dense && kc.sized && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_sized_table_kernel), tiles, wg, 0, st, sc, rp);
+        hipLaunchKernelGGL(RPT_K(render_small_compact_media_kernel), tiles, wg, 0, st, WithMedia<SceneSmall>(sc), rp);
+#endif
+    } else if (dense && kc.sized && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_sized_table_kernel), tiles, wg, 0, st, sc, rp);
     else if (kc.sized && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_compact_sized_table_kernel), tiles, wg, 0, st, sc, rp);
     else if (dense && kc.sized) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_sized_kernel), tiles, wg, 0, st, sc, rp);
     else if (kc.sized) hipLaunchKernelGGL(RPT_K(render_small_compact_sized_kernel), tiles, wg, 0, st, sc, rp);
-    else
-#endif
-    if (dense) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
+    else if (dense) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
     else hipLaunchKernelGGL(RPT_K(render_small_compact_kernel), tiles, wg, 0, st, sc, rp);
     return hipGetLastError();
 }

@@ -235,7 +235,6 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
 
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD)
 void RPT_K(render_sdf_march2_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body(kernarg_scene(sc), rp); }
-#ifndef RPT_RELAXED_BUILD
 template <uint32_t NPRIMS>
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD)
 void RPT_K(render_sdf_march2_sized_kernel)(const SceneSmallSdf sc, const RenderParams rp) { render_sdf_march2_body<NPRIMS>(sized_sdf_scene<NPRIMS>(kernarg_scene(sc)), rp); }
@@ -248,6 +247,7 @@ void RPT_K(render_sdf_march2_sized_table_kernel)(const SceneSmallSdf sc, const R
     const SceneSmallSdf& s = sized_sdf_scene<NPRIMS>(kernarg_scene(sc));
     render_sdf_march2_body<NPRIMS>(s, rp, material_table_build<true>(s, s.n_spheres, 1u, s_rows));
 }
+#ifndef RPT_RELAXED_BUILD                                           // (media have no relaxed form)
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march2_body(kernarg_scene(sc), rp); }
 #endif
 
@@ -264,12 +264,13 @@ hipError_t render_sdf(const SceneSmallSdf& scs, bool media, const RenderParams& 
 {
     const dim3 tiles(nblocks), wg(256);
     (void)hipGetLastError();
+    if (media) {
 #ifdef RPT_RELAXED_BUILD
-    (void)kc;
-    if (media) return hipErrorNotSupported;
+        return hipErrorNotSupported;
 #else
-    if (media) hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, WithMedia<SceneSmallSdf>(scs), rp);
-    else if (kc.sized_sdf == 1u && kc.material_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<1u>, tiles, wg, 0, st, scs, rp);
+        hipLaunchKernelGGL(RPT_K(render_sdf_march2_media_kernel), tiles, wg, 0, st, WithMedia<SceneSmallSdf>(scs), rp);
+#endif
+    } else if (kc.sized_sdf == 1u && kc.material_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<1u>, tiles, wg, 0, st, scs, rp);
     else if (kc.sized_sdf == 2u && kc.material_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<2u>, tiles, wg, 0, st, scs, rp);
     else if (kc.sized_sdf == 3u && kc.material_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<3u>, tiles, wg, 0, st, scs, rp);
     else if (kc.sized_sdf == 4u && kc.material_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_table_kernel)<4u>, tiles, wg, 0, st, scs, rp);
@@ -277,9 +278,7 @@ hipError_t render_sdf(const SceneSmallSdf& scs, bool media, const RenderParams& 
     else if (kc.sized_sdf == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<2u>, tiles, wg, 0, st, scs, rp);
     else if (kc.sized_sdf == 3u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<3u>, tiles, wg, 0, st, scs, rp);
     else if (kc.sized_sdf == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<4u>, tiles, wg, 0, st, scs, rp);
-    else
-#endif
-    hipLaunchKernelGGL(RPT_K(render_sdf_march2_kernel), tiles, wg, 0, st, scs, rp);
+    else hipLaunchKernelGGL(RPT_K(render_sdf_march2_kernel), tiles, wg, 0, st, scs, rp);
     return hipGetLastError();
 }
 

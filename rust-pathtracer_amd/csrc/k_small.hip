@@ -133,7 +133,6 @@ RPT_DEV void render_regen_body(const S& sc, const RenderParams& launch, const M&
 #define RPT_SMALL_WAVES_PER_SIMD RPT_WAVES_PER_SIMD
 #endif
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_kernel)(const SceneSmall sc, const RenderParams rp) { render_regen_body(kernarg_scene(sc), rp); }
-#ifndef RPT_RELAXED_BUILD
 // ... and that reads a hit's material from a table of the 2^(2 + 1 + 2) cases there are (dev_integrator.h, MaterialTable).
 // RPT_NO_MATERIAL_TABLE=1: the kernel below it.
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_sized_table_kernel)(const SceneSmall sc, const RenderParams rp)
@@ -147,6 +146,7 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 {
     render_regen_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
 }
+#ifndef RPT_RELAXED_BUILD                                           // (media have no relaxed form)
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_regen_body(kernarg_scene(sc), rp); }
 #endif
 
@@ -156,20 +156,17 @@ hipError_t render_small(const SceneSmall& sc, bool media, bool nested, const Ren
 {
     const dim3 tiles(nblocks), wg(256);
     (void)hipGetLastError();                                         // the thread's sticky error may be somebody else's (a host process's own HIP calls)
-#ifdef RPT_RELAXED_BUILD
-    (void)kc;
-    if (media) return hipErrorNotSupported;                          // (media have no relaxed form)
-    if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
-    else hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, 0, st, sc, rp);
-#else
     if (media) {
+#ifdef RPT_RELAXED_BUILD
+        return hipErrorNotSupported;                                 // (media have no relaxed form)
+#else
         if (nested) return hipErrorNotSupported;
         hipLaunchKernelGGL(RPT_K(render_small_regen_media_kernel), tiles, wg, 0, st, WithMedia<SceneSmall>(sc), rp);
+#endif
     } else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
     else if (kc.sized && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_table_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     else if (kc.sized) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     else hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
-#endif
     return hipGetLastError();
 }
 
