@@ -62,6 +62,8 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
         const uint32_t n_march = (uint32_t)__popcll(__ballot(state <= S2_MARCH_P));
         const uint32_t n_wait = (uint32_t)__popcll(__ballot(state == S2_WAIT));
         if (n_march == 0u && n_wait == 0u) break;
+        const uint32_t own_started = share_handed_out(s_count);     // (every lane of the wave: who still has samples to hand out)
+        const uint64_t needy = __ballot(own_started < rp.spp);
         if (n_march >= rp.march_min_lanes || n_wait == 0u) {
             // Nothing of a march is live in registers across the block: a marching lane takes its march from LDS here and puts it
             // back behind the loop (direction and origin are the path's ray or the parked shadow ray).
@@ -159,10 +161,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                 p_done = (s_pjob[tid] & kPjobDone) != 0u;
                 if (state == S2_MARCH_P || s_over) state = (p_done || ending) ? S2_WAIT : S2_MARCH_P;
             }
-        } else {
-          const uint32_t own_started = share_handed_out(s_count);              // (every lane of the wave: who still has samples to hand out)
-          const uint64_t needy = __ballot(own_started < rp.spp);
-          if (state == S2_WAIT) {
+        } else if (state == S2_WAIT) {
             RPT_PROF(PB_SHADE);
             if (pending) {                                          // last bounce's light sample: visible unless its march hit the object
                 if (lit) { const float4 gn = s_gain[tid]; p.radiance = p.radiance + mk3(gn.x, gn.y, gn.z); }
@@ -226,7 +225,6 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                 s_march[tid].x = 0.0f; s_march[tid].y = sdf_shadow_t_useful(sc, s_sho[tid].w); s_march[tid].z = rpt_u2f(0u);
                 state = S2_MARCH_S;
             }
-          }
         }
     }
     RPT_PROF_FLUSH();
