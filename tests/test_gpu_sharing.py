@@ -87,3 +87,27 @@ def test_the_same_frame_twice(rpt, torch_cuda):
             t.close()
         assert np.array_equal(images[0].view(np.uint32), images[1].view(np.uint32))
         assert np.array_equal(images[0].view(np.uint32), images[2].view(np.uint32))
+
+
+@pytest.mark.parametrize("knobs", [
+    {"RPT_SHADE_THRESHOLD": "1", "RPT_FINISH_THRESHOLD": "1", "RPT_SDF_MARCH_MIN_LANES": "1"},
+    {"RPT_SHADE_THRESHOLD": "64", "RPT_FINISH_THRESHOLD": "64", "RPT_SDF_MARCH_MIN_LANES": "64"},
+    {"RPT_SHADE_THRESHOLD": "64", "RPT_FINISH_THRESHOLD": "1", "RPT_SDF_MARCH_MIN_LANES": "33"},
+    {"RPT_UNIT_ROUNDS": "100000", "RPT_UNIT_MIN_SPP": "1"},          # every sample a chunk of its own, handed from workgroup to workgroup
+    {"RPT_UNIT_ROUNDS": "100000", "RPT_UNIT_MIN_SPP": "3", "RPT_DISPATCH_ORDER": "0"},
+])
+def test_the_scheduling_knobs_at_their_ends(rpt, oracle, monkeypatch, knobs):
+    """Blocked lanes, helpers and hand-offs under every vote the kernels can take: thresholds at 1 and at 64 (a room runs as soon as
+    one lane waits / only when all do), chunks of one sample.  None of it may change a pixel."""
+    from rust_pathtracer_amd import scenes
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    rpt.lib().rpt_debug_reload_knobs()
+    for make, w, h, spp in ((rpt.AnalyticalScene, 37, 21, 11), (scenes.sdf_scene, 29, 18, 7), (lambda: scenes.random_spheres_scene(300, 3), 24, 20, 6)):
+        s = make()
+        t = rpt.Tracer(s, device=0, seed=12)
+        buf = rpt.ColorBuffer(w, h)
+        t.render_n(buf, spp)
+        want = oracle.render(s.describe(), w, h, spp, seed=12)
+        assert_bit_identical(buf.image(), want, "knobs %s, %s" % (knobs, type(s).__name__))
+        t.close()
