@@ -206,6 +206,19 @@ __global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_sized
     const SceneSmall& s = sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc));
     render_compact_body(s, rp, material_table_build<false>(s, sizes[0], sizes[1], s_rows));
 }
+// ... for any scene of at most three primitives: the table's shape is data
+__global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_table_kernel)(const SceneSmall sc, const RenderParams rp)
+{
+    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
+    const SceneSmall& s = kernarg_scene(sc);
+    render_compact_body(s, rp, material_table_build<false>(s, uniform_here(s.n_spheres), uniform_here(s.n_planes), s_rows));
+}
+__global__ __launch_bounds__(256, 6) void RPT_K(render_small_compact_dense_table_kernel)(const SceneSmall sc, const RenderParams rp)
+{
+    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
+    const SceneSmall& s = kernarg_scene(sc);
+    render_compact_body(s, rp, material_table_build<false>(s, uniform_here(s.n_spheres), uniform_here(s.n_planes), s_rows));
+}
 #ifndef RPT_RELAXED_BUILD                                           // (media have no relaxed form)
 __global__ __launch_bounds__(256, RPT_COMPACT_WAVES_PER_SIMD) void RPT_K(render_small_compact_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_compact_body(kernarg_scene(sc), rp); }
 #endif
@@ -227,6 +240,8 @@ hipError_t render_compact(const SceneSmall& sc, bool media, const RenderParams& 
     else if (kc.sized && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_compact_sized_table_kernel), tiles, wg, 0, st, sc, rp);
     else if (dense && kc.sized) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_sized_kernel), tiles, wg, 0, st, sc, rp);
     else if (kc.sized) hipLaunchKernelGGL(RPT_K(render_small_compact_sized_kernel), tiles, wg, 0, st, sc, rp);
+    else if (dense && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_table_kernel), tiles, wg, 0, st, sc, rp);
+    else if (kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_compact_table_kernel), tiles, wg, 0, st, sc, rp);
     else if (dense) hipLaunchKernelGGL(RPT_K(render_small_compact_dense_kernel), tiles, wg, 0, st, sc, rp);
     else hipLaunchKernelGGL(RPT_K(render_small_compact_kernel), tiles, wg, 0, st, sc, rp);
     return hipGetLastError();

@@ -245,6 +245,14 @@ void RPT_K(render_sdf_march2_sized_table_kernel)(const SceneSmallSdf sc, const R
     const SceneSmallSdf& s = sized_sdf_scene<NPRIMS>(kernarg_scene(sc));
     render_sdf_march2_body<NPRIMS>(s, rp, material_table_build<true>(s, s.n_spheres, 1u, s_rows));
 }
+// ... for any scene of at most three primitives, the object included: the table's shape is data
+__global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD)
+void RPT_K(render_sdf_march2_table_kernel)(const SceneSmallSdf sc, const RenderParams rp)
+{
+    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
+    const SceneSmallSdf& s = kernarg_scene(sc);
+    render_sdf_march2_body(s, rp, material_table_build<true>(s, uniform_here(s.n_spheres), uniform_here(s.n_planes), s_rows));
+}
 #ifndef RPT_RELAXED_BUILD                                           // (media have no relaxed form)
 __global__ __launch_bounds__(256, RPT_SDF_WAVES_PER_SIMD) void RPT_K(render_sdf_march2_media_kernel)(const WithMedia<SceneSmallSdf> sc, const RenderParams rp) { render_sdf_march2_body(kernarg_scene(sc), rp); }
 #endif
@@ -276,6 +284,7 @@ hipError_t render_sdf(const SceneSmallSdf& scs, bool media, const RenderParams& 
     else if (kc.sized_sdf == 2u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<2u>, tiles, wg, 0, st, scs, rp);
     else if (kc.sized_sdf == 3u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<3u>, tiles, wg, 0, st, scs, rp);
     else if (kc.sized_sdf == 4u) hipLaunchKernelGGL(RPT_K(render_sdf_march2_sized_kernel)<4u>, tiles, wg, 0, st, scs, rp);
+    else if (kc.material_table) hipLaunchKernelGGL(RPT_K(render_sdf_march2_table_kernel), tiles, wg, 0, st, scs, rp);
     else hipLaunchKernelGGL(RPT_K(render_sdf_march2_kernel), tiles, wg, 0, st, scs, rp);
     return hipGetLastError();
 }

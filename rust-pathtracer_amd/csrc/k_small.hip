@@ -146,6 +146,13 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 {
     render_regen_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
 }
+// The material table for ANY scene of at most three primitives (kernel_common.h, material_table_fits): the table's shape is data here.
+__global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_table_kernel)(const SceneSmall sc, const RenderParams rp)
+{
+    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
+    const SceneSmall& s = kernarg_scene(sc);
+    render_regen_body(s, rp, material_table_build<false>(s, uniform_here(s.n_spheres), uniform_here(s.n_planes), s_rows));
+}
 #ifndef RPT_RELAXED_BUILD                                           // (media have no relaxed form)
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_regen_body(kernarg_scene(sc), rp); }
 #endif
@@ -166,6 +173,7 @@ hipError_t render_small(const SceneSmall& sc, bool media, bool nested, const Ren
     } else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
     else if (kc.sized && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_table_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     else if (kc.sized) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
+    else if (kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_regen_table_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     else hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     return hipGetLastError();
 }
