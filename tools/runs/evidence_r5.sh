@@ -5,7 +5,7 @@ set -e
 O=gpurun_out/evidence_r5; mkdir -p $O
 export RPT_LIB=    # (unset for the tools below: ab_time / bench load the PRODUCT library; pytest's conftest picks the test build)
 unset RPT_LIB
-python -m pytest tests -m gpu -q > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
+python -m pytest tests -m gpu -q --capture=sys > $O/tests.log 2>&1 || { tail -40 $O/tests.log; exit 1; }
 tail -2 $O/tests.log
 python tools/block_profile.py 256 c2 > $O/block_profile_c2.txt 2>&1
 python tools/block_profile.py 64 c4 > $O/block_profile_c4.txt 2>&1
