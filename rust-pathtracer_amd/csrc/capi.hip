@@ -480,6 +480,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         kc.sized = can_size && !has_sdf && sc.n_spheres == 2u && sc.n_planes == 1u && sc.n_lights == 1u;      // (kernel_common.h, RPT_REFERENCE_SIZES)
         kc.sized_sdf = (can_size && has_sdf && sc.n_planes == 1u && sc.n_lights == 1u && scs.sdf.n_prims <= 4u) ? scs.sdf.n_prims : 0u;
         kc.material_table = !knobs().no_material_table && !ctx->media && !ctx->large && !nested && rptlaunch::material_table_fits_small(scs, has_sdf);      // (with or without the sizes)
+        kc.material_table_wide = !knobs().no_material_table && !ctx->media && !ctx->large && !nested && !has_sdf && !rp.compact && rptlaunch::material_table_fits_small(scs, false, 4u);
         kc.extra_lds = knobs().debug_extra_lds;
     }
     const auto launch = [&](uint32_t grid) -> hipError_t {

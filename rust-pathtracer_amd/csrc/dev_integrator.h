@@ -697,6 +697,10 @@ struct MaterialPerHit {
 constexpr uint32_t kMatRowFloat4s = 8u;          // 128 B
 constexpr uint32_t kMatTableBits = 3u;
 constexpr uint32_t kMatTableRows = 1u << (kMatTableBits + 2u);       // 4 KB
+// ... and of at most kMatTableBitsWide primitives in the megakernel that takes the table's shape as data (k_small.hip, render_small_regen_table_kernel:
+// it has the LDS for 64 rows; the compacting and the SDF kernels do not)
+constexpr uint32_t kMatTableBitsWide = 4u;
+constexpr uint32_t kMatTableRowsWide = 1u << (kMatTableBitsWide + 2u);       // 8 KB
 template <bool SDF>
 struct MaterialTable {
     static constexpr bool kTable = true;

@@ -146,10 +146,11 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
 {
     render_regen_body(sized_scene<RPT_REFERENCE_SIZES>(kernarg_scene(sc)), rp);
 }
-// The material table for ANY scene of at most three primitives (kernel_common.h, material_table_fits): the table's shape is data here.
+// The material table for ANY scene of at most FOUR primitives (kernel_common.h, material_table_fits; three spheres on a floor): the
+// table's shape is data here, and 64 rows (8 KB) still leave five workgroups per CU.
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_table_kernel)(const SceneSmall sc, const RenderParams rp)
 {
-    __shared__ float4 s_rows[kMatTableRows * kMatRowFloat4s];
+    __shared__ float4 s_rows[kMatTableRowsWide * kMatRowFloat4s];
     const SceneSmall& s = kernarg_scene(sc);
     render_regen_body(s, rp, material_table_build<false>(s, uniform_here(s.n_spheres), uniform_here(s.n_planes), s_rows));
 }
@@ -173,13 +174,13 @@ hipError_t render_small(const SceneSmall& sc, bool media, bool nested, const Ren
     } else if (nested) hipLaunchKernelGGL(RPT_K(render_small_nested_kernel), tiles, wg, 0, st, sc, rp);
     else if (kc.sized && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_table_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     else if (kc.sized) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
-    else if (kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_regen_table_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
+    else if (kc.material_table || kc.material_table_wide) hipLaunchKernelGGL(RPT_K(render_small_regen_table_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     else hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     return hipGetLastError();
 }
 
 #ifndef RPT_RELAXED_BUILD
-bool material_table_fits_small(const SceneSmallSdf& scs, bool has_sdf) { return material_table_fits(static_cast<const SceneSmall&>(scs), scs.sdf.material, has_sdf); }
+bool material_table_fits_small(const SceneSmallSdf& scs, bool has_sdf, uint32_t max_bits) { return material_table_fits(static_cast<const SceneSmall&>(scs), scs.sdf.material, has_sdf, max_bits); }
 #ifdef RPT_PROFILE_BLOCKS
 hipError_t prof_read_small(unsigned long long* out) { return prof_read(out); }
 #endif

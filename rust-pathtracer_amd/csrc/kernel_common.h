@@ -437,9 +437,9 @@ RPT_DEV MaterialTable<SDF> material_table_build(const S& sc, uint32_t ns, uint32
 }
 // Which scenes: the host's side of the same rule (render(), below).
 template <class S>
-inline bool material_table_fits(const S& sc, uint32_t sdf_material, bool has_sdf)
+inline bool material_table_fits(const S& sc, uint32_t sdf_material, bool has_sdf, uint32_t max_bits = kMatTableBits)
 {
-    if (sc.n_spheres + sc.n_planes + (has_sdf ? 1u : 0u) > kMatTableBits) return false;
+    if (sc.n_spheres + sc.n_planes + (has_sdf ? 1u : 0u) > max_bits) return false;
     uint32_t n_procedural = 0;
     for (uint32_t i = 0; i < sc.n_spheres; ++i) n_procedural += sc.materials[sc.spheres[i].material].proc_kind != 0u;
     for (uint32_t k = 0; k < sc.n_planes; ++k) n_procedural += sc.materials[sc.planes[k].material].proc_kind != 0u;

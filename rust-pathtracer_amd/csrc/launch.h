@@ -15,14 +15,15 @@
 struct KernelChoice {
     bool sized = false;             // small scenes: the reference scene's table sizes are known at compile time (kernel_common.h, sized_scene)
     uint32_t sized_sdf = 0;         // SDF scenes: 1-4 primitives over one plane under one light: that many, known at compile time; 0: data
-    bool material_table = false;    // a hit's material from the workgroup's table (dev_integrator.h, MaterialTable)
+    bool material_table = false;    // a hit's material from the workgroup's table (dev_integrator.h, MaterialTable): at most 3 primitives
+    bool material_table_wide = false;   // ... at most 4: the megakernel of small scenes without an SDF object only (render_small_regen_table_kernel)
     uint32_t extra_lds = 0;         // development: pad the headline kernel's LDS (occupancy experiments)
 };
 
 namespace rptlaunch {
 
 uint32_t max_spp_per_launch(bool sdf_object);      // samples a chunk of the state-machine kernels can hold in its LDS tables (scenes with an SDF object: fewer)
-bool material_table_fits_small(const rptdev::SceneSmallSdf& scs, bool has_sdf);   // (kernel_common.h, material_table_fits)
+bool material_table_fits_small(const rptdev::SceneSmallSdf& scs, bool has_sdf, uint32_t max_bits = 3u);   // (kernel_common.h, material_table_fits)
 
 // One launch on `nblocks` workgroups (16x16 tiles x chunks of samples).  `media`: the scene has participating media — the same forms
 // instantiated for WithMedia<Scene> (dev_scene.h).  `nested`: the nested-loop baseline (small scenes without media only).

@@ -313,6 +313,17 @@ def _table_scene(rpt, which):
                        rpt.Material(rgb=(0.7, 0.7, 0.8), roughness=0.1, metallic=1.0)]
         s.spheres = [((0.0, 0.0, 0.0), 1.0, 0)]
         s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 1), ((0.0, 0.0, 1.0), (0.0, 0.0, -2.5), 0.0001, 2)]
+    elif which == "three spheres on a floor":
+        # four primitives: the megakernel's table has the rows for them (64), the compacting kernel's (one-sample launches) has not
+        s.materials = [rpt.Material(rgb=(0.9, 0.3, 0.2), clearcoat=1.0, clearcoat_gloss=0.7), rpt.Material(roughness=0.15, metallic=1.0, anisotropic=0.6),
+                       scenes.full_material(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5), rpt.Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1))]
+        s.spheres = [((0.2, 0.0, -0.6), 1.0, 0), ((-1.3, -0.3, 0.4), 0.7, 1), ((1.4, -0.4, 0.5), 0.6, 2)]
+        s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 3)]
+    elif which == "two spheres two planes":
+        s.materials = [rpt.Material(rgb=(0.2, 0.7, 0.3), roughness=0.3, sheen=0.6), rpt.Material(rgb=(0.8, 0.8, 0.2), roughness=0.05, metallic=1.0),
+                       rpt.Material(roughness=0.9, checker_dir=(0.5, 100.0, 0.25, 0.1)), rpt.Material(rgb=(0.7, 0.7, 0.8), roughness=0.4)]
+        s.spheres = [((-0.9, 0.0, 0.0), 1.0, 0), ((1.0, -0.2, 0.3), 0.8, 1)]
+        s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2), ((0.0, 0.0, 1.0), (0.0, 0.0, -2.5), 0.0001, 3)]
     elif which == "one plane two lights":
         s.spheres = []
         s.lights = list(s.lights) + [rpt.AnalyticalLight.spherical((-2.0, 1.5, 1.0), 0.5, (4.0, 4.0, 8.0))]
@@ -322,7 +333,7 @@ def _table_scene(rpt, which):
 
 
 _TABLE_CASES = ["reference", "overlapping patches", "camera inside glass", "checker on a sphere", "extreme materials", "two checkers", "sdf", "sdf no sphere", "sdf two spheres",
-                "sdf checker object", "three spheres", "one sphere two planes", "one plane two lights", "sdf two lights", "sdf two planes", 2, 5, 9, 13, 17, 21, 26, 33]
+                "sdf checker object", "three spheres", "one sphere two planes", "one plane two lights", "three spheres on a floor", "two spheres two planes", "sdf two lights", "sdf two planes", 2, 5, 9, 13, 17, 21, 26, 33]
 
 
 def test_the_material_table_holds_what_every_hit_would_compute(rpt, oracle, torch_cuda):
