@@ -161,8 +161,8 @@ def other_configs(rpt, torch, device, small):
     def run(scene, w, h, spp, reps):
         tracer = rpt.Tracer(scene, device=device, seed=1)
         buf = rpt.DeviceColorBuffer(w, h, device="cuda:%d" % device)
-        tracer.render_n(buf, 1)
-        torch.cuda.synchronize()
+        tracer.render_n(buf, spp)                                  # warm-up with the timed launch's own shape and size: the dispatch
+        torch.cuda.synchronize()                                    # order of a launch is learned from the previous one like it
         ms = []
         for _ in range(reps):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
