@@ -46,6 +46,13 @@ def lib():
                 fn.restype = res
                 fn.argtypes = args
         _lib = l
+        # Profiling runs (tools/collect_profiles.sh) ask which library the profiled process REALLY loaded: counters are stamped with
+        # that file's hash, not with what the collecting script assumes.
+        record = os.environ.get("RPT_LOADED_LIB_RECORD")
+        if record:
+            import hashlib
+            with open(record, "w") as f:
+                f.write("%s %s\n" % (hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest(), os.path.abspath(LIB_PATH)))
     return _lib
 
 

@@ -3,13 +3,13 @@ with_checker_dir / zero_unmasked`, `From<&AnalyticalLight> for RptLight` — met
 `impl GpuScene for AnalyticalScene` statement for statement.  The Rust files cannot be compiled here (no rustc); this mirror is what
 tests/test_rust_binding.py runs: the descriptor it builds for the stock scene is byte-identical to the library's
 `rpt_scene_analytical`, and its method list and the literals of `analytical_describe` are compared with the Rust sources
-mechanically.  Not used by the product path (api.Scene.describe is the package's own builder)."""
+mechanically.  Test scaffolding: the product path never imports it (api.Scene.describe is the package's own builder)."""
 import ctypes as C
 import math
 
 import numpy as np
 
-from . import _abi
+from rust_pathtracer_amd import _abi
 
 
 class RefMaterial:

@@ -180,6 +180,46 @@ def test_multi_context_large_scene_and_progressive_gathers(rpt, oracle, torch_cu
     t.close()
 
 
+@pytest.mark.parametrize("tile_rows", [2, 8])
+def test_full_size_config3_whole_frame_through_eight_ranks(rpt, oracle, torch_cuda, tile_rows):
+    """BASELINE.json configs[2] WHOLE: AnalyticalScene 3840x2160 x 1024 spp through the 8-rank code path — rpt_create_multi with
+    device 0 listed eight times (cyclic row blocks: 2 rows, the library's default, and the 8 rows bench.py asks for), every rank's
+    strided launch, the gather to rank 0 and the scatter at full size.  The gathered image must be the single-context frame bit for
+    bit, and one complete row out of EVERY rank's tile the oracle's (global rows follow tracer.rs:29-37: the pixel's index in the
+    whole frame keys its stream, whichever rank renders it)."""
+    from rust_pathtracer_amd import tiling
+    torch = torch_cuda
+    w, h, spp, world = 3840, 2160, 1024, 8
+    os.environ.pop("RPT_GATHER", None)
+    t = rpt.Tracer(rpt.AnalyticalScene(), devices=[0] * world, seed=1)
+    assert t.world() == (0, world, world)
+    job = tiling.TiledRender(t, w, h, tile_rows=tile_rows)
+    job.render_n(spp)
+    image = job.gather()
+    assert t.resident_frames() == spp
+    single = rpt.Tracer(rpt.AnalyticalScene(), device=0, seed=1)
+    buf = rpt.DeviceColorBuffer(w, h)
+    single.render_n(buf, spp)
+    torch.cuda.synchronize()
+    assert torch.equal(image.view(torch.int32), buf.pixels.view(torch.int32)), "the 8-rank frame is not the one-context frame"
+    got = image.cpu().numpy()
+    assert np.all(got[..., 3] == 1.0)
+    # one row per rank, spread over sky, spheres and floor: block b of `tile_rows` rows belongs to rank b % 8
+    picked = {}
+    for rank in range(world):
+        rows = tiling.tile_global_rows(h, tile_rows, rank, world)
+        assert len(rows) == h // world
+        g = rows[(37 * (rank + 1)) % len(rows)]
+        assert (g // tile_rows) % world == rank
+        picked[rank] = g
+    for rank, g in picked.items():
+        px = np.zeros((h, w, 4), dtype=np.float32)
+        oracle.render(oracle.scene_analytical(), w, h, spp, seed=1, pixels=px, rows=(g, g + 1))
+        assert_bit_identical(got[g], px[g], "configs[2] whole frame, rank %d's global row %d (blocks of %d rows)" % (rank, g, tile_rows))
+    single.close()
+    t.close()
+
+
 def test_bench_fallback_gather_gives_the_same_image(rpt, oracle, torch_cuda):
     """bench.py's insurance path (per-rank tile + torch.distributed RCCL gather + the library's scatter), on a one-rank
     group: the image of the plain render, bit for bit."""

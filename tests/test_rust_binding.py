@@ -305,10 +305,10 @@ def _rust_fn_body(src, signature_start):
 def test_the_rust_builder_describes_the_stock_scene_like_the_library(rpt):
     """rust/analytical_gpu.rs builds AnalyticalScene's descriptor from the Rust side's own values (lights through Scene::light_at,
     closest_hit's literals restated) with SceneDescBuilder.  Through the Python mirror of that builder and of that describe()
-    (rust-pathtracer_amd/scene_builder.py, statement for statement): every byte of the descriptor and of its four tables equals
+    (tests/scene_builder.py, statement for statement): every byte of the descriptor and of its four tables equals
     the library's rpt_scene_analytical."""
     import ctypes as C
-    from rust_pathtracer_amd import scene_builder as sb
+    import scene_builder as sb
 
     def dump(d):
         out = [d.abi_version, d.flags, bytes(d.camera), bytes(d.background), d.eps, d.max_depth, d.n_spheres, d.n_planes, d.n_lights, d.n_materials, d.sdf.n_prims]
@@ -334,7 +334,7 @@ def test_the_python_mirror_is_the_rust_adapter():
     set on both sides, and describe() of rust/analytical_gpu.rs and scene_builder.analytical_describe make the same builder calls
     with the same literals in the same order."""
     import inspect
-    from rust_pathtracer_amd import scene_builder as sb
+    import scene_builder as sb
     rust = strip_comments(open(RUST).read())
     impl = rust[rust.index("impl SceneDescBuilder {"):rust.index("pub trait GpuScene")]
     rust_methods = set(re.findall(r"pub fn (\w+)", impl))
@@ -385,3 +385,58 @@ def test_the_rust_surface_the_integration_guide_promises():
     ext = src[src.index('extern "C" {'):src.index("}", src.index('extern "C" {'))]
     for m in re.finditer(r"(#\[allow\(dead_code\)\]\s*)?fn (rpt_\w+)\(", ext):
         assert m.group(1) or src.count(m.group(2) + "(") >= 2, "%s is declared and never called" % m.group(2)
+
+
+REFERENCE = "/root/reference"
+
+
+def test_the_integration_patch_applies_to_the_reference_tree(tmp_path):
+    """rust/integration.patch is everything a maintainer changes in the reference beside dropping the two source files in:
+    `pub mod gpu_tracer;` (rust-pathtracer/src/lib.rs:12-22), the link stanza (build.rs + Cargo.toml), `mod analytical_gpu;` and
+    the ONE changed statement of renderer/src/main.rs:41-42.  `git apply --check` against a copy of /root/reference (never the
+    tree itself), then the patched tree is looked at the way rustc's module resolution would: every `mod` names a file that
+    exists, the crate that forbids `unsafe` gained none, what main.rs imports is `pub` in gpu_tracer.rs, and `pt.render(&mut buffer)`
+    / `buffer.convert_to_u8(frame)` (main.rs:118-122) are untouched."""
+    import pytest
+    import shutil
+    if not os.path.isdir(REFERENCE):
+        pytest.skip("the reference tree is not on this machine (GPU box)")
+    tree = tmp_path / "reference"
+    shutil.copytree(REFERENCE, tree, ignore=shutil.ignore_patterns("images", ".git"))
+    patch = os.path.join(ROOT, "rust", "integration.patch")
+    before = (tree / "renderer" / "src" / "main.rs").read_text()
+    for args in (["--check"], []):
+        r = subprocess.run(["git", "apply", "-p1"] + args + [patch], cwd=tree, capture_output=True, text=True)
+        assert r.returncode == 0, "git apply %s: %s" % (" ".join(args), r.stderr)
+    shutil.copy(os.path.join(ROOT, "rust", "gpu_tracer.rs"), tree / "rust-pathtracer" / "src" / "gpu_tracer.rs")
+    shutil.copy(os.path.join(ROOT, "rust", "analytical_gpu.rs"), tree / "renderer" / "src" / "analytical_gpu.rs")
+    # module resolution: `mod x;` in a crate root names src/x.rs or src/x/mod.rs
+    for crate, root_file in (("rust-pathtracer", "lib.rs"), ("renderer", "main.rs")):
+        src = strip_comments((tree / crate / "src" / root_file).read_text())
+        mods = re.findall(r"^\s*(?:pub\s+)?mod\s+(\w+)\s*;", src, flags=re.M)
+        assert ("gpu_tracer" in mods) if crate == "rust-pathtracer" else ("analytical_gpu" in mods)
+        for m in mods:
+            assert (tree / crate / "src" / (m + ".rs")).exists() or (tree / crate / "src" / m / "mod.rs").exists(), (crate, m)
+    main = (tree / "renderer" / "src" / "main.rs").read_text()
+    # renderer is #![forbid(unsafe_code)] (main.rs:2): the file added to it must hold none
+    assert "#![forbid(unsafe_code)]" in main
+    assert not re.search(r"\bunsafe\b", strip_comments((tree / "renderer" / "src" / "analytical_gpu.rs").read_text()))
+    # what main.rs now imports exists and is public; what analytical_gpu.rs implements is a public trait of the library crate
+    lib = strip_comments((tree / "rust-pathtracer" / "src" / "gpu_tracer.rs").read_text())
+    assert re.search(r"pub enum AutoTracer\b", lib) and re.search(r"pub fn describer_of\s*<", lib) and re.search(r"pub trait GpuScene\s*:\s*Scene", lib)
+    assert "use rust_pathtracer::gpu_tracer::{AutoTracer, describer_of};" in main
+    assert "AutoTracer::new(scene, describer_of::<AnalyticalScene>)" in main and "Tracer::new(scene)" not in main.replace("AutoTracer::new(scene", "")
+    # the redraw handler is the reference's own, line for line: only additions above it and one statement changed
+    changed = [l for l in before.splitlines() if l not in main.splitlines()]
+    assert changed == ["    let mut pt = Tracer::new(scene);"], changed
+    assert "pt.render(&mut buffer);" in main and "buffer.convert_to_u8(frame);" in main
+    # the link stanza: a build script the manifest names, asking for the library include/rpt.h is the header of
+    cargo = (tree / "rust-pathtracer" / "Cargo.toml").read_text()
+    build = (tree / "rust-pathtracer" / "build.rs").read_text()
+    assert 'build = "build.rs"' in cargo and "cargo:rustc-link-lib=dylib=rpt_hip" in build and "RPT_LIB_DIR" in build
+    assert os.path.exists(os.path.join(ROOT, "rust-pathtracer_amd", "librpt_hip.so")), "the library the stanza links (built by __graft_entry__.build())"
+    # AutoTracer keeps the three entry points the reference's Tracer has (tracer.rs:13, 22, 629) with their signatures
+    auto = lib[lib.index("impl AutoTracer"):]
+    assert re.search(r"pub fn new\(scene: Box<dyn Scene>, describe: Describer\) -> Self", auto)
+    assert re.search(r"pub fn render\(&mut self, buffer: &mut ColorBuffer\)", auto)
+    assert re.search(r"pub fn scene\(&mut self\) -> &mut Box<dyn Scene>", auto)

@@ -14,6 +14,8 @@ mkdir -p $OUT
 if [ $# -gt 0 ]; then PROG=("$@"); STATS_PROG=("$@"); KPAT=${RPT_PROFILE_KERNEL:-render_};
 else PROG=(bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only); STATS_PROG=(bench.py --steps 10 --warmup 2 --no-cpu-baseline --headline-only); KPAT=render_small; fi
 cd /tmp && export TMPDIR=/tmp
+export RPT_LOADED_LIB_RECORD=$OUT/loaded_lib.txt      # rust-pathtracer_amd/_lib.py writes "<sha256> <path>" of the library the profiled process loads
+rm -f $RPT_LOADED_LIB_RECORD
 run() {   # name, rocprof args...
     local name=$1; shift
     rm -rf /tmp/rp_$name

@@ -22,6 +22,20 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
         px = min(sizes, key=lambda s: abs(s - int(r["Grid_Size"])))
         kernels.add(r["Kernel_Name"].split("(")[0])
         per[sizes[px]][name].append(float(r["Counter_Value"]))
+# the share of the fused kernel's wave time spent waiting for LDS instructions (SQ_WAIT_INST_LDS of pass sq4 over SQ_WAVE_CYCLES of
+# pass sq2, the same dispatches): what bounds it, since it moves a fraction of HBM's rate
+lds_share = {}
+try:
+    acc = {k: collections.defaultdict(float) for k in sizes.values()}
+    for fn, name in (("pmc_sq4.csv", "SQ_WAIT_INST_LDS"), ("pmc_sq2.csv", "SQ_WAVE_CYCLES")):
+        for r in csv.DictReader(open(os.path.join(d, fn))):
+            if "denoise" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                acc[sizes[min(sizes, key=lambda s: abs(s - int(r["Grid_Size"])))]][name] += float(r["Counter_Value"])
+    for k, v in acc.items():
+        if v.get("SQ_WAVE_CYCLES"):
+            lds_share[k] = v.get("SQ_WAIT_INST_LDS", 0.0) / v["SQ_WAVE_CYCLES"]
+except OSError:
+    pass
 for label, px in (("1080p", 1920 * 1080), ("4k", 3840 * 2160)):
     f, w = per[label]["FETCH_SIZE"], per[label]["WRITE_SIZE"]
     if not f or not w:
@@ -29,7 +43,7 @@ for label, px in (("1080p", 1920 * 1080), ("4k", 3840 * 2160)):
     calls = len(f) // passes
     fetch = sum(f) / calls * 1024.0 * 2.0                            # KiB -> B, gfx950 counts 16-B-per-lane reads at half (MI355X_MICROARCH.md)
     write = sum(w) / calls * 1024.0
-    algo = 3 * 32.0 * px
+    algo = 32.0 * px                                                 # the fused kernel: one read and one write of the frame (three separate passes: 3 x)
     out = {"kernels": sorted(kernels), "calls_averaged": calls, "hbm_bytes_per_launch": fetch + write,
            "hbm_read_bytes_per_call": fetch, "hbm_write_bytes_per_call": write, "algorithmic_bytes_per_call": algo,
            "correction": "FETCH_SIZE x2 (gfx950 half-count of 16 B/lane reads), WRITE_SIZE x1; summed over the call's launches",
@@ -37,13 +51,15 @@ for label, px in (("1080p", 1920 * 1080), ("4k", 3840 * 2160)):
     # which code the counters belong to (bench.py prints them only for the library they were collected from)
     import hashlib
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    lib = os.path.join(root, "rust-pathtracer_amd", "librpt_hip.so")
-    if os.path.exists(lib):
-        out["library_sha256"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+    rec = os.path.join(d, "loaded_lib.txt")           # what the profiled process loaded (collect_profiles.sh, _lib.py)
     sys.path.insert(0, root)
     import bench
-    out["source_sha256"] = bench.source_hash()
+    if os.path.exists(rec):
+        out["library_sha256"] = open(rec).read().split()[0]
+        out["source_sha256"] = bench.source_hash()
+    if label in lds_share:
+        out["wait_inst_lds_share"] = round(lds_share[label], 4)
     json.dump(out, open(os.path.join(d, "traffic_%s.json" % label), "w"), indent=1)
     print("%-6s %d calls: read %.1f MB + written %.1f MB = %.1f MB per call against %.1f MB algorithmic (%.2f x): %s" % (
         label, calls, fetch / 1e6, write / 1e6, (fetch + write) / 1e6, algo / 1e6, (fetch + write) / algo,
-        "the passes' reads are served from the Infinity Cache" if fetch < 0.5 * algo / 2 else "HBM traffic"))
+        "LDS wait share of wave time %.1f %%" % (100.0 * lds_share[label]) if label in lds_share else "no SQ passes"))

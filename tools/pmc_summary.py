@@ -55,13 +55,19 @@ if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
     # Which code the counters belong to: bench.py prints them only for the library (or the sources) they were collected from.
     import hashlib
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-    lib = os.environ.get("RPT_PROFILED_LIB", os.path.join(root, "rust-pathtracer_amd", "librpt_hip.so"))
-    if os.path.exists(lib):
-        out["library_sha256"] = hashlib.sha256(open(lib, "rb").read()).hexdigest()
+    # The hash of the library the PROFILED PROCESS loaded (it leaves "<sha256> <path>" in loaded_lib.txt: collect_profiles.sh,
+    # _lib.py); without that record nothing is stamped and bench.py will not print these counters as the loaded library's.
+    rec = os.path.join(d, "loaded_lib.txt")
+    if os.path.exists(rec):
+        out["library_sha256"], out["library_path"] = open(rec).read().split(None, 1)
+        out["library_path"] = os.path.relpath(out["library_path"].strip(), os.path.abspath(root))
+    else:
+        print("NOT STAMPED: %s is missing (the profiled program did not load the library through rust-pathtracer_amd/_lib.py)" % rec)
     sys.path.insert(0, root)
     try:
         import bench
-        out["source_sha256"] = bench.source_hash()
+        if "library_sha256" in out:
+            out["source_sha256"] = bench.source_hash()
     except Exception as e:      # noqa: BLE001
         out["source_sha256_error"] = str(e)
     json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
