@@ -33,25 +33,33 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
     const uint32_t tid = threadIdx.x;
     share_init(s_count, false);                                     // (until the lane is known to have a pixel)
     RenderParams rp;                                                // this workgroup's unit of the launch
-    if (!lane_setup(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp)) return;
-    share_init(s_count, true);
+    // A lane of a ragged tile that has no pixel STAYS in its wave, as S2_DONE from the start: it owns no sample and shares none
+    // (its count says "none left"), but it is an idle lane like any other for the marches handed from lane to lane below — and the
+    // pairing there ranks lanes with ballots and moves the offers through lane registers, which is only right while every lane of the
+    // wave is alive (a ds_bpermute that selects a lane that has left the kernel returns 0, i.e. lane 0's job: ADVICE r5).
+    const uint32_t have = lane_setup_ex(LaneTables{s_fkey, s_weight, s_acc, s_pix}, sc.max_depth, launch, rp);
+    if (have == LANE_NOTHING) return;
+    const bool has_pixel = have == LANE_PIXEL;
+    if (has_pixel) share_init(s_count, true);
 
     uint32_t s = 0;
     uint32_t q = tid;                                               // the pixel this lane renders a sample of
-    uint32_t state = S2_MARCH_P;
+    uint32_t state = has_pixel ? S2_MARCH_P : S2_DONE;
     PathRegs p;
     bool pending = false;                                           // a light sample is parked, its shadow ray not answered yet
     bool lit = false;                                               // ... answered: it got through
     bool ending = false;                                            // the path is over once the parked sample is resolved
     bool blend_only = false;                                        // the sample is complete: it waits for its turn to be blended
     bool p_done = false;                                            // this lane's path march is over (its own work or a helper's)
-    {
+    if (has_pixel) {
         const float4 c = s_pix[tid];
         path_begin<true>(sc, p, c.x, c.y, s_fkey[0], rpt_f2u(c.z), rpt_f2u(c.w));
         MarchRegs m;
         march_begin_primary(sc, p, m);
         s_march[tid] = make_float4(0.0f, 0.0f, rpt_u2f(0u), rpt_u2f(m.accepted));
         s_shd[tid].w = 0.0f; s_gain[tid].w = m.t_useful; s_pjob[tid] = 0u;
+    } else {
+        p.ray.o = mk3(0.0f, 0.0f, 0.0f); p.ray.d = mk3(0.0f, 0.0f, 0.0f);     // (read by nobody: a lane without a pixel never offers a march)
     }
     const bool use_max = (sc.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
 
@@ -152,7 +160,12 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                     }
                 }
                 const uint32_t left = (uint32_t)__popcll(__ballot(work != 0u));
-                if (left == 0u || left < rp.march_min_lanes) break;
+                if (left == 0u) break;
+                // Few lanes still march: the phase ends for the block — if somebody is waiting for it.  Lanes that waited when the
+                // phase began, or a marcher whose marches have ended since (not one whose path march is out with a helper).  With
+                // nobody to run the block for, leaving would only re-enter this phase at its full price (the reload of every march,
+                // the records' scalar loads, the pairing) once per step: the wave's tail marches on instead.
+                if (left < rp.march_min_lanes && (n_wait != 0u || __ballot(state <= S2_MARCH_P && work == 0u && !p_given) != 0ull)) break;
             }
             // what is unfinished goes back to its slot; then every lane learns where its own marches stand
             if (work == 1u) { s_march[tid].x = m.t; s_march[tid].z = rpt_u2f(m.steps); }
@@ -228,6 +241,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
         }
     }
     RPT_PROF_FLUSH();
+    if (!has_pixel) return;                                         // (before lane_finish: the hand-off counts the lanes that stored a pixel)
     lane_finish(rp, s_acc[tid]);
 }
 

@@ -354,7 +354,10 @@ struct LaneTables {
 // Takes the workgroup's unit (unit_begin), fills the tables and this lane's slots.  `rp`: the unit's share of the launch.
 // False: the lane has no pixel, or the scene has max_depth == 0 (no bounce loop at all: every sample's radiance is zero and
 // the lane's pixel is finished here) — the caller returns.
-RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderParams& launch, RenderParams& rp)
+enum : uint32_t { LANE_NOTHING = 0u, LANE_PIXEL = 1u, LANE_NO_PIXEL = 2u };
+// LANE_NOTHING: the scene has no bounce loop (the whole workgroup is finished here); LANE_NO_PIXEL: this lane of a ragged tile has no
+// pixel (its wave goes on: the SDF march kernel keeps such lanes as helpers of their wave's marches, k_sdf.hip).
+RPT_DEV uint32_t lane_setup_ex(const LaneTables& lt, uint32_t max_depth, const RenderParams& launch, RenderParams& rp)
 {
     unit_begin(launch, rp);
     for (uint32_t i = threadIdx.x; i < rp.spp; i += 256u) {
@@ -372,16 +375,20 @@ RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderPa
             *pixel0 = acc;
             unit_end(rp, true);
         }
-        return false;
+        return LANE_NOTHING;
     }
     const PixelSetup ps = pixel_setup(rp);
-    if (!ps.valid) return false;
+    if (!ps.valid) return LANE_NO_PIXEL;
     float4* pixel = reinterpret_cast<float4*>(rp.pixels) + ps.pix_offset;
     lt.acc[threadIdx.x] = *pixel;
     const uint32_t pix_a = pcg_hash(ps.pixel_index);
     lt.pix[threadIdx.x] = make_float4(ps.px, ps.py, rpt_u2f(pix_a), rpt_u2f(pcg_hash(pix_a)));
     sample_guard_begin();
-    return true;
+    return LANE_PIXEL;
+}
+RPT_DEV bool lane_setup(const LaneTables& lt, uint32_t max_depth, const RenderParams& launch, RenderParams& rp)
+{
+    return lane_setup_ex(lt, max_depth, launch, rp) == LANE_PIXEL;
 }
 
 // Sharing a wave's samples among its lanes (round 5).  A lane renders its own pixel's samples one after the other; when they are all

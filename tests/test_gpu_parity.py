@@ -6,6 +6,7 @@ BIT-IDENTICAL (NaNs, if any, in the same places).  BASELINE.json's "per-pixel L2
 < 1e-4 after 256 spp" is therefore met with error exactly 0.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -416,6 +417,37 @@ def test_sdf_scene_matches_oracle(rpt, oracle):
             t.render_n(buf, spp)
             assert_bit_identical(buf.image(), want, "sdf scene use_max=%s flags=%d" % (use_max, flags))
         t.close()
+
+
+@pytest.mark.parametrize("w,h", [(13, 11), (43, 21), (65, 9), (23, 17), (9, 41)])
+def test_sdf_marches_handed_between_lanes_in_partly_filled_waves(rpt, oracle, w, h):
+    """The SDF march kernel hands a waiting path march to an idle lane of its wave, pairing offers and idle lanes by rank with
+    ballots, ds_permute and ds_bpermute (k_sdf.hip) — which is only right while every lane the ranks can name is alive.  Frames whose
+    width is 1..7 mod 8 (and heights off the 8-row grid) have waves with 1 to 7 live columns: lanes without a pixel must neither
+    break the pairing (a bpermute that names a lane that has left the kernel reads 0, i.e. takes lane 0's march: ADVICE r5) nor be
+    lost as helpers.  Depth 4, enough samples that many shadow marches are in flight with path marches behind them; every kernel
+    form an SDF scene can take (sized / table / general), with and without max_dist in any_hit; bit for bit against the oracle."""
+    from rust_pathtracer_amd import scenes
+    for use_max, spp, env in ((False, 9, {}), (True, 5, {}), (False, 6, {"RPT_NO_SIZED_KERNELS": "1"}),
+                              (False, 6, {"RPT_NO_SIZED_KERNELS": "1", "RPT_NO_MATERIAL_TABLE": "1"})):
+        s = scenes.sdf_scene()
+        s.any_hit_uses_max_dist = use_max
+        assert s.recursion_depth() >= 3
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        rpt.lib().rpt_debug_reload_knobs()
+        try:
+            t = rpt.Tracer(s, device=0, seed=17)
+            buf = rpt.ColorBuffer(w, h)
+            t.render_n(buf, spp)
+            t.render_n(buf, 2)                                      # and once more on top (the running mean carries over)
+            t.close()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            rpt.lib().rpt_debug_reload_knobs()
+        want = oracle.render(s.describe(), w, h, spp + 2, seed=17)
+        assert_bit_identical(buf.image(), want, "sdf scene %dx%d x %d spp, use_max=%s %s" % (w, h, spp + 2, use_max, env))
 
 
 def _with_ground_sphere(s, where):
