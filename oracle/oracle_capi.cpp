@@ -98,8 +98,13 @@ int oracle_max_threads(void)
 #endif
 }
 
+void oracle_undo_quirks(uint32_t mask) { g_undo_quirks = mask; }       // TESTS ONLY (rpt_oracle.hpp, g_undo_quirks)
+
 const char* oracle_build_info(void)
 {
+#if defined(RPT_ORACLE_F64)
+    return "oracle: f64";
+#endif
 #if defined(RPT_OPCOUNT)
     return "oracle: opcount";
 #elif defined(RPT_ORACLE_LIBM)
@@ -146,7 +151,7 @@ int oracle_sample_pixels(const rpt_scene_desc* desc, const uint32_t* cols, const
     Tracer tracer(scene);
     for (uint64_t k = 0; k < n; ++k) {
         F3 r = tracer.sample_pixel(cols[k], rows[k], width, height, frame_key(seed, frames[k]));
-        out[3 * k + 0] = raw(r.x); out[3 * k + 1] = raw(r.y); out[3 * k + 2] = raw(r.z);
+        out[3 * k + 0] = rawf(r.x); out[3 * k + 1] = rawf(r.y); out[3 * k + 2] = rawf(r.z);
     }
     return 0;
 }
@@ -228,23 +233,23 @@ int oracle_sphere(const float* o, const float* d, const float* c, float radius, 
 {
     F tt(0.0f);
     bool hit = sphere(Ray(F3(o[0], o[1], o[2]), F3(d[0], d[1], d[2])), F3(c[0], c[1], c[2]), radius, tt);
-    *t = raw(tt);
+    *t = rawf(tt);
     return hit ? 1 : 0;
 }
 int oracle_plane(const float* o, const float* d, const rpt_plane* p, float* t)
 {
     F tt(0.0f);
     bool hit = plane(Ray(F3(o[0], o[1], o[2]), F3(d[0], d[1], d[2])), *p, tt);
-    *t = raw(tt);
+    *t = rawf(tt);
     return hit ? 1 : 0;
 }
-float oracle_power_heuristic(float a, float b) { return raw(Tracer::power_heuristic(a, b)); }
-float oracle_schlick_fresnel(float u) { return raw(Tracer::schlick_fresnel(u)); }
-float oracle_dielectric_fresnel(float c, float eta) { return raw(Tracer::dielectric_fresnel(c, eta)); }
-float oracle_gtr1(float ndoth, float a) { return raw(Tracer::gtr1(ndoth, a)); }
-float oracle_smithg(float ndotv, float alphag) { return raw(Tracer::smithg(ndotv, alphag)); }
-float oracle_gtr2aniso(float ndoth, float hx, float hy, float ax, float ay) { return raw(Tracer::gtr2aniso(ndoth, hx, hy, ax, ay)); }
-float oracle_luminance(const float* c) { return raw(Tracer::luminance(F3(c[0], c[1], c[2]))); }
+float oracle_power_heuristic(float a, float b) { return rawf(Tracer::power_heuristic(a, b)); }
+float oracle_schlick_fresnel(float u) { return rawf(Tracer::schlick_fresnel(u)); }
+float oracle_dielectric_fresnel(float c, float eta) { return rawf(Tracer::dielectric_fresnel(c, eta)); }
+float oracle_gtr1(float ndoth, float a) { return rawf(Tracer::gtr1(ndoth, a)); }
+float oracle_smithg(float ndotv, float alphag) { return rawf(Tracer::smithg(ndotv, alphag)); }
+float oracle_gtr2aniso(float ndoth, float hx, float hy, float ax, float ay) { return rawf(Tracer::gtr2aniso(ndoth, hx, hy, ax, ay)); }
+float oracle_luminance(const float* c) { return rawf(Tracer::luminance(F3(c[0], c[1], c[2]))); }
 
 // Material::new + field overrides + finalize; m = 17 user-set floats (rgb, emission,
 // anisotropic, metallic, roughness, subsurface, specular_tint, sheen, sheen_tint,
@@ -252,16 +257,16 @@ float oracle_luminance(const float* c) { return raw(Tracer::luminance(F3(c[0], c
 void oracle_material_defaults(float* m)
 {
     Material mat;
-    float v[17] = {raw(mat.rgb.x), raw(mat.rgb.y), raw(mat.rgb.z), raw(mat.emission.x), raw(mat.emission.y), raw(mat.emission.z),
-                   raw(mat.anisotropic), raw(mat.metallic), raw(mat.roughness), raw(mat.subsurface), raw(mat.specular_tint),
-                   raw(mat.sheen), raw(mat.sheen_tint), raw(mat.clearcoat), raw(mat.clearcoat_gloss), raw(mat.spec_trans), raw(mat.ior)};
+    float v[17] = {rawf(mat.rgb.x), rawf(mat.rgb.y), rawf(mat.rgb.z), rawf(mat.emission.x), rawf(mat.emission.y), rawf(mat.emission.z),
+                   rawf(mat.anisotropic), rawf(mat.metallic), rawf(mat.roughness), rawf(mat.subsurface), rawf(mat.specular_tint),
+                   rawf(mat.sheen), rawf(mat.sheen_tint), rawf(mat.clearcoat), rawf(mat.clearcoat_gloss), rawf(mat.spec_trans), rawf(mat.ior)};
     std::memcpy(m, v, sizeof(v));
 }
 void oracle_material_finalize(const float* m, float* out)
 {
     Material mat = material_from_array(m);
     mat.finalize();
-    out[0] = raw(mat.roughness); out[1] = raw(mat.clearcoat_roughness); out[2] = raw(mat.ax); out[3] = raw(mat.ay);
+    out[0] = rawf(mat.roughness); out[1] = rawf(mat.clearcoat_roughness); out[2] = rawf(mat.ax); out[3] = rawf(mat.ay);
 }
 
 // Pinhole::gen_ray: cam = {origin[3], center[3], fov}; out = {origin[3], direction[3]}
@@ -270,8 +275,8 @@ void oracle_gen_ray(const float* cam, float px, float py, float offx, float offy
     Pinhole p;
     p.origin = F3(cam[0], cam[1], cam[2]); p.center = F3(cam[3], cam[4], cam[5]); p.fov = cam[6];
     Ray r = p.gen_ray(px, py, offx, offy, width, height);
-    out[0] = raw(r.origin.x); out[1] = raw(r.origin.y); out[2] = raw(r.origin.z);
-    out[3] = raw(r.direction.x); out[4] = raw(r.direction.y); out[5] = raw(r.direction.z);
+    out[0] = rawf(r.origin.x); out[1] = rawf(r.origin.y); out[2] = rawf(r.origin.z);
+    out[3] = rawf(r.direction.x); out[4] = rawf(r.direction.y); out[5] = rawf(r.direction.z);
 }
 
 // disney_eval on a finalized material: returns f[3], pdf in out[0..3]
@@ -286,7 +291,7 @@ void oracle_disney_eval(const float* m, float eta, const float* v, const float* 
     st.eta = eta;
     F pdf(0.0f);
     F3 f = tr.disney_eval(st, F3(v[0], v[1], v[2]), F3(n[0], n[1], n[2]), F3(l[0], l[1], l[2]), pdf);
-    out[0] = raw(f.x); out[1] = raw(f.y); out[2] = raw(f.z); out[3] = raw(pdf);
+    out[0] = rawf(f.x); out[1] = rawf(f.y); out[2] = rawf(f.z); out[3] = rawf(pdf);
 }
 
 // disney_sample with an explicit RNG position: out = {f[3], l[3], pdf, draws_used}
@@ -306,9 +311,9 @@ void oracle_disney_sample(const float* m, float eta, const float* v, const float
     F3 l(l_stale[0], l_stale[1], l_stale[2]);
     F pdf(0.0f);
     F3 f = tr.disney_sample(st, F3(v[0], v[1], v[2]), F3(n[0], n[1], n[2]), l, pdf, rng);
-    out[0] = raw(f.x); out[1] = raw(f.y); out[2] = raw(f.z);
-    out[3] = raw(l.x); out[4] = raw(l.y); out[5] = raw(l.z);
-    out[6] = raw(pdf); out[7] = (float)rng_draws_between(rng0, rng);
+    out[0] = rawf(f.x); out[1] = rawf(f.y); out[2] = rawf(f.z);
+    out[3] = rawf(l.x); out[4] = rawf(l.y); out[5] = rawf(l.z);
+    out[6] = rawf(pdf); out[7] = (float)rng_draws_between(rng0, rng);
 }
 
 // sample_light with an explicit RNG position: light = rpt_light; out = {normal[3], emission[3], direction[3], dist, pdf, draws_used}
@@ -326,10 +331,10 @@ void oracle_sample_light(const rpt_light* light, const float* scatter_pos, uint3
     const Rng rng0 = rng;
     LightSampleRec ls;
     tr.sample_light(*light, F3(scatter_pos[0], scatter_pos[1], scatter_pos[2]), ls, rng);
-    out[0] = raw(ls.normal.x); out[1] = raw(ls.normal.y); out[2] = raw(ls.normal.z);
-    out[3] = raw(ls.emission.x); out[4] = raw(ls.emission.y); out[5] = raw(ls.emission.z);
-    out[6] = raw(ls.direction.x); out[7] = raw(ls.direction.y); out[8] = raw(ls.direction.z);
-    out[9] = raw(ls.dist); out[10] = raw(ls.pdf); out[11] = (float)rng_draws_between(rng0, rng);
+    out[0] = rawf(ls.normal.x); out[1] = rawf(ls.normal.y); out[2] = rawf(ls.normal.z);
+    out[3] = rawf(ls.emission.x); out[4] = rawf(ls.emission.y); out[5] = rawf(ls.emission.z);
+    out[6] = rawf(ls.direction.x); out[7] = rawf(ls.direction.y); out[8] = rawf(ls.direction.z);
+    out[9] = rawf(ls.dist); out[10] = rawf(ls.pdf); out[11] = (float)rng_draws_between(rng0, rng);
 }
 
 // The record-per-call layouts of include/rpt.h's rpt_probe_fn, evaluated by the oracle (one call for n records).
@@ -384,7 +389,7 @@ void oracle_rng_u32(uint64_t seed, uint64_t frame, uint32_t pixel, uint32_t n, u
 void oracle_rng_f32(uint64_t seed, uint64_t frame, uint32_t pixel, uint32_t n, float* out)
 {
     Rng rng(frame_key(seed, frame), pixel);
-    for (uint32_t i = 0; i < n; ++i) out[i] = raw(rng.gen());
+    for (uint32_t i = 0; i < n; ++i) out[i] = rawf(rng.gen());
 }
 
 // element-wise math through the oracle's f_* layer (strict or glibc per build)
@@ -393,14 +398,14 @@ void oracle_math(uint32_t fn, const float* a, const float* b, float* out, uint64
 {
     for (uint64_t i = 0; i < n; ++i) {
         switch (fn) {
-        case 0: out[i] = raw(f_sin(a[i])); break;
-        case 1: out[i] = raw(f_cos(a[i])); break;
-        case 2: out[i] = raw(f_log2(a[i])); break;
-        case 3: out[i] = raw(f_powf(a[i], b[i])); break;
+        case 0: out[i] = rawf(f_sin(a[i])); break;
+        case 1: out[i] = rawf(f_cos(a[i])); break;
+        case 2: out[i] = rawf(f_log2(a[i])); break;
+        case 3: out[i] = rawf(f_powf(a[i], b[i])); break;
         case 4: out[i] = a[i] / b[i]; break;
         case 5: out[i] = std::sqrt(a[i]); break;
-        case 7: out[i] = raw(f_exp(a[i])); break;           // RPT_PROBE_EXP
-        case 8: out[i] = raw(f_ln(a[i])); break;            // RPT_PROBE_LOG
+        case 7: out[i] = rawf(f_exp(a[i])); break;           // RPT_PROBE_EXP
+        case 8: out[i] = rawf(f_ln(a[i])); break;            // RPT_PROBE_LOG
         case 9: {                                           // RPT_PROBE_DIV3: the same quotients, IEEE divides
             const float x = a[i], d = b[i];
             const float qx = (i & 4u) ? x / d : x / d, qy = (i & 4u) ? (0.5f * d) / d : (-d) / d, qz = (i & 4u) ? 0.0f / d : (0.75f * x) / d;
@@ -413,18 +418,18 @@ void oracle_math(uint32_t fn, const float* a, const float* b, float* out, uint64
             out[i] = rpt_powf_log2x(a[i], la, b[i]);
             break;
         }
-        case 100: out[i] = raw(f_tan(a[i])); break;         // host only (the camera's fov)
+        case 100: out[i] = rawf(f_tan(a[i])); break;         // host only (the camera's fov)
         default: out[i] = 0.0f;
         }
     }
 }
 
 // Media leaves (PROJECT-DEFINED, include/rpt.h): the phase function and its sampling.
-float oracle_phase_hg(float cos_theta, float g) { return raw(Tracer::phase_hg(cos_theta, g)); }
+float oracle_phase_hg(float cos_theta, float g) { return rawf(Tracer::phase_hg(cos_theta, g)); }
 void oracle_sample_hg(const float* v, float g, float r1, float r2, float* out)
 {
     F3 d = Tracer::sample_hg(F3(v[0], v[1], v[2]), g, r1, r2);
-    out[0] = raw(d.x); out[1] = raw(d.y); out[2] = raw(d.z);
+    out[0] = rawf(d.x); out[1] = rawf(d.y); out[2] = rawf(d.z);
 }
 
 // ColorBuffer::convert_to_u8, buffer.rs:55-64: (p.powf(0.4545) * 255.0) as u8 for
@@ -441,9 +446,9 @@ void oracle_convert_to_u8(const float* pixels, uint8_t* frame, uint32_t width, u
     for (uint32_t y = 0; y < height; ++y)
         for (uint32_t x = 0; x < width; ++x) {
             size_t o = (size_t)x * 4 + (size_t)y * width * 4;
-            frame[o + 0] = as_u8(raw(f_powf(pixels[o + 0], 0.4545f) * F(255.0f)));
-            frame[o + 1] = as_u8(raw(f_powf(pixels[o + 1], 0.4545f) * F(255.0f)));
-            frame[o + 2] = as_u8(raw(f_powf(pixels[o + 2], 0.4545f) * F(255.0f)));
+            frame[o + 0] = as_u8(rawf(f_powf(pixels[o + 0], 0.4545f) * F(255.0f)));
+            frame[o + 1] = as_u8(rawf(f_powf(pixels[o + 1], 0.4545f) * F(255.0f)));
+            frame[o + 2] = as_u8(rawf(f_powf(pixels[o + 2], 0.4545f) * F(255.0f)));
             frame[o + 3] = as_u8(pixels[o + 3] * 255.0f);
         }
 }

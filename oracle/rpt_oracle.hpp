@@ -47,7 +47,20 @@ struct OpCounts {
     void operator+=(const OpCounts& o) { add += o.add; mul += o.mul; div += o.div; sqrt += o.sqrt; transc += o.transc; cmp += o.cmp; }
 };
 
-#ifdef RPT_OPCOUNT
+#if defined(RPT_ORACLE_F64)
+// The whole path in f64 (BASELINE.json configs[0] says "f64"; the crate at this commit is f32, lib.rs:6, and its Readme's "default is
+// f64" is stale: SURVEY.md fact 4).  Same statements, same draws (a draw is (u32 >> 8) * 2^-24: exact in both), same operation order,
+// double arithmetic and glibc's double libm: what the f32 frames — the kernel's and the f32 oracle's — are a ROUNDED version of.  Used
+// for error analysis only (bench.py `f64_reference`, tests/test_oracle_f64.py): the distance of an f32 frame from this one is the
+// "stated float tolerance" of BASELINE.json's north_star, measured instead of assumed.  The running mean is accumulated in f64 too.
+typedef double F;
+typedef double Raw;
+inline Raw raw(F a) { return a; }
+inline void count_sqrt() {}
+inline void count_transc() {}
+struct MissedSphereTest { void missed() {} };
+#elif defined(RPT_OPCOUNT)
+typedef float Raw;
 inline thread_local OpCounts g_ops;
 // Operations spent in tests of SCENE spheres that missed (closest_hit / any_hit loops): what an ideal acceleration
 // structure never executes.  bench.py prices a large scene's kernels against g_ops - g_ops_missed, not against the
@@ -81,16 +94,19 @@ inline bool operator<(F a, F b) { g_ops.cmp++; return a.v < b.v; }
 inline bool operator>(F a, F b) { g_ops.cmp++; return a.v > b.v; }
 inline bool operator<=(F a, F b) { g_ops.cmp++; return a.v <= b.v; }
 inline bool operator>=(F a, F b) { g_ops.cmp++; return a.v >= b.v; }
-inline float raw(F a) { return a.v; }
+inline Raw raw(F a) { return a.v; }
 inline void count_sqrt() { g_ops.sqrt++; }
 inline void count_transc() { g_ops.transc++; }
 #else
 typedef float F;
-inline float raw(F a) { return a; }
+typedef float Raw;
+inline Raw raw(F a) { return a; }
 inline void count_sqrt() {}
 inline void count_transc() {}
 struct MissedSphereTest { void missed() {} };
 #endif
+
+inline float rawf(F a) { return (float)raw(a); }              // for outputs that are f32 whatever F is (ray log, C ABI)
 
 // crate constants: rust-pathtracer/src/lib.rs:8-10
 static const float PI_F = 3.14159265358979323846f;          // std::f32::consts::PI
@@ -105,7 +121,7 @@ inline F f_floor(F x) { return F(std::floor(raw(x))); }
 // f32::max / f32::min: a NaN operand yields the other operand.
 inline F f_max(F self, F other)
 {
-    float a = raw(self), b = raw(other);
+    Raw a = raw(self), b = raw(other);
     if (a != a) return F(b);
     if (b != b) return F(a);
     return F(a > b ? a : b);
@@ -113,14 +129,14 @@ inline F f_max(F self, F other)
 // f32::clamp: NaN stays NaN.
 inline F f_clamp(F x, float lo, float hi)
 {
-    float a = raw(x);
+    Raw a = raw(x);
     if (a < lo) return F(lo);
     if (a > hi) return F(hi);
     return F(a);
 }
 inline F f_min(F self, F other)
 {
-    float a = raw(self), b = raw(other);
+    Raw a = raw(self), b = raw(other);
     if (a != a) return F(b);
     if (b != b) return F(a);
     return F(a < b ? a : b);
@@ -128,7 +144,15 @@ inline F f_min(F self, F other)
 // Rust's `%` on f32 is C fmodf (exact).
 inline F f_rem(F a, float b) { return F(std::fmod(raw(a), b)); }
 
-#ifdef RPT_ORACLE_LIBM
+#if defined(RPT_ORACLE_F64)
+inline F f_sin(F x) { return ::sin(x); }
+inline F f_cos(F x) { return ::cos(x); }
+inline F f_tan(F x) { return ::tan(x); }
+inline F f_powf(F x, F y) { return ::pow(x, y); }
+inline F f_log2(F x) { return ::log2(x); }
+inline F f_exp(F x) { return ::exp(x); }
+inline F f_ln(F x) { return ::log(x); }
+#elif defined(RPT_ORACLE_LIBM)
 inline F f_sin(F x) { count_transc(); return F(::sinf(raw(x))); }
 inline F f_cos(F x) { count_transc(); return F(::cosf(raw(x))); }
 inline F f_tan(F x) { count_transc(); return F(::tanf(raw(x))); }
@@ -385,6 +409,10 @@ struct Pinhole {                                                                
 // Debug aid for tests: when set, every closest_hit / any_hit query appends {o, d, max_dist} (max_dist = -1
 // for closest_hit) so a test can replay the exact rays of a pixel-sample through the device probes.
 inline thread_local std::vector<float>* g_ray_log = nullptr;
+// TESTS ONLY (tests/test_reference_screenshot.py): render with a quirk of the reference UNDONE, to show that the comparison with the
+// reference's screenshot tells the two apart.  Bit 0: GTR1 with ln(a^2), the textbook form, instead of the reference's log2 (Q5).
+// (Q3, any_hit honouring max_dist, is the scene flag RPT_SCENE_ANYHIT_USES_MAX_DIST.)  Always 0 otherwise.
+inline uint32_t g_undo_quirks = 0u;
 // Debug aid for tools/sched_sim.py: when set, sample_pixel appends one byte per path event: per bounce
 // 'M' miss (path over) | 'E' emitter (over) | 'H' surface hit ('k' follows when its material has clearcoat != 0), then 'n' light sample not facing / 's' shadowed /
 // 'v' unshadowed (disney_eval runs) / 'z' no lights, then the sampled lobe 'D' 'C' 'S', then 'x' if pdf <= 0 (over);
@@ -569,7 +597,7 @@ struct Scene {
     // (analytical.rs:43 has no `d < dist` test); the others only when nearer.
     bool closest_hit(const Ray& ray, State& state, LightSampleRec& light_sample) const
     {
-        if (g_ray_log) for (float v : {raw(ray.origin.x), raw(ray.origin.y), raw(ray.origin.z), raw(ray.direction.x), raw(ray.direction.y), raw(ray.direction.z), -1.0f}) g_ray_log->push_back(v);
+        if (g_ray_log) for (float v : {rawf(ray.origin.x), rawf(ray.origin.y), rawf(ray.origin.z), rawf(ray.direction.x), rawf(ray.direction.y), rawf(ray.direction.z), -1.0f}) g_ray_log->push_back(v);
         F dist(3.40282347e+38f);                                                   // F::MAX, analytical.rs:38
         bool hit = false;
         bool first = true;
@@ -623,7 +651,7 @@ struct Scene {
     // analytical.rs:130-145; max_dist is ignored there (flag off)
     bool any_hit(const Ray& ray, F max_dist) const
     {
-        if (g_ray_log) for (float v : {raw(ray.origin.x), raw(ray.origin.y), raw(ray.origin.z), raw(ray.direction.x), raw(ray.direction.y), raw(ray.direction.z), raw(max_dist)}) g_ray_log->push_back(v);
+        if (g_ray_log) for (float v : {rawf(ray.origin.x), rawf(ray.origin.y), rawf(ray.origin.z), rawf(ray.direction.x), rawf(ray.direction.y), rawf(ray.direction.z), rawf(max_dist)}) g_ray_log->push_back(v);
         bool use_max = (d.flags & RPT_SCENE_ANYHIT_USES_MAX_DIST) != 0;
         for (const rpt_sphere& s : spheres) {
             F dd;
@@ -661,7 +689,8 @@ struct Tracer {
         if (a >= F(1.0f)) return F(INV_PI_F);
         F a2 = a * a;
         F t = F(1.0f) + (a2 - F(1.0f)) * ndoth * ndoth;
-        return (a2 - F(1.0f)) / (F(PI_F) * f_log2(a2) * t);
+        if (g_undo_quirks & 1u) return (a2 - F(1.0f)) / (F(PI_F) * f_ln(a2) * t);     // (tests only: the textbook form, NOT the reference's)
+        return (a2 - F(1.0f)) / (F(PI_F) * f_log2(a2) * t);                           // quirk Q5: log2, tracer.rs:239
     }
 
     static F3 sample_gtr1(F rgh, F r1, F /*r2*/)                                   // tracer.rs:242-254
@@ -1203,6 +1232,14 @@ struct Tracer {
     void render(float* pixels, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp, uint64_t seed,
                 uint32_t row_begin, uint32_t row_end) const
     {
+#ifdef RPT_ORACLE_F64
+        // (the f64 instantiation keeps the call's running mean in f64 as well: `pixels` is read once and written once)
+        std::vector<Raw> mean_store((size_t)(row_end - row_begin) * width * 4);
+        Raw* const mean = mean_store.data() - (size_t)row_begin * width * 4;
+        for (size_t i = (size_t)row_begin * width * 4; i < (size_t)row_end * width * 4; ++i) mean[i] = pixels[i];
+#else
+        float* const mean = pixels;
+#endif
         for (uint32_t s = 0; s < spp; ++s) {
             uint64_t frames = frames_done + s;
             FrameKey fkey = frame_key(seed, frames);
@@ -1212,13 +1249,16 @@ struct Tracer {
                 uint32_t row_mem = row_end - 1u - (uint32_t)jj;                    // bottom-up like par_rchunks
                 for (uint32_t col = 0; col < width; ++col) {
                     F3 radiance = sample_pixel(col, row_mem, width, height, fkey);
-                    float* pixel = pixels + ((size_t)row_mem * width + col) * 4;
+                    Raw* pixel = mean + ((size_t)row_mem * width + col) * 4;
                     F color[4] = {radiance.x, radiance.y, radiance.z, F(1.0f)};    // tracer.rs:59,105
                     for (int c = 0; c < 4; ++c)                                    // mix_color, tracer.rs:108-113
                         pixel[c] = raw((F(1.0f) - v) * F(pixel[c]) + color[c] * v);
                 }
             }
         }
+#ifdef RPT_ORACLE_F64
+        for (size_t i = (size_t)row_begin * width * 4; i < (size_t)row_end * width * 4; ++i) pixels[i] = (float)mean[i];
+#endif
     }
 };
 
