@@ -183,5 +183,6 @@ TEST_SYMBOLS = {
     "rpt_probe_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "rpt_debug_render_overlap_ms": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "rpt_debug_sched_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]),
+    "rpt_debug_kernel_choice": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "rpt_probe_math": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
 }

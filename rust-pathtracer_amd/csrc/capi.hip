@@ -59,6 +59,7 @@ struct DevState {
     // dispatch (kernel_common.h, "Dispatch: units, their order, their hand-off"), for launches of `sched_tiles` tiles: per tile 4 dwords of
     // cost, 1 of order, 1 of sorting scratch, 4 of start stamps (development), then the hand-off words (SchedLayout)
     uint32_t* sched = nullptr;        // the tables of the CURRENT launch shape (an entry of sched_cache)
+    uint32_t last_choice = 0;         // the last launch's KernelChoice as bits (include/rpt_test.h, rpt_debug_kernel_choice)
     uint32_t sched_tiles = 0;
     uint64_t sched_launches = 0;      // launches since the order was last started from scratch (the costs are re-sorted after the 1st, 2nd, 4th, ...)
     // A context that alternates between launch shapes (a viewer's preview and full frames, bench.py's legs, one rank's tile and the
@@ -427,6 +428,44 @@ static int sched_for(rpt_ctx* ctx, DevState& d, uint32_t nblocks, uint32_t width
     return RPT_OK;
 }
 
+// The classes of accepted sets of a small scene of 5-8 primitives (launch.h, MatClassMap).  The material of a hit is Material::new()
+// overwritten field by field by the accepted primitives in order (apply_patch_fields; a procedural patch writes rgb whatever its
+// mask says: apply_patch_row), so two sets give the same material when every field has the same last writer in both.  False: the
+// scene is not one the mapped table serves (fewer than 5 or more than 8 primitives, two procedural materials, more than 16 classes).
+static bool material_class_map(const SceneSmall& sc, MatClassMap& map)
+{
+    const uint32_t ns = sc.n_spheres, np = sc.n_planes, nb = ns + np;
+    if (nb < 5u || nb > 8u) return false;
+    uint32_t n_procedural = 0;
+    uint32_t mask_of[kMaxSpheres + kMaxPlanes];
+    for (uint32_t i = 0; i < nb; ++i) {
+        const DevMaterial& m = sc.materials[i < ns ? sc.spheres[i].material : sc.planes[i - ns].material];
+        n_procedural += m.proc_kind != 0u;
+        mask_of[i] = (m.mask & (uint32_t)RPT_MAT_ALL) | (m.proc_kind == RPT_PROC_CHECKER_DIR ? (uint32_t)RPT_MAT_RGB : 0u);
+    }
+    if (n_procedural > 1u) return false;
+    memset(&map, 0, sizeof(map));
+    struct Signature { uint8_t last[13]; bool operator==(const Signature& o) const { return memcmp(last, o.last, sizeof(last)) == 0; } };
+    std::vector<Signature> classes;
+    for (uint32_t set = 0; set < (1u << nb); ++set) {
+        Signature sig;
+        memset(sig.last, 0xFF, sizeof(sig.last));
+        for (uint32_t i = 0; i < nb; ++i)
+            if ((set >> i) & 1u)
+                for (uint32_t f = 0; f < 13u; ++f) if ((mask_of[i] >> f) & 1u) sig.last[f] = (uint8_t)i;
+        size_t c = 0;
+        while (c < classes.size() && !(classes[c] == sig)) ++c;
+        if (c == classes.size()) {
+            if (classes.size() == kMatClasses) return false;
+            classes.push_back(sig);
+            map.class_set[c] = (uint16_t)((set & ((1u << ns) - 1u)) | ((set >> ns) << kMaxSpheres));      // (GeomHit.code's layout: planes from bit 8)
+        }
+        map.cls[set] = (uint8_t)c;
+    }
+    map.n_classes = (uint32_t)classes.size();
+    return true;
+}
+
 // One render launch sequence on one device.
 static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp,
                          uint64_t seed, uint32_t flags, uint32_t tile_rows, uint32_t rank, uint32_t world, hipStream_t stream)
@@ -481,7 +520,12 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         kc.sized_sdf = (can_size && has_sdf && sc.n_planes == 1u && sc.n_lights == 1u && scs.sdf.n_prims <= 4u) ? scs.sdf.n_prims : 0u;
         kc.material_table = !knobs().no_material_table && !ctx->media && !ctx->large && !nested && rptlaunch::material_table_fits_small(scs, has_sdf);      // (with or without the sizes)
         kc.material_table_wide = !knobs().no_material_table && !ctx->media && !ctx->large && !nested && !has_sdf && !rp.compact && rptlaunch::material_table_fits_small(scs, false, 4u);
+        // five to eight primitives: the table by class of accepted set (launch.h, MatClassMap), in the megakernel of small scenes
+        if (!kc.material_table && !kc.material_table_wide && !knobs().no_material_table && !ctx->media && !ctx->large && !nested && !has_sdf && !rp.compact)
+            kc.material_table_mapped = material_class_map(sc, kc.class_map);
         kc.extra_lds = knobs().debug_extra_lds;
+        d.last_choice = (kc.sized ? 1u : 0u) | (kc.material_table ? 2u : 0u) | (kc.material_table_wide ? 4u : 0u) | (kc.material_table_mapped ? 8u : 0u) |
+                        ((kc.material_table_mapped ? kc.class_map.n_classes : 0u) << 8) | (kc.sized_sdf << 16);
     }
     const auto launch = [&](uint32_t grid) -> hipError_t {
         if (ctx->large) return fast ? rptlaunch_fast::render_large(scl, false, rp, grid, stream) : rptlaunch::render_large(scl, ctx->media, rp, grid, stream);
@@ -1108,6 +1152,14 @@ int rpt_debug_sched_read(rpt_ctx* ctx, uint32_t* out, uint32_t capacity_tiles, u
     RPT_ON_DEVICE(ctx);
     RPT_HIP_CHECK(ctx, hipDeviceSynchronize());
     RPT_HIP_CHECK(ctx, hipMemcpy(out, d.sched, (size_t)d.sched_tiles * 10u * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RPT_OK;
+}
+
+// (include/rpt_test.h) the last launch's KernelChoice on device 0
+int rpt_debug_kernel_choice(rpt_ctx* ctx, uint32_t* out)
+{
+    if (!ctx || !out) return RPT_ERR_INVALID_ARG;
+    *out = ctx->devs[0].last_choice;
     return RPT_OK;
 }
 

@@ -732,8 +732,8 @@ struct MaterialTable {
     }
 };
 // The table's procedural primitive: wave-uniform, looked up once per workgroup.
-template <bool SDF, class S>
-RPT_DEV void material_table_procedural(const S& sc, uint32_t ns, uint32_t np, MaterialTable<SDF>& t)
+template <bool SDF, class S, class T>
+RPT_DEV void material_table_procedural(const S& sc, uint32_t ns, uint32_t np, T& t)
 {
     t.proc_bit = 0u; t.proc_scale = 0.0f; t.proc_offset = 0.0f;
     for (uint32_t i = 0; i < ns; ++i) {
@@ -749,17 +749,17 @@ RPT_DEV void material_table_procedural(const S& sc, uint32_t ns, uint32_t np, Ma
         if (pm.proc_kind == RPT_PROC_CHECKER_DIR) { t.proc_bit = 1u << (kMaxSpheres + kMaxPlanes); t.proc_scale = pm.proc_params[0]; t.proc_offset = pm.proc_params[1]; }
     }
 }
-// One row of that table (the lane that owns it calls this; any pass's functions: the row holds their results).
+// One row of that table (the lane that owns it calls this; any pass's functions: the row holds their results): the material of the
+// accepted set `set` (spheres | planes << ns | SDF object << (ns + np)) on the squares of the checker's first or `second` colour, seen
+// from the side `ndd_negative` says, into rows[row].
 template <bool SDF, class S>
-RPT_DEV void material_table_row(const S& sc, uint32_t ns, uint32_t np, uint32_t row, float4* rows)
+RPT_DEV void material_table_row_of(const S& sc, uint32_t ns, uint32_t np, uint32_t set, bool second, bool ndd_negative, uint32_t row, float4* rows)
 {
-    const uint32_t nb = ns + np + (SDF ? 1u : 0u);
-    const bool second = (row >> nb) & 1u, ndd_negative = (row >> (nb + 1u)) & 1u;
     Mat m;
     mat_defaults(m);
-    for (uint32_t i = 0; i < ns; ++i) apply_patch_row(m, sc.materials[sc.spheres[i].material], (row >> i) & 1u, second);
-    for (uint32_t k = 0; k < np; ++k) apply_patch_row(m, sc.materials[sc.planes[k].material], (row >> (ns + k)) & 1u, second);
-    if constexpr (SDF) apply_patch_row(m, sc.materials[sc.sdf.material], (row >> (ns + np)) & 1u, second);
+    for (uint32_t i = 0; i < ns; ++i) apply_patch_row(m, sc.materials[sc.spheres[i].material], (set >> i) & 1u, second);
+    for (uint32_t k = 0; k < np; ++k) apply_patch_row(m, sc.materials[sc.planes[k].material], (set >> (ns + k)) & 1u, second);
+    if constexpr (SDF) apply_patch_row(m, sc.materials[sc.sdf.material], (set >> (ns + np)) & 1u, second);
     mat_finalize(m);
     const float eta = ndd_negative ? fdiv(1.0f, m.ior) : m.ior;
     v3 spec_col, sheen_col;
@@ -778,6 +778,39 @@ RPT_DEV void material_table_row(const S& sc, uint32_t ns, uint32_t np, uint32_t 
     r[kMatRowMore + 1] = make_float4(x.dm, x.gtr1_a2m1, x.gtr1_k, x.cc_a2);
     static_assert(kMatRowMore + 2 == (int)kMatRowFloat4s, "row layout");
 }
+template <bool SDF, class S>
+RPT_DEV void material_table_row(const S& sc, uint32_t ns, uint32_t np, uint32_t row, float4* rows)
+{
+    const uint32_t nb = ns + np + (SDF ? 1u : 0u);
+    material_table_row_of<SDF>(sc, ns, np, row & ((1u << nb) - 1u), (row >> nb) & 1u, (row >> (nb + 1u)) & 1u, row, rows);
+}
+
+// The table by CLASS of accepted set (launch.h, MatClassMap: scenes of five to eight primitives): row = class | the checker's second
+// colour << 4 | (normal . ray < 0) << 5, the class looked up in a byte table in LDS.  Otherwise MaterialTable<false>.
+constexpr uint32_t kMatClassBits = 4u;
+struct MaterialTableMapped {
+    static constexpr bool kTable = true;
+    typedef MatRow MatType;
+    const float4* rows;
+    const uint8_t* cls;                        // [256] in LDS
+    uint32_t ns, np;
+    uint32_t proc_bit;
+    float proc_scale, proc_offset;
+    template <class S>
+    RPT_DEV void fetch(const S& sc, const RayD& ray, uint32_t accepted, bool ndd_negative, MatRow& m, float& eta, v3& emission) const
+    {
+        (void)sc;
+        bool second = false;
+        if (proc_bit != 0u) { if (accepted & proc_bit) second = checker_second(proc_scale, proc_offset, ray.d); }
+        const uint32_t set = (accepted & ((1u << ns) - 1u)) | (((accepted >> kMaxSpheres) & ((1u << np) - 1u)) << ns);
+        const uint32_t row = (uint32_t)cls[set] | ((second ? 1u : 0u) << kMatClassBits) | ((ndd_negative ? 1u : 0u) << (kMatClassBits + 1u));
+        const float4* r = rows + row * kMatRowFloat4s;
+        const float4 em = r[1];
+        emission = mk3(em.x, em.y, em.z);
+        eta = r[4].w;
+        m.more = r + kMatRowMore;
+    }
+};
 
 // Head of direct_light (tracer.rs:130-145): pick a light, sample it.  Returns the facing test of tracer.rs:147.
 // OFFSET false: the estimate is taken at a point inside a medium (media, dev_media.h): scatter_pos is `fhp` itself.

@@ -154,6 +154,20 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
     const SceneSmall& s = kernarg_scene(sc);
     render_regen_body(s, rp, material_table_build<false>(s, uniform_here(s.n_spheres), uniform_here(s.n_planes), s_rows));
 }
+// ... and for scenes of FIVE TO EIGHT primitives whose accepted sets fall into at most 16 classes of equal material (launch.h,
+// MatClassMap): the same 64 rows, indexed by class.  The map is the kernel's third argument, read from the kernarg segment.
+__global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_maptable_kernel)(const SceneSmall sc, const RenderParams rp, const MatClassMap map)
+{
+    __shared__ float4 s_rows[kMatTableRowsWide * kMatRowFloat4s];
+    __shared__ uint8_t s_cls[256];
+    const SceneSmall& s = kernarg_scene(sc);
+    // (the map where the launch put it: the kernarg segment is laid out like a struct of the arguments; read through a pointer, its
+    //  per-lane reads are plain loads — indexed as a by-value argument the compiler would copy it to every lane's scratch)
+    struct Args { SceneSmall sc; RenderParams rp; MatClassMap map; };
+    (void)map;
+    const MatClassMap& m = *(const MatClassMap*)((const char*)(const void*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Args, map));
+    render_regen_body(s, rp, material_table_build_mapped(s, m, uniform_here(s.n_spheres), uniform_here(s.n_planes), s_rows, s_cls));
+}
 #ifndef RPT_RELAXED_BUILD                                           // (media have no relaxed form)
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_media_kernel)(const WithMedia<SceneSmall> sc, const RenderParams rp) { render_regen_body(kernarg_scene(sc), rp); }
 #endif
@@ -175,6 +189,7 @@ hipError_t render_small(const SceneSmall& sc, bool media, bool nested, const Ren
     else if (kc.sized && kc.material_table) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_table_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     else if (kc.sized) hipLaunchKernelGGL(RPT_K(render_small_regen_sized_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     else if (kc.material_table || kc.material_table_wide) hipLaunchKernelGGL(RPT_K(render_small_regen_table_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
+    else if (kc.material_table_mapped) hipLaunchKernelGGL(RPT_K(render_small_regen_maptable_kernel), tiles, wg, kc.extra_lds, st, sc, rp, kc.class_map);
     else hipLaunchKernelGGL(RPT_K(render_small_regen_kernel), tiles, wg, kc.extra_lds, st, sc, rp);
     return hipGetLastError();
 }

@@ -439,7 +439,26 @@ RPT_DEV MaterialTable<SDF> material_table_build(const S& sc, uint32_t ns, uint32
     __syncthreads();
     MaterialTable<SDF> t;
     t.rows = rows; t.ns = ns; t.np = np;
-    material_table_procedural(sc, ns, np, t);
+    material_table_procedural<SDF>(sc, ns, np, t);
+    return t;
+}
+// ... by class of accepted set (dev_integrator.h, MaterialTableMapped): 64 rows, of which the classes there are get built; the class
+// of every accepted set goes to `cls_lds`.  `map`: the launch's MatClassMap in the kernarg segment.
+template <class S>
+RPT_DEV MaterialTableMapped material_table_build_mapped(const S& sc, const MatClassMap& map, uint32_t ns, uint32_t np, float4* rows, uint8_t* cls_lds)
+{
+    const uint32_t tid = threadIdx.x;
+    cls_lds[tid] = map.cls[tid];
+    const uint32_t c = tid & (kMatClasses - 1u);
+    if (tid < 4u * kMatClasses && c < map.n_classes) {
+        const uint32_t set16 = map.class_set[c];                    // spheres in bits 0-7, planes in bits 8-11
+        const uint32_t set = (set16 & ((1u << ns) - 1u)) | (((set16 >> kMaxSpheres) & ((1u << np) - 1u)) << ns);
+        RPT_ROW_NS::material_table_row_of<false>(sc, ns, np, set, (tid >> kMatClassBits) & 1u, (tid >> (kMatClassBits + 1u)) & 1u, tid, rows);
+    }
+    __syncthreads();
+    MaterialTableMapped t;
+    t.rows = rows; t.cls = cls_lds; t.ns = ns; t.np = np;
+    material_table_procedural<false>(sc, ns, np, t);
     return t;
 }
 // Which scenes: the host's side of the same rule (render(), below).

@@ -324,6 +324,38 @@ def _table_scene(rpt, which):
                        rpt.Material(roughness=0.9, checker_dir=(0.5, 100.0, 0.25, 0.1)), rpt.Material(rgb=(0.7, 0.7, 0.8), roughness=0.4)]
         s.spheres = [((-0.9, 0.0, 0.0), 1.0, 0), ((1.0, -0.2, 0.3), 0.8, 1)]
         s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2), ((0.0, 0.0, 1.0), (0.0, 0.0, -2.5), 0.0001, 3)]
+    elif which in ("five spheres on a floor", "six spheres two planes", "six primitives partial patches", "eight primitives many classes"):
+        # five to eight primitives (round 6): the table by CLASS of accepted set (launch.h, MatClassMap) — whole materials: n + 1 classes;
+        # patches that write different fields: more, up to 16; beyond that the material is built per hit
+        full = scenes.full_material
+        if which == "five spheres on a floor":
+            s.materials = [full(rgb=(0.9, 0.3, 0.2), clearcoat=1.0, clearcoat_gloss=0.7, roughness=0.4), full(rgb=(0.8, 0.8, 0.9), roughness=0.15, metallic=1.0, anisotropic=0.6),
+                           full(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5), full(rgb=(0.2, 0.7, 0.3), roughness=0.6, sheen=0.8, subsurface=0.4),
+                           full(rgb=(0.9, 0.8, 0.1), roughness=0.3, metallic=1.0), rpt.Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1))]
+            s.spheres = [((0.2, 0.0, -0.6), 1.0, 0), ((-1.3, -0.3, 0.4), 0.7, 1), ((1.4, -0.4, 0.5), 0.6, 2), ((-0.4, -0.6, 1.1), 0.4, 3), ((0.6, -0.65, 1.3), 0.35, 4)]
+            s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 5)]
+        elif which == "six spheres two planes":
+            s.materials = [full(rgb=(0.9, 0.3, 0.2), roughness=0.4), full(rgb=(0.8, 0.8, 0.9), roughness=0.15, metallic=1.0),
+                           full(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5), full(rgb=(0.2, 0.7, 0.3), roughness=0.6, sheen=0.8),
+                           full(rgb=(0.9, 0.8, 0.1), roughness=0.3, metallic=1.0), full(rgb=(0.3, 0.3, 0.9), roughness=0.2, clearcoat=1.0, clearcoat_gloss=1.0),
+                           rpt.Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1)), full(rgb=(0.7, 0.7, 0.8), roughness=0.5)]
+            s.spheres = [((0.2, 0.0, -0.6), 1.0, 0), ((-1.3, -0.3, 0.4), 0.7, 1), ((1.4, -0.4, 0.5), 0.6, 2), ((-0.4, -0.6, 1.1), 0.4, 3), ((0.6, -0.65, 1.3), 0.35, 4),
+                         ((0.1, 1.3, -0.2), 0.5, 5)]
+            s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 6), ((0.0, 0.0, 1.0), (0.0, 0.0, -3.0), 0.0001, 7)]
+        elif which == "six primitives partial patches":
+            # spheres through each other whose patches write different fields (analytical.rs:56-58 writes field by field): sets with
+            # the same last writers share a class, the others do not
+            s.materials = [rpt.Material(rgb=(0.9, 0.3, 0.2), clearcoat=1.0, clearcoat_gloss=0.7), rpt.Material(roughness=0.15, metallic=1.0, anisotropic=0.6),
+                           full(rgb=(0.2, 0.4, 0.9), roughness=0.5), full(rgb=(0.9, 0.9, 0.2), roughness=0.3, sheen=0.7),
+                           full(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5), rpt.Material(roughness=0.8, checker_dir=(0.5, 100.0, 0.25, 0.1))]      # 14 classes
+            s.spheres = [((0.2, 0.0, -0.6), 1.0, 0), ((-0.3, 0.1, 0.2), 0.9, 1), ((1.4, -0.4, 0.5), 0.6, 2), ((-1.5, -0.5, 0.8), 0.5, 3), ((0.7, -0.6, 1.2), 0.4, 4)]
+            s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 5)]
+        else:
+            # eight primitives whose patches each write one field of their own: 2^7 combinations of last writers, far more than 16 classes
+            names = ["metallic", "roughness", "subsurface", "sheen", "clearcoat", "specular_tint", "anisotropic"]
+            s.materials = [rpt.Material(**{n: 0.7}) for n in names] + [rpt.Material(roughness=0.9, checker_dir=(0.5, 100.0, 0.25, 0.1))]
+            s.spheres = [((-1.5 + 0.5 * i, -0.2 + 0.1 * (i % 3), 0.3 * (i % 2)), 0.6, i) for i in range(7)]
+            s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 7)]
     elif which == "one plane two lights":
         s.spheres = []
         s.lights = list(s.lights) + [rpt.AnalyticalLight.spherical((-2.0, 1.5, 1.0), 0.5, (4.0, 4.0, 8.0))]
@@ -333,7 +365,8 @@ def _table_scene(rpt, which):
 
 
 _TABLE_CASES = ["reference", "overlapping patches", "camera inside glass", "checker on a sphere", "extreme materials", "two checkers", "sdf", "sdf no sphere", "sdf two spheres",
-                "sdf checker object", "three spheres", "one sphere two planes", "one plane two lights", "three spheres on a floor", "two spheres two planes", "sdf two lights", "sdf two planes", 2, 5, 9, 13, 17, 21, 26, 33]
+                "sdf checker object", "three spheres", "one sphere two planes", "one plane two lights", "three spheres on a floor", "two spheres two planes", "sdf two lights", "sdf two planes",
+                "five spheres on a floor", "six spheres two planes", "six primitives partial patches", "eight primitives many classes", 2, 5, 9, 13, 17, 21, 26, 33]
 
 
 def test_the_material_table_holds_what_every_hit_would_compute(rpt, oracle, torch_cuda):
@@ -383,5 +416,18 @@ for which in T._TABLE_CASES:
             t.render_n(buf, n)
         torch_cuda.cuda.synchronize()
         got = buf.pixels.cpu().numpy()
-        t.close()
+        t_handle = t._h
         assert_bit_identical(got, want, "material table, scene %r" % (which,))
+        # the kernel aimed at is the one that ran (the last launch: 3 samples, the megakernel)
+        choice = C.c_uint32()
+        assert rpt.lib().rpt_debug_kernel_choice(t_handle, C.byref(choice)) == 0
+        # (bits that must be set, bits that must not, classes: None = between 8 and 16)
+        expect = {"reference": (1 | 2, 8, 0), "three spheres on a floor": (4, 2 | 8, 0), "five spheres on a floor": (8, 2 | 4, 12), "six spheres two planes": (8, 2 | 4, 15),
+                  "six primitives partial patches": (8, 2 | 4, None), "eight primitives many classes": (0, 2 | 4 | 8, 0), "two checkers": (0, 2 | 4 | 8, 0)}.get(which)
+        if expect is not None:
+            assert choice.value & expect[0] == expect[0] and choice.value & expect[1] == 0, (which, hex(choice.value))
+            if expect[2] is None:
+                assert 7 < (choice.value >> 8) & 0xFF <= 16, (which, hex(choice.value))
+            else:
+                assert (choice.value >> 8) & 0xFF == expect[2], (which, hex(choice.value))
+        t.close()

@@ -9,7 +9,8 @@ sys.path.insert(0, %r)
 import conftest, torch
 rpt = conftest.load_package()
 import test_gpu_dispatch as T
-for which in ("three spheres", "one sphere two planes", "three spheres on a floor", "two spheres two planes", "sdf two lights"):
+for which in ("three spheres", "one sphere two planes", "three spheres on a floor", "two spheres two planes", "sdf two lights",
+              "five spheres on a floor", "six spheres two planes", "six primitives partial patches"):
     s, _ = T._table_scene(rpt, which)
     t = rpt.Tracer(s, device=0, seed=1)
     buf = rpt.DeviceColorBuffer(1920, 1080)
