@@ -296,6 +296,8 @@ def other_configs(rpt, torch, device, small):
                         "c3_sdf": out["roofline_c4"]["value"], "c3_sdf_frac": out["roofline_c4"]["frac"],
                         "c4_large": out["roofline_c5"]["value"], "c4_large_frac": out["roofline_c5"]["frac"],
                         "general": out.get("general_kernels", {}).get("value"), "relaxed": out.get("relaxed", {}).get("value"),
+                        "six_primitives": out.get("six_primitives", {}).get("value"),
+                        "six_primitives_material_per_hit": out.get("six_primitives", {}).get("value_material_per_hit"),
                         "relaxed_rmse": out.get("relaxed", {}).get("rmse_vs_strict"),
                         "c2_projected_8gpu": out["c3_rank_tiles"].get("projected_value"),
                         "c2_projected_scaling": out["c3_rank_tiles"].get("projected_scaling_vs_whole_frame"),
@@ -379,8 +381,13 @@ def general_kernels_leg(small):
     buf = rpt.DeviceColorBuffer(w, h, device="cuda:0")
     t = timed_steps(torch, tracer, buf, spp, 5)
     tracer.close()
+    from rust_pathtracer_amd import scenes
+    tracer = rpt.Tracer(scenes.six_primitive_scene(), device=0, seed=1)
+    t6 = timed_steps(torch, tracer, buf, spp, 5)
+    tracer.close()
     print("GENERAL " + json.dumps({"value": round(w * h * spp / t / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(t * 1e3, 3),
                                    "kernel": "render_small_regen_kernel",
+                                   "six_primitives_value": round(w * h * spp / t6 / 1e6, 2),
                                    "workload": "AnalyticalScene %dx%d x %d spp per step with RPT_NO_SIZED_KERNELS=1 RPT_NO_MATERIAL_TABLE=1" % (w, h, spp)}))
 
 
@@ -414,6 +421,21 @@ def headline_variants(rpt, torch, device, small):
                                               "per hit; the headline value is the sized + material-table instantiation of the same kernel")
     except Exception as e:      # noqa: BLE001 - a secondary leg must not cost the line
         out["general_kernels"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        # A small scene of MORE than four primitives (scenes.six_primitive_scene: five spheres on the checker floor): until round 6 every
+        # such scene took the kernel that builds the material per hit; now its accepted sets are sorted into classes of equal material on
+        # the host and the megakernel reads 64 LDS rows by class (csrc/launch.h, MatClassMap).
+        from rust_pathtracer_amd import scenes
+        six = rpt.Tracer(scenes.six_primitive_scene(), device=device, seed=1)
+        t6 = timed_steps(torch, six, rpt.DeviceColorBuffer(w, h, device="cuda:%d" % device), spp, 5)
+        six.close()
+        out["six_primitives"] = {"value": round(w * h * spp / t6 / 1e6, 2), "unit": "Msamples/s", "kernel_ms": round(t6 * 1e3, 3),
+                                 "kernel": "render_small_regen_maptable_kernel",
+                                 "value_material_per_hit": out.get("general_kernels", {}).get("six_primitives_value"),
+                                 "workload": "five spheres with whole materials on the checker floor, %dx%d x %d spp per step: the material table by class "
+                                             "of accepted set (12 classes); value_material_per_hit: the same scene with RPT_NO_MATERIAL_TABLE=1" % (w, h, spp)}
+    except Exception as e:      # noqa: BLE001
+        out["six_primitives"] = {"error": "%s: %s" % (type(e).__name__, e)}
     try:
         A = rpt._abi
         strict = rpt.Tracer(rpt.AnalyticalScene(), device=device, seed=1)

@@ -99,6 +99,23 @@ def random_spheres_scene(n_spheres=10000, n_lights=16, seed=0x5EED0005, n_palett
     return s
 
 
+def six_primitive_scene():
+    """Five spheres with whole materials on the reference's checker floor: a small scene of more than four primitives — what
+    bench.py's `six_primitives` leg renders (the material table by class of accepted set, csrc/launch.h MatClassMap) and
+    tests/test_gpu_dispatch.py checks against the oracle ("five spheres on a floor")."""
+    from .api import AnalyticalScene
+    s = AnalyticalScene()
+    s.materials = [full_material(rgb=(0.9, 0.3, 0.2), clearcoat=1.0, clearcoat_gloss=0.7, roughness=0.4),
+                   full_material(rgb=(0.8, 0.8, 0.9), roughness=0.15, metallic=1.0, anisotropic=0.6),
+                   full_material(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5),
+                   full_material(rgb=(0.2, 0.7, 0.3), roughness=0.6, sheen=0.8, subsurface=0.4),
+                   full_material(rgb=(0.9, 0.8, 0.1), roughness=0.3, metallic=1.0),
+                   Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1))]
+    s.spheres = [((0.2, 0.0, -0.6), 1.0, 0), ((-1.3, -0.3, 0.4), 0.7, 1), ((1.4, -0.4, 0.5), 0.6, 2), ((-0.4, -0.6, 1.1), 0.4, 3), ((0.6, -0.65, 1.3), 0.35, 4)]
+    s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 5)]
+    return s
+
+
 def sdf_scene():
     """BASELINE.json configs[3] (project-defined; the reference has no SDF scene, Readme.md:18): a
     sphere-marched blob — the polynomial smooth union of two spheres and a torus — over the reference's

@@ -329,11 +329,7 @@ def _table_scene(rpt, which):
         # patches that write different fields: more, up to 16; beyond that the material is built per hit
         full = scenes.full_material
         if which == "five spheres on a floor":
-            s.materials = [full(rgb=(0.9, 0.3, 0.2), clearcoat=1.0, clearcoat_gloss=0.7, roughness=0.4), full(rgb=(0.8, 0.8, 0.9), roughness=0.15, metallic=1.0, anisotropic=0.6),
-                           full(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5), full(rgb=(0.2, 0.7, 0.3), roughness=0.6, sheen=0.8, subsurface=0.4),
-                           full(rgb=(0.9, 0.8, 0.1), roughness=0.3, metallic=1.0), rpt.Material(roughness=1.0, checker_dir=(0.5, 100.0, 0.25, 0.1))]
-            s.spheres = [((0.2, 0.0, -0.6), 1.0, 0), ((-1.3, -0.3, 0.4), 0.7, 1), ((1.4, -0.4, 0.5), 0.6, 2), ((-0.4, -0.6, 1.1), 0.4, 3), ((0.6, -0.65, 1.3), 0.35, 4)]
-            s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 5)]
+            s = scenes.six_primitive_scene()                          # (bench.py's `six_primitives` leg)
         elif which == "six spheres two planes":
             s.materials = [full(rgb=(0.9, 0.3, 0.2), roughness=0.4), full(rgb=(0.8, 0.8, 0.9), roughness=0.15, metallic=1.0),
                            full(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5), full(rgb=(0.2, 0.7, 0.3), roughness=0.6, sheen=0.8),
