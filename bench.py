@@ -665,6 +665,9 @@ def main():
     if args.general_kernels_leg:
         return general_kernels_leg(args.small)
 
+    # (the host driver of this pool supports dmabuf IPC only: without this RCCL's peer mappings fail with `hipIpcGetMemHandle: invalid
+    #  argument`; the launcher's environment normally carries it already)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import __graft_entry__ as entry
     rpt = entry._load_package()

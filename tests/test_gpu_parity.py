@@ -92,6 +92,45 @@ def test_probe_pow(rpt, torch_cuda, tracer, oracle):
     assert_bit_identical(_probe(rpt, torch_cuda, tracer, 3, a, b), oracle.math(3, a, b), "pow")
 
 
+def test_device_libm_against_float64(rpt, torch_cuda, tracer):
+    """include/rpt_strict_math.h is the one source oracle and kernels share, so "HIP equals oracle" on sin / cos / log2 / pow says
+    that two compilers agree on it, not that it is right.  This test does not load the oracle: what the DEVICE
+    returns against NumPy's float64 functions, in ulps of the float32 result — the bounds the header claims (sin / cos 1.5 ulp on the
+    path's domain, log2 / pow / exp / log 0.5001: almost always the correctly rounded float32), and division and square root
+    correctly rounded outright (0.5 ulp, and equal to the rounded float64 result)."""
+    A = rpt._abi
+    rng = np.random.default_rng(77)
+    n = 1_000_000
+
+    def ulps(got, ref64):
+        ref32 = ref64.astype(np.float32)
+        return np.abs(got.astype(np.float64) - ref64) / np.spacing(np.abs(ref32)).astype(np.float64)
+
+    x = rng.uniform(0, 2 * np.pi, n).astype(np.float32)
+    for fn, f in ((0, np.sin), (1, np.cos)):
+        got, ref = _probe(rpt, torch_cuda, tracer, fn, x), f(x.astype(np.float64))
+        big = np.abs(ref) > 1e-3                                     # (near a zero the ulp is tiny: the absolute error counts there)
+        assert ulps(got, ref)[big].max() <= 1.5 and np.abs(got - ref).max() < 1.2e-7, f.__name__
+    x = rng.integers(0x00800000, 0x7f7fffff, size=n, dtype=np.uint32).view(np.float32)          # every positive normal f32
+    got, ref = _probe(rpt, torch_cuda, tracer, 2, x), np.log2(x.astype(np.float64))
+    assert ulps(got, ref).max() <= 0.5001 and (got == ref.astype(np.float32)).mean() > 0.99999, "log2"
+    got, ref = _probe(rpt, torch_cuda, tracer, A.RPT_PROBE_LOG, x), np.log(x.astype(np.float64))
+    assert ulps(got, ref).max() <= 0.5001, "log"
+    # pow as the path uses it: the background's x^2.2 (scene.rs:32-34), convert_to_u8's x^0.4545 (buffer.rs:59), sqrt-like 0.5, any y in (0, 3)
+    a = rng.uniform(1e-4, 4.0, n).astype(np.float32)
+    for b in (np.full(n, 2.2, dtype=np.float32), np.full(n, 0.4545, dtype=np.float32), np.full(n, 0.5, dtype=np.float32), rng.uniform(0, 3, n).astype(np.float32)):
+        got, ref = _probe(rpt, torch_cuda, tracer, 3, a, b), np.power(a.astype(np.float64), b.astype(np.float64))
+        assert ulps(got, ref).max() <= 0.5001, "pow, y = %r" % (b[0],)
+    x = rng.uniform(-80, 80, n).astype(np.float32)
+    got, ref = _probe(rpt, torch_cuda, tracer, A.RPT_PROBE_EXP, x), np.exp(x.astype(np.float64))
+    assert ulps(got, ref).max() <= 0.5001, "exp"
+    # the IEEE operations: the float64 quotient / root of two float32s rounds to the correctly rounded float32 (double rounding cannot
+    # bite: 53 >= 2 * 24 + 2), results in the normal range
+    a, b = rng.uniform(-1e3, 1e3, n).astype(np.float32), rng.uniform(0.01, 1e3, n).astype(np.float32)
+    assert np.array_equal(_probe(rpt, torch_cuda, tracer, A.RPT_PROBE_DIV, a, b), (a.astype(np.float64) / b.astype(np.float64)).astype(np.float32)), "divide"
+    assert np.array_equal(_probe(rpt, torch_cuda, tracer, 5, b), np.sqrt(b.astype(np.float64)).astype(np.float32)), "square root"
+
+
 def test_probe_div_sqrt_are_correctly_rounded(rpt, torch_cuda, tracer, oracle):
     rng = np.random.default_rng(14)
     n = 3_000_000
