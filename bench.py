@@ -41,7 +41,7 @@ C3 = (3840, 2160, 1024)        # BASELINE.json configs[2]
 # ranks still balance.
 TILE_ROWS = 8
 SECONDARY_LIMIT_S = int(os.environ.get("RPT_BENCH_SECONDARY_LIMIT_S", "150"))        # N > 1: the legs after the headline (weak scaling, the one-GPU frame, configs[4]) may take this long together
-PROFILES = os.path.join("profiles", "r5")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
+PROFILES = os.path.join("profiles", "r6")                    # committed rocprofv3 summaries of this command (tools/collect_profiles.sh)
 # What a correctly rounded f32 divide / square root costs the VALU in this library (csrc/dev_math.h): a quotient is v_rcp + 2 fma
 # shared by the numerators of one denominator, then mul + 2 fma + v_div_fixup each; a root is v_rsq + 2 mul + 2 fma; plus the range
 # test.  Small scenes' megakernel tracks the operands (v_frexp_exp + v_max3 per divide, v_frexp_exp + v_min per root; the two DS
