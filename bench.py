@@ -274,7 +274,7 @@ def other_configs(rpt, torch, device, small):
         gbs = algo / t / 1e9
         c, tr_src = counters_for("denoise_1080p" if name.endswith("1080p") else "denoise_4k", rpt._lib.LIB_PATH) if not small else (None, None)
         tr = c["hbm_bytes_per_launch"] if c else None
-        out[name] = {"bound": "lds/issue", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+        out[name] = {"bound": "latency (barriers and LDS reads between the fused stages)", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                      "traffic": tr, **({"traffic_source": tr_src} if tr_src else {}),
                      **({"counter_GBs": round(tr / t / 1e9, 1), "counter_frac": round(tr / t / 1e9 / HBM_PEAK_GBS, 4)} if tr else {}),
                      **({"wait_inst_lds_share_of_wave_time": c["wait_inst_lds_share"]} if c and "wait_inst_lds_share" in c else {}),
@@ -283,8 +283,10 @@ def other_configs(rpt, torch, device, small):
                      "algorithmic_bytes_per_step": algo,
                      "three_pass_equivalent_GBs": round(iters * algo / t / 1e9, 1),
                      "note": "NOT HBM-bound: `achieved` is the fused kernel's algorithmic 32 B per pixel over its time, `counter_GBs` what the PMC "
-                             "passes saw it move; the kernel waits on its LDS taps and the barriers between its stages (profiles/%s/denoise/summary.txt); "
-                             "three_pass_equivalent_GBs is what rounds 4-5 printed as `achieved`" % PROFILES.split(os.sep)[-1],
+                             "passes saw it move; its waves spend 24 / 30 / 46 %% of their time issuing / stalled / in s_waitcnt behind the barriers and "
+                             "LDS reads between the stages, at 99 %% lane utilisation and 7 waves per SIMD; waiting for the LDS unit to ISSUE is 3 %% "
+                             "(SQ_WAIT_INST_LDS: wait_inst_lds_share_of_wave_time) (profiles/%s/denoise/summary.txt); three_pass_equivalent_GBs is what "
+                             "rounds 4-5 printed as `achieved`" % PROFILES.split(os.sep)[-1],
                      "workload": "a-trous denoiser, %d iterations on a %dx%d RGBA f32 buffer" % (iters, dw, dh)}
         del buf
     try:
