@@ -63,7 +63,7 @@ int rpt_debug_sched_read(rpt_ctx* ctx, uint32_t* out, uint32_t capacity_tiles, u
 
 /* Which instantiation of its kernel class the context's last render launch took on its first device (csrc/launch.h, KernelChoice):
  * bit 0 the table sizes known at compile time, bit 1 the material table (at most 3 primitives), bit 2 its 64-row form (4 primitives),
- * bit 3 the table by class of accepted set (5-8 primitives), bits 8-15 the number of classes then, bits 16-19 the SDF object's
+ * bit 3 the table by class of accepted set (5-12 primitives), bits 8-15 the number of classes then, bits 16-19 the SDF object's
  * compile-time primitive count.  For tests that must know that the kernel they aim at is the one that ran. */
 int rpt_debug_kernel_choice(rpt_ctx* ctx, uint32_t* out);
 

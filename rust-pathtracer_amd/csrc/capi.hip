@@ -86,6 +86,8 @@ struct rpt_ctx {
     bool large = false;               // scene exceeds the kernarg tables: SceneLarge + device tables
     bool media = false;               // RPT_SCENE_MEDIA and some material carries a medium: the media kernels (dev_media.h)
     SceneSmallSdf scene;              // camera part is filled per launch (depends on width/height); sdf.n_prims == 0: plain
+    bool class_map_ok = false;        // small scenes of 5-12 primitives: their accepted sets fall into at most 16 classes of equal material
+    MatClassMap class_map = {};       // (launch.h; `cls` is filled per device at launch: the 4 096-byte map is DevState::tables of such a scene)
     rpt_camera camera;
     // resident ColorBuffer (buffer.rs:6-14): pixels as per-rank tiles + frames
     uint32_t res_w = 0, res_h = 0, res_tile_rows = 0, res_rows_padded = 0;
@@ -428,14 +430,14 @@ static int sched_for(rpt_ctx* ctx, DevState& d, uint32_t nblocks, uint32_t width
     return RPT_OK;
 }
 
-// The classes of accepted sets of a small scene of 5-8 primitives (launch.h, MatClassMap).  The material of a hit is Material::new()
+// The classes of accepted sets of a small scene of 5-12 primitives (launch.h, MatClassMap).  The material of a hit is Material::new()
 // overwritten field by field by the accepted primitives in order (apply_patch_fields; a procedural patch writes rgb whatever its
 // mask says: apply_patch_row), so two sets give the same material when every field has the same last writer in both.  False: the
-// scene is not one the mapped table serves (fewer than 5 or more than 8 primitives, two procedural materials, more than 16 classes).
-static bool material_class_map(const SceneSmall& sc, MatClassMap& map)
+// scene is not one the mapped table serves (fewer than 5 primitives, two procedural materials, more than 16 classes).
+static bool material_class_map(const SceneSmall& sc, MatClassMap& map, std::vector<uint8_t>& cls)
 {
     const uint32_t ns = sc.n_spheres, np = sc.n_planes, nb = ns + np;
-    if (nb < 5u || nb > 8u) return false;
+    if (nb < 5u || nb > 12u) return false;
     uint32_t n_procedural = 0;
     uint32_t mask_of[kMaxSpheres + kMaxPlanes];
     for (uint32_t i = 0; i < nb; ++i) {
@@ -445,6 +447,7 @@ static bool material_class_map(const SceneSmall& sc, MatClassMap& map)
     }
     if (n_procedural > 1u) return false;
     memset(&map, 0, sizeof(map));
+    cls.assign(4096, 0);
     struct Signature { uint8_t last[13]; bool operator==(const Signature& o) const { return memcmp(last, o.last, sizeof(last)) == 0; } };
     std::vector<Signature> classes;
     for (uint32_t set = 0; set < (1u << nb); ++set) {
@@ -460,7 +463,7 @@ static bool material_class_map(const SceneSmall& sc, MatClassMap& map)
             classes.push_back(sig);
             map.class_set[c] = (uint16_t)((set & ((1u << ns) - 1u)) | ((set >> ns) << kMaxSpheres));      // (GeomHit.code's layout: planes from bit 8)
         }
-        map.cls[set] = (uint8_t)c;
+        cls[set] = (uint8_t)c;
     }
     map.n_classes = (uint32_t)classes.size();
     return true;
@@ -520,9 +523,13 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
         kc.sized_sdf = (can_size && has_sdf && sc.n_planes == 1u && sc.n_lights == 1u && scs.sdf.n_prims <= 4u) ? scs.sdf.n_prims : 0u;
         kc.material_table = !knobs().no_material_table && !ctx->media && !ctx->large && !nested && rptlaunch::material_table_fits_small(scs, has_sdf);      // (with or without the sizes)
         kc.material_table_wide = !knobs().no_material_table && !ctx->media && !ctx->large && !nested && !has_sdf && !rp.compact && rptlaunch::material_table_fits_small(scs, false, 4u);
-        // five to eight primitives: the table by class of accepted set (launch.h, MatClassMap), in the megakernel of small scenes
-        if (!kc.material_table && !kc.material_table_wide && !knobs().no_material_table && !ctx->media && !ctx->large && !nested && !has_sdf && !rp.compact)
-            kc.material_table_mapped = material_class_map(sc, kc.class_map);
+        // five to twelve primitives: the table by class of accepted set (launch.h, MatClassMap), in the megakernel of small scenes
+        if (!kc.material_table && !kc.material_table_wide && !knobs().no_material_table && !ctx->media && !ctx->large && !nested && !has_sdf && !rp.compact &&
+            ctx->class_map_ok && d.tables) {
+            kc.material_table_mapped = true;
+            kc.class_map = ctx->class_map;
+            kc.class_map.cls = reinterpret_cast<const uint8_t*>(d.tables);
+        }
         kc.extra_lds = knobs().debug_extra_lds;
         d.last_choice = (kc.sized ? 1u : 0u) | (kc.material_table ? 2u : 0u) | (kc.material_table_wide ? 4u : 0u) | (kc.material_table_mapped ? 8u : 0u) |
                         ((kc.material_table_mapped ? kc.class_map.n_classes : 0u) << 8) | (kc.sized_sdf << 16);
@@ -997,6 +1004,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
             if (use_accel) accel.bind(L, base + sz_tables);
         }
         ctx->camera = s->camera;
+        ctx->class_map_ok = false;
         ctx->large = true;
         ctx->media = media;
         ctx->has_scene = true;
@@ -1004,7 +1012,7 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
         return RPT_OK;
     }
 
-    for (DevState& d : ctx->devs) {                                 // a small scene needs no tables: drop a previous large scene's
+    for (DevState& d : ctx->devs) {                                 // drop the previous scene's tables (a large scene's, or a small one's class map)
         if (!d.tables) continue;
         DeviceGuard guard(d.device);
         RPT_HIP_CHECK(ctx, guard.status);
@@ -1032,6 +1040,18 @@ int rpt_upload_scene(rpt_ctx* ctx, const rpt_scene_desc* s)
     for (uint32_t i = 0; i < s->sdf.n_prims; ++i) {
         const rpt_sdf_prim& a = s->sdf.prims[i];
         d.sdf.prims[i] = DevSdfPrim{a.center[0], a.center[1], a.center[2], a.params[0], a.params[1], a.kind, {0u, 0u}};
+    }
+    // five to twelve primitives: the classes of accepted sets the material table is indexed by (launch.h, MatClassMap), once per scene;
+    // the 4 096-byte map lives in each device's `tables`
+    std::vector<uint8_t> cls;
+    ctx->class_map_ok = s->sdf.n_prims == 0 && !media && material_class_map(static_cast<const SceneSmall&>(d), ctx->class_map, cls);
+    if (ctx->class_map_ok) {
+        for (DevState& dv : ctx->devs) {
+            DeviceGuard guard(dv.device);
+            RPT_HIP_CHECK(ctx, guard.status);
+            RPT_HIP_CHECK(ctx, hipMalloc(&dv.tables, cls.size()));
+            RPT_HIP_CHECK(ctx, hipMemcpy(dv.tables, cls.data(), cls.size(), hipMemcpyHostToDevice));
+        }
     }
     ctx->camera = s->camera;
     ctx->large = false;

@@ -785,14 +785,14 @@ RPT_DEV void material_table_row(const S& sc, uint32_t ns, uint32_t np, uint32_t 
     material_table_row_of<SDF>(sc, ns, np, row & ((1u << nb) - 1u), (row >> nb) & 1u, (row >> (nb + 1u)) & 1u, row, rows);
 }
 
-// The table by CLASS of accepted set (launch.h, MatClassMap: scenes of five to eight primitives): row = class | the checker's second
+// The table by CLASS of accepted set (launch.h, MatClassMap: scenes of five to twelve primitives): row = class | the checker's second
 // colour << 4 | (normal . ray < 0) << 5, the class looked up in a byte table in LDS.  Otherwise MaterialTable<false>.
 constexpr uint32_t kMatClassBits = 4u;
 struct MaterialTableMapped {
     static constexpr bool kTable = true;
     typedef MatRow MatType;
     const float4* rows;
-    const uint8_t* cls;                        // [256] in LDS
+    const uint8_t* cls;                        // [4096] in LDS
     uint32_t ns, np;
     uint32_t proc_bit;
     float proc_scale, proc_offset;

@@ -154,12 +154,13 @@ __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_sm
     const SceneSmall& s = kernarg_scene(sc);
     render_regen_body(s, rp, material_table_build<false>(s, uniform_here(s.n_spheres), uniform_here(s.n_planes), s_rows));
 }
-// ... and for scenes of FIVE TO EIGHT primitives whose accepted sets fall into at most 16 classes of equal material (launch.h,
-// MatClassMap): the same 64 rows, indexed by class.  The map is the kernel's third argument, read from the kernarg segment.
+// ... and for scenes of FIVE TO TWELVE primitives — every small scene there is — whose accepted sets fall into at most 16 classes of
+// equal material (launch.h, MatClassMap): the same 64 rows, indexed by class.  The map is the kernel's third argument, read from the
+// kernarg segment.
 __global__ __launch_bounds__(256, RPT_SMALL_WAVES_PER_SIMD) void RPT_K(render_small_regen_maptable_kernel)(const SceneSmall sc, const RenderParams rp, const MatClassMap map)
 {
     __shared__ float4 s_rows[kMatTableRowsWide * kMatRowFloat4s];
-    __shared__ uint8_t s_cls[256];
+    __shared__ __attribute__((aligned(16))) uint8_t s_cls[4096];
     const SceneSmall& s = kernarg_scene(sc);
     // (the map where the launch put it: the kernarg segment is laid out like a struct of the arguments; read through a pointer, its
     //  per-lane reads are plain loads — indexed as a by-value argument the compiler would copy it to every lane's scratch)

@@ -448,7 +448,7 @@ template <class S>
 RPT_DEV MaterialTableMapped material_table_build_mapped(const S& sc, const MatClassMap& map, uint32_t ns, uint32_t np, float4* rows, uint8_t* cls_lds)
 {
     const uint32_t tid = threadIdx.x;
-    cls_lds[tid] = map.cls[tid];
+    reinterpret_cast<uint4*>(cls_lds)[tid] = reinterpret_cast<const uint4*>(map.cls)[tid];     // 4 096 bytes from device memory, 16 per thread
     const uint32_t c = tid & (kMatClasses - 1u);
     if (tid < 4u * kMatClasses && c < map.n_classes) {
         const uint32_t set16 = map.class_set[c];                    // spheres in bits 0-7, planes in bits 8-11

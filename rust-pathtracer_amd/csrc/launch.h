@@ -11,7 +11,7 @@
 
 #include "tile_plan.h"
 
-// The material table of a scene of FIVE TO EIGHT primitives (round 6; k_small.hip, render_small_regen_maptable_kernel).  2^n rows per
+// The material table of a scene of FIVE TO TWELVE primitives (round 6; k_small.hip, render_small_regen_maptable_kernel).  2^n rows per
 // checker colour and side do not fit the LDS beyond four primitives — but a row is a MATERIAL, and the material of a hit depends on the
 // accepted set only through which primitive wrote each field last (analytical.rs:56-58, 82-85, 115-116 are field writes): accepted sets
 // with the same last writers are one class, and a scene whose primitives carry whole materials has n + 1 of them.  The host sorts the
@@ -20,7 +20,7 @@ constexpr uint32_t kMatClasses = 16u;
 struct MatClassMap {
     uint32_t n_classes;
     uint16_t class_set[kMatClasses];    // one accepted set of each class: spheres in bits 0-7, planes in bits 8-11 (GeomHit.code's layout)
-    uint8_t cls[256];                   // accepted spheres | accepted planes << n_spheres  ->  class
+    const uint8_t* cls;                 // [4096] in device memory: accepted spheres | accepted planes << n_spheres (8 + 4 bits at most) -> class
 };
 
 // Which instantiation of a class's kernel a launch takes (capi.hip decides from the scene and the knobs, knobs.h).
@@ -29,7 +29,7 @@ struct KernelChoice {
     uint32_t sized_sdf = 0;         // SDF scenes: 1-4 primitives over one plane under one light: that many, known at compile time; 0: data
     bool material_table = false;    // a hit's material from the workgroup's table (dev_integrator.h, MaterialTable): at most 3 primitives
     bool material_table_wide = false;   // ... at most 4: the megakernel of small scenes without an SDF object only (render_small_regen_table_kernel)
-    bool material_table_mapped = false; // ... five to eight, by class (MatClassMap): the same megakernel
+    bool material_table_mapped = false; // ... five to twelve, by class (MatClassMap): the same megakernel
     MatClassMap class_map = {};
     uint32_t extra_lds = 0;         // development: pad the headline kernel's LDS (occupancy experiments)
 };

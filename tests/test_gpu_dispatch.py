@@ -324,7 +324,7 @@ def _table_scene(rpt, which):
                        rpt.Material(roughness=0.9, checker_dir=(0.5, 100.0, 0.25, 0.1)), rpt.Material(rgb=(0.7, 0.7, 0.8), roughness=0.4)]
         s.spheres = [((-0.9, 0.0, 0.0), 1.0, 0), ((1.0, -0.2, 0.3), 0.8, 1)]
         s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 2), ((0.0, 0.0, 1.0), (0.0, 0.0, -2.5), 0.0001, 3)]
-    elif which in ("five spheres on a floor", "six spheres two planes", "six primitives partial patches", "eight primitives many classes"):
+    elif which in ("five spheres on a floor", "six spheres two planes", "six primitives partial patches", "eight primitives many classes", "eight spheres four planes"):
         # five to eight primitives (round 6): the table by CLASS of accepted set (launch.h, MatClassMap) — whole materials: n + 1 classes;
         # patches that write different fields: more, up to 16; beyond that the material is built per hit
         full = scenes.full_material
@@ -346,6 +346,14 @@ def _table_scene(rpt, which):
                            full(rgb=(0.95, 0.95, 1.0), roughness=0.05, spec_trans=1.0, ior=1.5), rpt.Material(roughness=0.8, checker_dir=(0.5, 100.0, 0.25, 0.1))]      # 14 classes
             s.spheres = [((0.2, 0.0, -0.6), 1.0, 0), ((-0.3, 0.1, 0.2), 0.9, 1), ((1.4, -0.4, 0.5), 0.6, 2), ((-1.5, -0.5, 0.8), 0.5, 3), ((0.7, -0.6, 1.2), 0.4, 4)]
             s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 5)]
+        elif which == "eight spheres four planes":
+            # the kernarg tables full: twelve primitives with whole materials = 13 classes (4 096 accepted sets sorted on the host)
+            cols = [(0.9, 0.3, 0.2), (0.8, 0.8, 0.9), (0.95, 0.95, 1.0), (0.2, 0.7, 0.3), (0.9, 0.8, 0.1), (0.3, 0.3, 0.9), (0.7, 0.2, 0.7), (0.6, 0.6, 0.6)]
+            s.materials = [full(rgb=c, roughness=0.1 + 0.1 * i, metallic=float(i % 2), clearcoat=float(i % 3 == 0), clearcoat_gloss=0.5) for i, c in enumerate(cols)] + \
+                          [full(rgb=(0.5, 0.5, 0.5), roughness=0.9), full(rgb=(0.7, 0.7, 0.8), roughness=0.5), full(rgb=(0.8, 0.6, 0.5), roughness=0.7), full(rgb=(0.4, 0.6, 0.5), roughness=0.3, metallic=1.0)]
+            s.spheres = [((-1.6 + 0.45 * i, -0.3 + 0.25 * (i % 3), -0.4 + 0.35 * (i % 2)), 0.5, i) for i in range(8)]
+            s.planes = [((0.0, 1.0, 0.0), (0.0, -1.0, 0.0), 0.0001, 8), ((0.0, 0.0, 1.0), (0.0, 0.0, -3.0), 0.0001, 9),
+                        ((1.0, 0.0, 0.0), (-3.5, 0.0, 0.0), 0.0001, 10), ((-1.0, 0.0, 0.0), (3.5, 0.0, 0.0), 0.0001, 11)]
         else:
             # eight primitives whose patches each write one field of their own: 2^7 combinations of last writers, far more than 16 classes
             names = ["metallic", "roughness", "subsurface", "sheen", "clearcoat", "specular_tint", "anisotropic"]
@@ -362,7 +370,7 @@ def _table_scene(rpt, which):
 
 _TABLE_CASES = ["reference", "overlapping patches", "camera inside glass", "checker on a sphere", "extreme materials", "two checkers", "sdf", "sdf no sphere", "sdf two spheres",
                 "sdf checker object", "three spheres", "one sphere two planes", "one plane two lights", "three spheres on a floor", "two spheres two planes", "sdf two lights", "sdf two planes",
-                "five spheres on a floor", "six spheres two planes", "six primitives partial patches", "eight primitives many classes", 2, 5, 9, 13, 17, 21, 26, 33]
+                "five spheres on a floor", "six spheres two planes", "six primitives partial patches", "eight primitives many classes", "eight spheres four planes", 2, 5, 9, 13, 17, 21, 26, 33]
 
 
 def test_the_material_table_holds_what_every_hit_would_compute(rpt, oracle, torch_cuda):
@@ -419,7 +427,7 @@ for which in T._TABLE_CASES:
         assert rpt.lib().rpt_debug_kernel_choice(t_handle, C.byref(choice)) == 0
         # (bits that must be set, bits that must not, classes: None = between 8 and 16)
         expect = {"reference": (1 | 2, 8, 0), "three spheres on a floor": (4, 2 | 8, 0), "five spheres on a floor": (8, 2 | 4, 12), "six spheres two planes": (8, 2 | 4, 15),
-                  "six primitives partial patches": (8, 2 | 4, None), "eight primitives many classes": (0, 2 | 4 | 8, 0), "two checkers": (0, 2 | 4 | 8, 0)}.get(which)
+                  "six primitives partial patches": (8, 2 | 4, None), "eight primitives many classes": (0, 2 | 4 | 8, 0), "two checkers": (0, 2 | 4 | 8, 0), "eight spheres four planes": (8, 2 | 4, 13)}.get(which)
         if expect is not None:
             assert choice.value & expect[0] == expect[0] and choice.value & expect[1] == 0, (which, hex(choice.value))
             if expect[2] is None:

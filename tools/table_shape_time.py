@@ -10,7 +10,7 @@ import conftest, torch
 rpt = conftest.load_package()
 import test_gpu_dispatch as T
 for which in ("three spheres", "one sphere two planes", "three spheres on a floor", "two spheres two planes", "sdf two lights",
-              "five spheres on a floor", "six spheres two planes", "six primitives partial patches"):
+              "five spheres on a floor", "six spheres two planes", "six primitives partial patches", "eight spheres four planes"):
     s, _ = T._table_scene(rpt, which)
     t = rpt.Tracer(s, device=0, seed=1)
     buf = rpt.DeviceColorBuffer(1920, 1080)
