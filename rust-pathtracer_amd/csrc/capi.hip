@@ -493,7 +493,7 @@ static int launch_render(rpt_ctx* ctx, DevState& d, float* pixels_dev, uint32_t 
     rp.tile_rows = tile_rows; rp.rank = rank; rp.world = world;
     rp.seed = seed;
     rp.tiles_x = (width + 15u) / 16u;
-    rp.shade_threshold = knobs().shade_threshold;
+    rp.shade_threshold = has_sdf ? knobs().sdf_shade_room : knobs().shade_threshold;      // (k_sdf.hip: the second room's threshold, 0 = one block)
     // (small scenes' megakernel only; 8 ... 48 are within 2 % of each other, +5.9 % over finishing un-voted)
     rp.finish_threshold = knobs().finish_threshold;
     rp.march_min_lanes = knobs().sdf_march_min_lanes;

@@ -10,7 +10,12 @@
 // for the lanes that wait.
 // A lane whose pixel has no sample left takes samples of another pixel of its wave (kernel_common.h, share_next; `q`: the pixel a lane
 // works for); a sample that is finished before its predecessor has been blended waits in S2_BLOCKED.
-enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u, S2_BLOCKED = 4u };
+enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u, S2_BLOCKED = 4u, S2_SHADE = 5u };
+// Round 6: the block is cut behind closest_hit's acceptance.  A lane that hit a SURFACE waits in a second room (S2_SHADE, one dword
+// parked: GeomHit) until rp.shade_threshold lanes do, or nobody marches or waits for the first part; the first part — the parked light
+// sample, closest_hit's acceptance, and for a path that is over the background, the blend and the pixel's next camera path — runs as
+// before.  A block used to mix both kinds (shading ran with 54 % of the lanes, finishing with 43 %); lanes that wait for the second room
+// are idle lanes of the march phases, i.e. helpers.  (Threshold 1 is round 5's one block cut in two passes.)
 // A lane's two marches between passes.  Its shadow march (the lane's own work always): s_march = {t, t_useful, steps, -}.  Its path
 // march, which ANY lane of the wave may run: t in the parked ray's direction.w, t_useful in the parked gain's .w, s_pjob = steps | hit | over;
 // s_march.w: the analytic primitives accepted before it.
@@ -46,6 +51,8 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
     uint32_t q = tid;                                               // the pixel this lane renders a sample of
     uint32_t state = has_pixel ? S2_MARCH_P : S2_DONE;
     PathRegs p;
+    GeomHit g_hit;                                                  // what closest_hit's acceptance found: the dword a lane waiting for the second room parks
+    g_hit.code = 0u;
     bool pending = false;                                           // a light sample is parked, its shadow ray not answered yet
     bool lit = false;                                               // ... answered: it got through
     bool ending = false;                                            // the path is over once the parked sample is resolved
@@ -68,11 +75,19 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
         RPT_PROF_ALIVE((uint32_t)__popcll(__ballot(state != S2_DONE)));
         if (__ballot(state == S2_BLOCKED) != 0ull) { if (state == S2_BLOCKED && share_my_turn(s_count, q, s)) state = S2_WAIT; }
         const uint32_t n_march = (uint32_t)__popcll(__ballot(state <= S2_MARCH_P));
-        const uint32_t n_wait = (uint32_t)__popcll(__ballot(state == S2_WAIT));
-        if (n_march == 0u && n_wait == 0u) break;
+        uint32_t n_wait = (uint32_t)__popcll(__ballot(state == S2_WAIT));
+        const uint32_t kShadeRoom = rp.shade_threshold;             // (>= 1: capi.hip)
+        bool run_shade_room = false;
+        {
+            const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == S2_SHADE));
+            if (n_march == 0u && n_wait == 0u && n_shade == 0u) break;
+            // the second room runs when it is full enough, or when nobody marches and nobody waits for the first part
+            run_shade_room = n_shade >= kShadeRoom || (n_shade != 0u && n_wait == 0u && n_march < rp.march_min_lanes);
+            if (run_shade_room) n_wait = n_shade;                   // (the phase decision below: "somebody waits for a block")
+        }
         const uint32_t own_started = share_handed_out(s_count);     // (every lane of the wave: who still has samples to hand out)
         const uint64_t needy = __ballot(own_started < rp.spp);
-        if (n_march >= rp.march_min_lanes || n_wait == 0u) {
+        if (!run_shade_room && (n_march >= rp.march_min_lanes || n_wait == 0u)) {
             // Nothing of a march is live in registers across the block: a marching lane takes its march from LDS here and puts it
             // back behind the loop (direction and origin are the path's ray or the parked shadow ray).
             // A lane that marches its shadow ray has a SECOND march waiting behind it, its path ray's.  Lanes with nothing to march
@@ -174,29 +189,33 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
                 p_done = (s_pjob[tid] & kPjobDone) != 0u;
                 if (state == S2_MARCH_P || s_over) state = (p_done || ending) ? S2_WAIT : S2_MARCH_P;
             }
-        } else if (state == S2_WAIT) {
+        } else if (state == (run_shade_room ? S2_SHADE : S2_WAIT)) {
             RPT_PROF(PB_SHADE);
-            if (pending) {                                          // last bounce's light sample: visible unless its march hit the object
-                if (lit) { const float4 gn = s_gain[tid]; p.radiance = p.radiance + mk3(gn.x, gn.y, gn.z); }
-                pending = false;
-            }
-            bool over = ending || blend_only;
-            ending = false;
-            if (!over) {
-                GeomHit g;
-                g.code = 0u;
-                // the finished march of the path's ray
-                const SdfDeferredQuery query{{(s_pjob[tid] & kPjobHit) != 0u, s_shd[tid].w}, AnalyticPre{s_gain[tid].w, rpt_f2u(s_march[tid].w)}};
-                const uint32_t what = path_trace_geom_split(sc, query, p, g);
-                if (what == 0u) { p.radiance = p.radiance + background(sc, p.ray) * p.throughput; over = true; }
-                else if (what == 1u) over = true;
-                else {
-                    // (pending comes back through the parked ray: the query marks it in the slot's direction.w)
-                    s_shd[tid].w = 1.0f;
-                    over = path_shade_full(sc, query, p, g, nullptr, nullptr, materials);
-                    pending = s_shd[tid].w == 0.0f;
+            bool over = false, shade_now = state == S2_SHADE, to_room = false;
+            // the finished march of the path's ray
+            const SdfDeferredQuery query{{(s_pjob[tid] & kPjobHit) != 0u, s_shd[tid].w}, AnalyticPre{s_gain[tid].w, rpt_f2u(s_march[tid].w)}};
+            if (!shade_now) {
+                if (pending) {                                      // last bounce's light sample: visible unless its march hit the object
+                    if (lit) { const float4 gn = s_gain[tid]; p.radiance = p.radiance + mk3(gn.x, gn.y, gn.z); }
+                    pending = false;
+                }
+                over = ending || blend_only;
+                ending = false;
+                if (!over) {
+                    g_hit.code = 0u;
+                    const uint32_t what = path_trace_geom_split(sc, query, p, g_hit);
+                    if (what == 0u) { p.radiance = p.radiance + background(sc, p.ray) * p.throughput; over = true; }
+                    else if (what == 1u) over = true;
+                    else { state = S2_SHADE; to_room = true; }      // the surface waits for its room
                 }
             }
+            if (shade_now) {
+                // (pending comes back through the parked ray: the query marks it in the slot's direction.w)
+                s_shd[tid].w = 1.0f;
+                over = path_shade_full(sc, query, p, g_hit, nullptr, nullptr, materials);
+                pending = s_shd[tid].w == 0.0f;
+            }
+            if (!to_room) {
             // what comes next for this lane: [the parked shadow ray] then the path's ray (or the end of the path)
             bool new_ray = !over;
             ending = pending && over;
@@ -237,6 +256,7 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
             if (pending) {
                 s_march[tid].x = 0.0f; s_march[tid].y = sdf_shadow_t_useful(sc, s_sho[tid].w); s_march[tid].z = rpt_u2f(0u);
                 state = S2_MARCH_S;
+            }
             }
         }
     }

@@ -16,6 +16,7 @@ struct Knobs {
     uint32_t shade_threshold = 56;       // RPT_SHADE_THRESHOLD      megakernels: SHADE runs when this many lanes wait for it
     uint32_t finish_threshold = 24;      // RPT_FINISH_THRESHOLD     small scenes' megakernel: ... FINISH (background, blend, next camera path)
     uint32_t sdf_march_min_lanes = 8;    // RPT_SDF_MARCH_MIN_LANES  SDF scenes: a wave keeps marching while this many lanes march
+    uint32_t sdf_shade_room = 40;        // RPT_SDF_SHADE_ROOM       SDF scenes: surface hits wait in a room of their own until this many lanes do
     // -- dispatch of a launch (rpt_set_dispatch overrides per context)
     uint32_t dispatch_order = 1;         // RPT_DISPATCH_ORDER       0 bottom rows first; 1 most expensive tile first; 2 costs recorded, order kept (development)
     uint32_t unit_rounds = 12;           // RPT_UNIT_ROUNDS          launches of fewer rounds of workgroups are cut into chunks of samples
@@ -49,6 +50,7 @@ inline Knobs read_knobs()
     v.shade_threshold = knob_lanes("RPT_SHADE_THRESHOLD", v.shade_threshold);
     v.finish_threshold = knob_lanes("RPT_FINISH_THRESHOLD", v.finish_threshold);
     v.sdf_march_min_lanes = knob_lanes("RPT_SDF_MARCH_MIN_LANES", v.sdf_march_min_lanes);
+    v.sdf_shade_room = knob_lanes("RPT_SDF_SHADE_ROOM", v.sdf_shade_room);
     v.dispatch_order = knob_u32("RPT_DISPATCH_ORDER", v.dispatch_order);
     v.unit_rounds = knob_u32("RPT_UNIT_ROUNDS", v.unit_rounds);
     v.unit_min_spp = knob_u32("RPT_UNIT_MIN_SPP", v.unit_min_spp);

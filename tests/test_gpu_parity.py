@@ -489,6 +489,30 @@ def test_sdf_marches_handed_between_lanes_in_partly_filled_waves(rpt, oracle, w,
         assert_bit_identical(buf.image(), want, "sdf scene %dx%d x %d spp, use_max=%s %s" % (w, h, spp + 2, use_max, env))
 
 
+@pytest.mark.parametrize("room,min_lanes", [(1, 8), (17, 3), (40, 1), (64, 8), (64, 64)])
+def test_sdf_second_room_at_its_ends(rpt, oracle, room, min_lanes):
+    """The SDF march kernel cuts its block behind closest_hit's acceptance: surface hits wait in a room of their own until
+    RPT_SDF_SHADE_ROOM lanes do (default 40; k_sdf.hip), beside the march phases' own minimum (RPT_SDF_MARCH_MIN_LANES).  Neither knob
+    can change a pixel — they decide WHEN a lane's next block runs — at their ends least of all: a room that fires for one lane, one
+    that needs the whole wave (and therefore mostly fires because nobody else can go on), march phases of one lane or of none below 64."""
+    from rust_pathtracer_amd import scenes
+    s = scenes.sdf_scene()
+    w, h, spp = 83, 45, 7
+    old = {k: os.environ.get(k) for k in ("RPT_SDF_SHADE_ROOM", "RPT_SDF_MARCH_MIN_LANES")}
+    os.environ.update(RPT_SDF_SHADE_ROOM=str(room), RPT_SDF_MARCH_MIN_LANES=str(min_lanes))
+    rpt.lib().rpt_debug_reload_knobs()
+    try:
+        t = rpt.Tracer(s, device=0, seed=23)
+        buf = rpt.ColorBuffer(w, h)
+        t.render_n(buf, spp)
+        t.close()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        rpt.lib().rpt_debug_reload_knobs()
+    assert_bit_identical(buf.image(), oracle.render(s.describe(), w, h, spp, seed=23), "sdf scene, second room at %d lanes, march phases of >= %d" % (room, min_lanes))
+
+
 def _with_ground_sphere(s, where):
     """The classic r = 1000 ground sphere in a field of small ones: far beyond 8 x the median radius, so the grid keeps it out
     and every walk tests it up front (host_scene.h, pick_oversize) — as sphere 0 (the unconditional first test of
