@@ -2,12 +2,12 @@
 // Built with the range tests next to every operation (kernel_common.h).
 #include "kernel_common.h"
 
-// SDF scenes, two rooms (dev_sdf_path.h, SdfDeferredQuery).  Per lane:
-//   [MARCH_S: the parked shadow ray of the bounce just shaded] -> MARCH_P: the path ray -> WAIT -> one block: add the parked light
-//   sample if its ray got through; finish closest_hit; miss / emitter / path over -> blend, the pixel's next sample; surface ->
-//   material, light sample (parked), BSDF, next ray -> the marches again.
-// Per wave each pass either marches (while at least `march_min_lanes` lanes are marching, or nobody waits) or runs the block
-// for the lanes that wait.
+// SDF scenes (dev_sdf_path.h, SdfDeferredQuery).  Per lane:
+//   [MARCH_S: the parked shadow ray of the bounce just shaded] -> MARCH_P: the path ray -> WAIT -> first block: add the parked light
+//   sample if its ray got through; finish closest_hit; miss / emitter / path over -> blend, the pixel's next sample -> the marches
+//   again; surface -> SHADE (the second room) -> second block: material, light sample (parked), BSDF, next ray -> the marches again.
+// Per wave each pass either marches (while at least `march_min_lanes` lanes are marching, or nobody waits) or runs ONE of the two
+// blocks between marches for the lanes that wait for it (round 6: below, S2_SHADE).
 // A lane whose pixel has no sample left takes samples of another pixel of its wave (kernel_common.h, share_next; `q`: the pixel a lane
 // works for); a sample that is finished before its predecessor has been blended waits in S2_BLOCKED.
 enum : uint32_t { S2_MARCH_S = 0u, S2_MARCH_P = 1u, S2_WAIT = 2u, S2_DONE = 3u, S2_BLOCKED = 4u, S2_SHADE = 5u };
@@ -76,13 +76,13 @@ RPT_DEV void render_sdf_march2_body(const S& sc, const RenderParams& launch, con
         if (__ballot(state == S2_BLOCKED) != 0ull) { if (state == S2_BLOCKED && share_my_turn(s_count, q, s)) state = S2_WAIT; }
         const uint32_t n_march = (uint32_t)__popcll(__ballot(state <= S2_MARCH_P));
         uint32_t n_wait = (uint32_t)__popcll(__ballot(state == S2_WAIT));
-        const uint32_t kShadeRoom = rp.shade_threshold;             // (>= 1: capi.hip)
+        const uint32_t shade_room = rp.shade_threshold;             // (>= 1: capi.hip)
         bool run_shade_room = false;
         {
             const uint32_t n_shade = (uint32_t)__popcll(__ballot(state == S2_SHADE));
             if (n_march == 0u && n_wait == 0u && n_shade == 0u) break;
             // the second room runs when it is full enough, or when nobody marches and nobody waits for the first part
-            run_shade_room = n_shade >= kShadeRoom || (n_shade != 0u && n_wait == 0u && n_march < rp.march_min_lanes);
+            run_shade_room = n_shade >= shade_room || (n_shade != 0u && n_wait == 0u && n_march < rp.march_min_lanes);
             if (run_shade_room) n_wait = n_shade;                   // (the phase decision below: "somebody waits for a block")
         }
         const uint32_t own_started = share_handed_out(s_count);     // (every lane of the wave: who still has samples to hand out)
