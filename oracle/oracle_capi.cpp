@@ -143,6 +143,24 @@ int oracle_render_flags(const rpt_scene_desc* desc, float* pixels, uint32_t widt
     return 0;
 }
 
+// The same for a LIST of rows (each row one task, like the reference's scanline tasks, tracer.rs:29-32): what a bounded sample of a large
+// frame spread evenly over it costs (bench.py, f64_reference).  Rows are independent of each other, so the pixels are oracle_render's.
+int oracle_render_rows(const rpt_scene_desc* desc, float* pixels, uint32_t width, uint32_t height, uint64_t frames_done, uint32_t spp,
+                       uint64_t seed, const uint32_t* rows, uint32_t n_rows, int nthreads, uint32_t render_flags)
+{
+    if (!desc || !pixels || !rows || width == 0 || height == 0) return -1;
+    for (uint32_t i = 0; i < n_rows; ++i) if (rows[i] >= height) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    Scene scene(*desc);
+    Tracer tracer(scene);
+    tracer.russian_roulette = (render_flags & RPT_RENDER_RUSSIAN_ROULETTE) != 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t i = 0; i < (int64_t)n_rows; ++i) tracer.render(pixels, width, height, frames_done, spp, seed, rows[i], rows[i] + 1u);
+    return 0;
+}
+
 // Radiance of single pixel-samples (no accumulation): out[3*k..] for k-th (col,row,frame).
 int oracle_sample_pixels(const rpt_scene_desc* desc, const uint32_t* cols, const uint32_t* rows, const uint64_t* frames,
                          uint64_t n, uint32_t width, uint32_t height, uint64_t seed, float* out)

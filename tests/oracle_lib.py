@@ -68,6 +68,19 @@ class Oracle:
         assert rc == 0
         return pixels
 
+    def render_rows(self, desc, width, height, spp, rows, seed=1, frames_done=0, pixels=None, threads=0, render_flags=0):
+        """Tracer::render for the listed rows only (one task per row): the pixels oracle.render gives for them."""
+        if pixels is None:
+            pixels = np.zeros((height, width, 4), dtype=np.float32)
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        if threads <= 0:
+            threads = max(1, min(len(rows), 16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 16))
+        self.lib.oracle_render_rows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64,
+                                                C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
+        rc = self.lib.oracle_render_rows(C.byref(desc), pixels.ctypes.data, width, height, frames_done, spp, seed, rows.ctypes.data, len(rows), threads, render_flags)
+        assert rc == 0
+        return pixels
+
     def probe_fn(self, fn, records, cam=None, params=None):
         """include/rpt.h rpt_probe_fn's record layouts through the oracle: records [n, 32] f32 -> [n, 16] f32."""
         A = _abi()
