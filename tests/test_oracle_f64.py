@@ -62,3 +62,18 @@ def test_f64_progressive_calls_continue_the_mean(oracle_f64):
     two = oracle_f64.render(desc, w, h, 3, seed=2)
     two = oracle_f64.render(desc, w, h, 3, seed=2, frames_done=3, pixels=two)
     assert np.abs(_diff(one, two)).max() < 1e-6
+
+
+def test_render_rows_is_render(oracle, oracle_f64):
+    """oracle_render_rows (a list of rows, one task each: what bench.py's f64_reference samples a large frame with) gives the pixels
+    oracle_render gives for those rows, and touches no other row."""
+    w, h, spp = 96, 60, 5
+    rows = np.arange(1, h, 3, dtype=np.uint32)
+    for o in (oracle, oracle_f64):
+        d = o.scene_analytical()
+        whole = o.render(d, w, h, spp, seed=3)
+        some = o.render_rows(d, w, h, spp, rows, seed=3)
+        assert np.array_equal(whole[rows].view(np.uint32), some[rows].view(np.uint32))
+        rest = np.ones(h, dtype=bool)
+        rest[rows] = False
+        assert not some[rest].any()
